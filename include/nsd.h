@@ -1,0 +1,160 @@
+/*
+ * nsd.h -- C ABI of libnsd_hip.so: the MI355X (gfx950) implementation of the
+ * EEG_LSTM hot path of aa217/Neural-Speech-Decoding.
+ *
+ * The reference has NO native interface: its hot path is a torch nn.Module
+ * (Neuro-Alpha-App/Utilities/lstm_eeg_model.py:13-39) called through
+ * SimplePredictor.predict (lstm_eeg_model.py:86-101).  Each entry point below
+ * names the reference lines whose arithmetic it replaces; the Python facade in
+ * neural-speech-decoding_amd/ binds them with ctypes (INTEGRATION.md shows the
+ * stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C symbols, no C++/torch types; every function returns int:
+ *     0 = ok, <0 = error (NSD_E_*); nsd_last_error() gives thread-local text.
+ *   - the CALLER owns every buffer.  All pointers are DEVICE pointers (fp32
+ *     unless stated) valid on the current HIP device; the library allocates
+ *     nothing and never synchronises: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the legacy default stream).
+ *   - re-entrant per stream; kernels are deterministic (no float atomics).
+ *   - shapes: B trials, T time steps, C channels, H hidden, L layers,
+ *     K classes, F = width of the first dense layer (32 in the reference).
+ *
+ * Flat parameter vector (same order as the reference state_dict, so the
+ * reference .pth maps 1:1; see nsd_param_layout):
+ *   for l in 0..L-1: lstm.weight_ih_l{l}[4H,I_l] lstm.weight_hh_l{l}[4H,H]
+ *                    lstm.bias_ih_l{l}[4H] lstm.bias_hh_l{l}[4H]   (I_0=C, I_l=H)
+ *   ln.weight[H] ln.bias[H] attn.weight[H] attn.bias[1]
+ *   fc.0.weight[F,H] fc.0.bias[F] fc.3.weight[K,F] fc.3.bias[K]
+ */
+#ifndef NSD_H
+#define NSD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSD_VERSION 100          /* 0.1.0 */
+#define NSD_MAX_LAYERS 8
+
+#define NSD_OK            0
+#define NSD_E_INVALID    -1      /* bad argument / unsupported shape */
+#define NSD_E_LAUNCH     -2      /* HIP launch or runtime error */
+#define NSD_E_WORKSPACE  -3      /* workspace too small */
+
+/* flags */
+#define NSD_FLAG_RESIDUAL   1u   /* extension (not in the reference): out_l = LSTM_l(in_l) + in_l, l>=1 */
+#define NSD_FLAG_TRAIN      2u   /* keep activations in the workspace for nsd_*_bwd */
+
+typedef struct nsd_dims {
+    int32_t B, T, C, H, L, K, F;
+} nsd_dims;
+
+/* word offsets (units of float) of the regions inside the training workspace */
+typedef struct nsd_ws_layout {
+    int64_t hseq;      /* [L,B,T,H]   h_t of every layer (LSTM's own output)          */
+    int64_t cseq;      /* [L,B,T,H]   c_t                                              */
+    int64_t gact;      /* [L,B,T,H,4] activated gates, unit-major: (i,f,g,o) per unit  */
+    int64_t inseq;     /* [L-1,B,T,H] input fed to layer l+1 (after residual+dropout)  */
+    int64_t top;       /* [B,T,H]     sequence fed to attention (== hseq[L-1] unless residual) */
+    int64_t alpha;     /* [B,T]       attention weights                                */
+    int64_t pooled;    /* [B,H]                                                        */
+    int64_t fc0_pre;   /* [B,F]       pre-activation of fc.0                           */
+    int64_t dscore;    /* [B,T]       d loss / d attention score  (head_bwd -> lstm_bwd) */
+    int64_t dpooled;   /* [B,H]       d loss / d pooled           (head_bwd -> lstm_bwd) */
+    int64_t loss;      /* [B]         per-trial CE loss                                */
+    int64_t slabs;     /* [n_slabs,P_lstm] per-workgroup partial gradients of the LSTM stack */
+    int64_t n_slabs;
+    int64_t hslabs;    /* [B,P_head]  per-trial gradients of ln/attn/fc                  */
+    int64_t total;     /* floats */
+} nsd_ws_layout;
+
+int         nsd_version(void);
+const char *nsd_last_error(void);
+
+/* number of floats in the flat parameter vector; <0 on bad dims */
+int64_t nsd_param_count(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F);
+/* offsets[4L+8]: per layer w_ih,w_hh,b_ih,b_hh; then ln.w ln.b attn.w attn.b fc0.w fc0.b fc3.w fc3.b */
+int     nsd_param_layout(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int64_t *offsets);
+
+/* workspace needed by the train-mode calls for these dims, in BYTES; layout optional */
+int64_t nsd_workspace_bytes(const nsd_dims *d, nsd_ws_layout *layout_out);
+
+/* 1 if the fused register-resident kernels cover these dims (H in {32,48,64}, L==2, C<=8), else 0 (generic path) */
+int     nsd_fast_path(const nsd_dims *d);
+
+/*
+ * Per-channel z-score over time, y = (x - mean_T) / (std_T(ddof=0) + 1e-6).
+ * Replaces normalize_eeg, Neuro-Alpha-App/Frontend/app.py:166-170.  x,y [B,T,C]; in-place allowed.
+ */
+int nsd_zscore_fwd(const float *x, float *y, int32_t B, int32_t T, int32_t C, void *stream);
+
+/*
+ * Inference: x[B,T,C] -> logits[B,K] (+ probs[B,K] if non-NULL).
+ * Replaces EEG_LSTM.forward in eval mode (lstm_eeg_model.py:32-39) and the class
+ * softmax of SimplePredictor.predict (lstm_eeg_model.py:97).
+ * scratch: device buffer of nsd_infer_scratch_bytes(d) bytes.
+ */
+int64_t nsd_infer_scratch_bytes(const nsd_dims *d);
+int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t flags,
+              float *logits, float *probs, void *scratch, void *stream);
+
+/*
+ * Stacked LSTM forward (lstm_eeg_model.py:34, self.lstm(x)), train mode.
+ * drop_lstm: NULL, or multiplier masks [L-1,B,T,H] (0 or 1/(1-p)) applied to the output of every
+ *            layer but the last (nn.LSTM(dropout=p), lstm_eeg_model.py:21).
+ * Fills hseq/cseq/gact/inseq/top of the workspace.
+ */
+int nsd_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
+                 uint32_t flags, float *workspace, void *stream);
+
+/*
+ * Head forward: attention pooling over time, LayerNorm, fc (lstm_eeg_model.py:35-39),
+ * optional class softmax (lstm_eeg_model.py:97).  Reads `top` from the workspace.
+ * rrelu_slope: NULL -> eval slope (lower+upper)/2, else per-element slopes [B,F] (train-mode RReLU noise)
+ * drop_head:   NULL or multiplier mask [B,F] (nn.Dropout, lstm_eeg_model.py:28)
+ */
+int nsd_head_fwd(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
+                 float *workspace, float *logits, float *probs, void *stream);
+
+/*
+ * Head backward.  Either dlogits[B,K] is given, or labels[B] (int32) with `scale`:
+ * then dlogits = (softmax(logits) - onehot(label)) * scale (mean CE when scale = 1/B_global) and the
+ * per-trial CE loss is written to the workspace's `loss` region.  Writes dscore/dpooled for
+ * nsd_lstm_bwd and the head's partial gradients into the slabs.
+ */
+int nsd_head_bwd(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
+                 const float *logits, const float *dlogits, const int32_t *labels, float scale,
+                 float *workspace, void *stream);
+
+/*
+ * Stacked LSTM backward (BPTT) through lstm_eeg_model.py:34 with the activations kept by nsd_lstm_fwd.
+ * Partial gradients go to the slabs.  dx: NULL or [B,T,C].
+ */
+int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
+                 uint32_t flags, float *workspace, float *dx, void *stream);
+
+/* grads[P] (=|+=) sum over slabs.  accumulate: 0 overwrite, 1 add to existing. */
+int nsd_grad_reduce(const nsd_dims *d, const float *workspace, float *grads, int32_t accumulate, void *stream);
+
+/* sum of the per-trial losses written by nsd_head_bwd -> out[0] (device) */
+int nsd_loss_sum(const nsd_dims *d, const float *workspace, float *out, void *stream);
+
+/* torch.optim.Adam semantics (no amsgrad); step counted from 1; all vectors length n */
+int nsd_adam_step(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float grad_scale, int32_t step, void *stream);
+
+/*
+ * Counter-based random streams of the trainer (the reference's training RNG is torch's and is not
+ * portable): value(seed, stream, index) is a pure function, identical in oracle/nsd_oracle.c.
+ *   nsd_dropout_mask: out[i] = keep ? 1/(1-p) : 0       nsd_rrelu_noise: out[i] ~ U(1/8, 1/3)
+ */
+int nsd_dropout_mask(uint64_t seed, uint32_t stream_id, float p, int64_t n, float *out, void *stream);
+int nsd_rrelu_noise(uint64_t seed, uint32_t stream_id, int64_t n, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSD_H */

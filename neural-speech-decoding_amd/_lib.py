@@ -1,0 +1,88 @@
+"""ctypes binding of libnsd_hip.so (C ABI: include/nsd.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback.  If the shared object is
+missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsd_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+NSD_FLAG_RESIDUAL = 1
+NSD_FLAG_TRAIN = 2
+
+
+class NsdError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "T", "C", "H", "L", "K", "F")]
+
+
+class WsLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("hseq", "cseq", "gact", "inseq", "top", "alpha", "pooled", "fc0_pre",
+                                          "dscore", "dpooled", "loss", "slabs", "n_slabs", "hslabs", "total")]
+
+
+# every symbol include/nsd.h declares: name -> (restype, argtypes)
+_fp, _vp, _ip = C.c_void_p, C.c_void_p, C.c_void_p   # device pointers travel as integers
+_dp = C.POINTER(Dims)
+SYMBOLS = {
+    "nsd_version": (C.c_int, []),
+    "nsd_last_error": (C.c_char_p, []),
+    "nsd_param_count": (C.c_int64, [C.c_int32] * 5),
+    "nsd_param_layout": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int64)]),
+    "nsd_workspace_bytes": (C.c_int64, [_dp, C.POINTER(WsLayout)]),
+    "nsd_fast_path": (C.c_int, [_dp]),
+    "nsd_zscore_fwd": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "nsd_infer_scratch_bytes": (C.c_int64, [_dp]),
+    "nsd_infer": (C.c_int, [_dp, _fp, _fp, C.c_uint32, _fp, _fp, _vp, _vp]),
+    "nsd_lstm_fwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, _vp]),
+    "nsd_head_fwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
+    "nsd_head_bwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, _fp, _vp]),
+    "nsd_lstm_bwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, _fp, _vp]),
+    "nsd_grad_reduce": (C.c_int, [_dp, _fp, _fp, C.c_int32, _vp]),
+    "nsd_loss_sum": (C.c_int, [_dp, _fp, _fp, _vp]),
+    "nsd_adam_step": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [C.c_int32, _vp]),
+    "nsd_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint32, C.c_float, C.c_int64, _fp, _vp]),
+    "nsd_rrelu_noise": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int64, _fp, _vp]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 with hipcc into libnsd_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "nsd.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libnsd_hip.so; raise loudly when it is absent (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NsdError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)        # AttributeError if the ABI and the header ever diverge
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise NsdError(f"{what} failed (rc={rc}): {lib().nsd_last_error().decode(errors='replace')}")

@@ -1,0 +1,327 @@
+// nsd_abi.hip -- extern "C" entry points of libnsd_hip.so (declared in include/nsd.h).
+// Argument validation, parameter / workspace layout, kernel dispatch.  No allocation, no synchronisation.
+#include <stdarg.h>
+#include <string.h>
+#include "nsd_args.h"
+
+// ---- error text -------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void nsd_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int nsd_num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        else
+            cus = 256;   // MI355X
+    }
+    return cus;
+}
+
+ParamLayout nsd_make_layout(int C, int H, int L, int K, int F) {
+    ParamLayout o;
+    memset(&o, 0, sizeof(o));
+    int64_t p = 0;
+    for (int l = 0; l < L; ++l) {
+        const int I = l == 0 ? C : H;
+        o.w_ih[l] = p; p += 4LL * H * I;
+        o.w_hh[l] = p; p += 4LL * H * H;
+        o.b_ih[l] = p; p += 4LL * H;
+        o.b_hh[l] = p; p += 4LL * H;
+    }
+    o.lstm_total = p;
+    o.ln_w = p; p += H;   o.ln_b = p; p += H;
+    o.attn_w = p; p += H; o.attn_b = p; p += 1;
+    o.fc0_w = p; p += (int64_t)F * H; o.fc0_b = p; p += F;
+    o.fc3_w = p; p += (int64_t)K * F; o.fc3_b = p; p += K;
+    o.total = p;
+    return o;
+}
+
+static int check_model(int C, int H, int L, int K, int F) {
+    if (C < 1 || H < 1 || L < 1 || L > NSD_MAX_LAYERS || K < 1 || F < 1) {
+        nsd_set_error("bad model dims C=%d H=%d L=%d K=%d F=%d", C, H, L, K, F);
+        return NSD_E_INVALID;
+    }
+    return NSD_OK;
+}
+int nsd_check_dims(const nsd_dims *d) {
+    if (!d) { nsd_set_error("dims is NULL"); return NSD_E_INVALID; }
+    if (d->B < 0 || d->T < 1) { nsd_set_error("bad batch dims B=%d T=%d", d->B, d->T); return NSD_E_INVALID; }
+    return check_model(d->C, d->H, d->L, d->K, d->F);
+}
+
+static inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+
+static nsd_ws_layout make_ws(const nsd_dims *d, bool have_device) {
+    nsd_ws_layout w;
+    memset(&w, 0, sizeof(w));
+    const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+    const int64_t B = d->B, T = d->T, H = d->H, L = d->L, F = d->F;
+    int64_t p = 0;
+    w.hseq = p;    p = align4(p + L * B * T * H);
+    w.cseq = p;    p = align4(p + L * B * T * H);
+    w.gact = p;    p = align4(p + L * B * T * H * 4);
+    w.inseq = p;   p = align4(p + (L - 1) * B * T * H);
+    w.top = p;     p = align4(p + B * T * H);
+    w.alpha = p;   p = align4(p + B * T);
+    w.pooled = p;  p = align4(p + B * H);
+    w.fc0_pre = p; p = align4(p + B * F);
+    w.dscore = p;  p = align4(p + B * T);
+    w.dpooled = p; p = align4(p + B * H);
+    w.loss = p;    p = align4(p + B);
+    // LSTM slabs: one per backward workgroup (<= #CUs); head slabs: one per trial, stored behind them.
+    // Without a device (symbol / layout checks on CPU) assume the MI355X's 256 CUs.
+    int64_t nsl = B < 256 ? B : 256;
+    if (have_device) nsl = nsd_lstm2_bwd_grid((int)B);
+    if (nsl < 1) nsl = 1;
+    w.n_slabs = nsl;
+    w.slabs = p;   p = align4(p + nsl * align4(pl.lstm_total));
+    w.hslabs = p;  p = align4(p + B * (pl.total - pl.lstm_total));
+    w.total = p;
+    return w;
+}
+
+static bool device_present() {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+static int fast_path_ok(const nsd_dims *d) {
+    return d->L == 2 && (d->H == 32 || d->H == 48 || d->H == 64) && d->C <= 8;
+}
+
+extern "C" {
+
+int nsd_version(void) { return NSD_VERSION; }
+const char *nsd_last_error(void) { return g_err; }
+
+int64_t nsd_param_count(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F) {
+    if (check_model(C, H, L, K, F) != NSD_OK) return NSD_E_INVALID;
+    return nsd_make_layout(C, H, L, K, F).total;
+}
+
+int nsd_param_layout(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int64_t *offsets) {
+    if (check_model(C, H, L, K, F) != NSD_OK || !offsets) return NSD_E_INVALID;
+    const ParamLayout o = nsd_make_layout(C, H, L, K, F);
+    for (int l = 0; l < L; ++l) {
+        offsets[4 * l + 0] = o.w_ih[l]; offsets[4 * l + 1] = o.w_hh[l];
+        offsets[4 * l + 2] = o.b_ih[l]; offsets[4 * l + 3] = o.b_hh[l];
+    }
+    int64_t *q = offsets + 4 * L;
+    q[0] = o.ln_w; q[1] = o.ln_b; q[2] = o.attn_w; q[3] = o.attn_b;
+    q[4] = o.fc0_w; q[5] = o.fc0_b; q[6] = o.fc3_w; q[7] = o.fc3_b;
+    return NSD_OK;
+}
+
+int64_t nsd_workspace_bytes(const nsd_dims *d, nsd_ws_layout *layout_out) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    const nsd_ws_layout w = make_ws(d, device_present());
+    if (layout_out) *layout_out = w;
+    return w.total * (int64_t)sizeof(float);
+}
+
+int nsd_fast_path(const nsd_dims *d) {
+    if (nsd_check_dims(d) != NSD_OK) return 0;
+    return fast_path_ok(d);
+}
+
+int nsd_zscore_fwd(const float *x, float *y, int32_t B, int32_t T, int32_t C, void *stream) {
+    if (!x || !y || B < 0) { nsd_set_error("zscore: null pointer or B<0"); return NSD_E_INVALID; }
+    return nsd_zscore_launch(x, y, B, T, C, (hipStream_t)stream);
+}
+
+// ---- shared argument builders -----------------------------------------------------------------------------
+static int build_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
+                          uint32_t flags, float *ws, const nsd_ws_layout &w, bool train, float *top_only,
+                          Lstm2FwdArgs *out) {
+    const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+    Lstm2FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.w_ih0 = params + pl.w_ih[0]; a.w_hh0 = params + pl.w_hh[0]; a.b_ih0 = params + pl.b_ih[0]; a.b_hh0 = params + pl.b_hh[0];
+    a.w_ih1 = params + pl.w_ih[1]; a.w_hh1 = params + pl.w_hh[1]; a.b_ih1 = params + pl.b_ih[1]; a.b_hh1 = params + pl.b_hh[1];
+    a.mask = drop_lstm;
+    a.B = d->B; a.T = d->T; a.C = d->C;
+    a.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
+    const int64_t BTH = (int64_t)d->B * d->T * d->H;
+    if (train) {
+        a.hseq0 = ws + w.hseq; a.hseq1 = ws + w.hseq + BTH;
+        a.cseq0 = ws + w.cseq; a.cseq1 = ws + w.cseq + BTH;
+        a.gact0 = ws + w.gact; a.gact1 = ws + w.gact + 4 * BTH;
+        a.inseq = ws + w.inseq;
+        a.top = ws + w.top;
+    } else {
+        a.top = top_only;
+    }
+    *out = a;
+    return NSD_OK;
+}
+
+static HeadArgs build_head(const nsd_dims *d, const float *params) {
+    const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+    HeadArgs h;
+    memset(&h, 0, sizeof(h));
+    h.ln_w = params + pl.ln_w; h.ln_b = params + pl.ln_b; h.attn_w = params + pl.attn_w; h.attn_b = params + pl.attn_b;
+    h.fc0_w = params + pl.fc0_w; h.fc0_b = params + pl.fc0_b; h.fc3_w = params + pl.fc3_w; h.fc3_b = params + pl.fc3_b;
+    h.eval_slope = (float)((0.125 + 1.0 / 3.0) / 2.0);   // nn.RReLU eval slope, lstm_eeg_model.py:27
+    h.o_ln_w = pl.ln_w - pl.lstm_total; h.o_ln_b = pl.ln_b - pl.lstm_total;
+    h.o_attn_w = pl.attn_w - pl.lstm_total; h.o_attn_b = pl.attn_b - pl.lstm_total;
+    h.o_fc0_w = pl.fc0_w - pl.lstm_total; h.o_fc0_b = pl.fc0_b - pl.lstm_total;
+    h.o_fc3_w = pl.fc3_w - pl.lstm_total; h.o_fc3_b = pl.fc3_b - pl.lstm_total;
+    h.Ph = pl.total - pl.lstm_total;
+    h.B = d->B; h.T = d->T; h.H = d->H; h.F = d->F; h.K = d->K;
+    return h;
+}
+
+#define REQUIRE_FAST(d, name)                                                                              \
+    do {                                                                                                   \
+        if (!fast_path_ok(d)) {                                                                            \
+            nsd_set_error("%s: dims C=%d H=%d L=%d not covered yet (fast path: L==2, H in {32,48,64}, C<=8)", \
+                          name, (d)->C, (d)->H, (d)->L);                                                   \
+            return NSD_E_INVALID;                                                                          \
+        }                                                                                                  \
+    } while (0)
+
+int64_t nsd_infer_scratch_bytes(const nsd_dims *d) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    return align4((int64_t)d->B * d->T * d->H) * (int64_t)sizeof(float);
+}
+
+int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t flags, float *logits, float *probs,
+              void *scratch, void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!params || !x || !logits || !scratch) { nsd_set_error("infer: null pointer"); return NSD_E_INVALID; }
+    REQUIRE_FAST(d, "nsd_infer");
+    if (d->B == 0) return NSD_OK;
+    nsd_ws_layout w;
+    memset(&w, 0, sizeof(w));
+    Lstm2FwdArgs a;
+    build_lstm_fwd(d, params, x, nullptr, flags, nullptr, w, false, (float *)scratch, &a);
+    int rc = nsd_lstm2_fwd_launch(a, d->H, (hipStream_t)stream);
+    if (rc != NSD_OK) return rc;
+    HeadArgs h = build_head(d, params);
+    h.top = (const float *)scratch;
+    h.logits = logits; h.probs = probs;
+    return nsd_head_launch(h, false, (hipStream_t)stream);
+}
+
+int nsd_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, uint32_t flags,
+                 float *workspace, void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!params || !x || !workspace) { nsd_set_error("lstm_fwd: null pointer"); return NSD_E_INVALID; }
+    REQUIRE_FAST(d, "nsd_lstm_fwd");
+    if (d->B == 0) return NSD_OK;
+    const nsd_ws_layout w = make_ws(d, true);
+    Lstm2FwdArgs a;
+    build_lstm_fwd(d, params, x, drop_lstm, flags, workspace, w, true, nullptr, &a);
+    return nsd_lstm2_fwd_launch(a, d->H, (hipStream_t)stream);
+}
+
+int nsd_head_fwd(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
+                 float *workspace, float *logits, float *probs, void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!params || !workspace || !logits) { nsd_set_error("head_fwd: null pointer"); return NSD_E_INVALID; }
+    if (d->B == 0) return NSD_OK;
+    const nsd_ws_layout w = make_ws(d, true);
+    HeadArgs h = build_head(d, params);
+    h.top = workspace + w.top;
+    h.rrelu_slope = rrelu_slope; h.drop_head = drop_head;
+    h.logits = logits; h.probs = probs;
+    h.alpha = workspace + w.alpha; h.pooled = workspace + w.pooled; h.fc0_pre = workspace + w.fc0_pre;
+    return nsd_head_launch(h, false, (hipStream_t)stream);
+}
+
+int nsd_head_bwd(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
+                 const float *logits, const float *dlogits, const int32_t *labels, float scale, float *workspace,
+                 void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!params || !workspace) { nsd_set_error("head_bwd: null pointer"); return NSD_E_INVALID; }
+    if (!dlogits && !(labels && logits)) {
+        nsd_set_error("head_bwd: need dlogits, or labels together with logits");
+        return NSD_E_INVALID;
+    }
+    if (d->B == 0) return NSD_OK;
+    const nsd_ws_layout w = make_ws(d, true);
+    HeadArgs h = build_head(d, params);
+    h.top = workspace + w.top;
+    h.rrelu_slope = rrelu_slope; h.drop_head = drop_head;
+    h.alpha = workspace + w.alpha; h.pooled = workspace + w.pooled; h.fc0_pre = workspace + w.fc0_pre;
+    h.logits_in = logits; h.dlogits = dlogits; h.labels = labels; h.scale = scale;
+    h.loss = workspace + w.loss; h.dscore = workspace + w.dscore; h.dpooled = workspace + w.dpooled;
+    h.hslabs = workspace + w.hslabs;
+    return nsd_head_launch(h, true, (hipStream_t)stream);
+}
+
+int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, uint32_t flags,
+                 float *workspace, float *dx, void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!params || !x || !workspace) { nsd_set_error("lstm_bwd: null pointer"); return NSD_E_INVALID; }
+    REQUIRE_FAST(d, "nsd_lstm_bwd");
+    if (dx) { nsd_set_error("lstm_bwd: dx (gradient w.r.t. the EEG window) is not implemented"); return NSD_E_INVALID; }
+    if (d->B == 0) return NSD_OK;
+    const nsd_ws_layout w = make_ws(d, true);
+    const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+    const int64_t BTH = (int64_t)d->B * d->T * d->H;
+    Lstm2BwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.w_hh0 = params + pl.w_hh[0]; a.w_ih1 = params + pl.w_ih[1]; a.w_hh1 = params + pl.w_hh[1];
+    a.attn_w = params + pl.attn_w;
+    a.mask = drop_lstm;
+    a.hseq0 = workspace + w.hseq; a.hseq1 = workspace + w.hseq + BTH;
+    a.cseq0 = workspace + w.cseq; a.cseq1 = workspace + w.cseq + BTH;
+    a.gact0 = workspace + w.gact; a.gact1 = workspace + w.gact + 4 * BTH;
+    a.in1seq = workspace + w.inseq;
+    a.alpha = workspace + w.alpha; a.dscore = workspace + w.dscore; a.dpooled = workspace + w.dpooled;
+    a.slabs = workspace + w.slabs;
+    a.slab_stride = align4(pl.lstm_total);
+    a.o_w_ih0 = pl.w_ih[0]; a.o_w_hh0 = pl.w_hh[0]; a.o_b_ih0 = pl.b_ih[0]; a.o_b_hh0 = pl.b_hh[0];
+    a.o_w_ih1 = pl.w_ih[1]; a.o_w_hh1 = pl.w_hh[1]; a.o_b_ih1 = pl.b_ih[1]; a.o_b_hh1 = pl.b_hh[1];
+    a.B = d->B; a.T = d->T; a.C = d->C;
+    a.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
+    return nsd_lstm2_bwd_launch(a, d->H, (hipStream_t)stream);
+}
+
+int nsd_grad_reduce(const nsd_dims *d, const float *workspace, float *grads, int32_t accumulate, void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!workspace || !grads) { nsd_set_error("grad_reduce: null pointer"); return NSD_E_INVALID; }
+    const nsd_ws_layout w = make_ws(d, true);
+    const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+    return nsd_grad_reduce_launch(workspace + w.slabs, align4(pl.lstm_total), d->B > 0 ? (int)w.n_slabs : 0, pl.lstm_total,
+                                  workspace + w.hslabs, pl.total - pl.lstm_total, d->B, grads, accumulate,
+                                  (hipStream_t)stream);
+}
+
+int nsd_loss_sum(const nsd_dims *d, const float *workspace, float *out, void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!workspace || !out) { nsd_set_error("loss_sum: null pointer"); return NSD_E_INVALID; }
+    const nsd_ws_layout w = make_ws(d, true);
+    return nsd_loss_sum_launch(workspace + w.loss, d->B, out, (hipStream_t)stream);
+}
+
+int nsd_adam_step(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float grad_scale, int32_t step, void *stream) {
+    if (n < 0 || !p || !g || !m || !v) { nsd_set_error("adam: null pointer or n<0"); return NSD_E_INVALID; }
+    return nsd_adam_launch(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step, (hipStream_t)stream);
+}
+
+int nsd_dropout_mask(uint64_t seed, uint32_t stream_id, float p, int64_t n, float *out, void *stream) {
+    if (n < 0 || !out) { nsd_set_error("dropout_mask: null pointer or n<0"); return NSD_E_INVALID; }
+    return nsd_dropout_mask_launch(seed, stream_id, p, n, out, (hipStream_t)stream);
+}
+
+int nsd_rrelu_noise(uint64_t seed, uint32_t stream_id, int64_t n, float *out, void *stream) {
+    if (n < 0 || !out) { nsd_set_error("rrelu_noise: null pointer or n<0"); return NSD_E_INVALID; }
+    return nsd_rrelu_noise_launch(seed, stream_id, n, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

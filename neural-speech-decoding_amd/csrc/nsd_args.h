@@ -1,0 +1,52 @@
+// nsd_args.h -- kernel argument blocks and host launchers shared by the .hip files of libnsd_hip.so.
+#pragma once
+#include "nsd_common.h"
+
+struct Lstm2FwdArgs {
+    const float *x;
+    const float *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1;
+    const float *mask;
+    float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
+    int B, T, C, residual;
+};
+struct Lstm2BwdArgs {
+    const float *x;
+    const float *w_hh0, *w_ih1, *w_hh1, *attn_w;
+    const float *mask;
+    const float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1;
+    const float *in1seq;
+    const float *alpha, *dscore, *dpooled;
+    float *slabs;
+    long slab_stride;
+    long o_w_ih0, o_w_hh0, o_b_ih0, o_b_hh0, o_w_ih1, o_w_hh1, o_b_ih1, o_b_hh1;
+    int B, T, C, residual;
+};
+struct HeadArgs {
+    const float *top;
+    const float *ln_w, *ln_b, *attn_w, *attn_b, *fc0_w, *fc0_b, *fc3_w, *fc3_b;
+    const float *rrelu_slope, *drop_head;
+    float eval_slope;
+    float *logits, *probs;
+    float *alpha, *pooled, *fc0_pre;
+    const float *logits_in, *dlogits;
+    const int32_t *labels;
+    float scale;
+    float *loss, *dscore, *dpooled;
+    float *hslabs;
+    long o_ln_w, o_ln_b, o_attn_w, o_attn_b, o_fc0_w, o_fc0_b, o_fc3_w, o_fc3_b;
+    long Ph;
+    int B, T, H, F, K;
+};
+int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st);
+int nsd_lstm2_bwd_launch(const Lstm2BwdArgs &a, int H, hipStream_t st);
+int nsd_lstm2_bwd_grid(int B);
+int nsd_head_launch(const HeadArgs &a, bool bwd, hipStream_t st);
+int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t st);
+int nsd_grad_reduce_launch(const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs,
+                           long ph, int n_hslabs, float *grads, int accumulate, hipStream_t st);
+int nsd_adam_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
+                    float wd, float gscale, int step, hipStream_t st);
+int nsd_dropout_mask_launch(uint64_t seed, uint32_t stream_id, float p, long n, float *out, hipStream_t st);
+int nsd_rrelu_noise_launch(uint64_t seed, uint32_t stream_id, long n, float *out, hipStream_t st);
+int nsd_loss_sum_launch(const float *loss, int B, float *out, hipStream_t st);
+

@@ -1,0 +1,87 @@
+// nsd_common.h -- shared host/device helpers of libnsd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/nsd.h"
+
+// ---------------------------------------------------------------------------------------------
+// host side: error text + parameter layout
+// ---------------------------------------------------------------------------------------------
+void nsd_set_error(const char *fmt, ...);
+
+struct ParamLayout {
+    int64_t w_ih[NSD_MAX_LAYERS], w_hh[NSD_MAX_LAYERS], b_ih[NSD_MAX_LAYERS], b_hh[NSD_MAX_LAYERS];
+    int64_t ln_w, ln_b, attn_w, attn_b, fc0_w, fc0_b, fc3_w, fc3_b, total;
+    int64_t lstm_total;   // floats belonging to the LSTM stack (prefix of the vector)
+};
+ParamLayout nsd_make_layout(int C, int H, int L, int K, int F);
+int nsd_check_dims(const nsd_dims *d);
+int nsd_num_cus();
+
+#define NSD_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            nsd_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return NSD_E_LAUNCH;                                                      \
+        }                                                                             \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+#define LOG2E_F 1.44269504088896340736f
+
+// quad (4 adjacent lanes) cross-lane moves via DPP quad_perm: no LDS, no latency beyond a VALU op.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+#define QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+__device__ __forceinline__ float quad_xor1(float v) { return dpp_quad<QP(1, 0, 3, 2)>(v); }
+__device__ __forceinline__ float quad_xor2(float v) { return dpp_quad<QP(2, 3, 0, 1)>(v); }
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) { return dpp_quad<QP(Q, Q, Q, Q)>(v); }
+__device__ __forceinline__ float quad_sum(float v) {
+    v += quad_xor1(v);
+    v += quad_xor2(v);
+    return v;
+}
+
+// sigma(x) = 1/(1+2^(-x*log2e)); tanh(x) = 2*sigma(2x) - 1.  v_exp_f32 / v_rcp_f32 (1 ulp each).
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E_F * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * LOG2E_F * x)), -1.0f);
+}
+// unified gate activation: a*rcp(1+exp2(b*x))+c with per-lane constants (sigmoid: 1,-log2e,0; tanh: 2,-2log2e,-1)
+__device__ __forceinline__ float gate_act(float x, float a, float b, float c) {
+    return fmaf(a, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(b * x)), c);
+}
+
+// wave64 reductions (all lanes get the result)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// counter-based random stream shared bit-for-bit with oracle/nsd_oracle.c (nsd_oracle_rand_u32)
+__host__ __device__ __forceinline__ uint32_t nsd_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+__host__ __device__ __forceinline__ uint32_t nsd_rand_u32(uint64_t seed, uint32_t stream, uint64_t index) {
+    uint32_t lo = (uint32_t)index, hi = (uint32_t)(index >> 32);
+    uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    uint32_t h = nsd_mix32(lo ^ s0);
+    h = nsd_mix32(h + 0x9e3779b9U * (stream + 1u) + hi);
+    h = nsd_mix32(h ^ s1);
+    return h;
+}

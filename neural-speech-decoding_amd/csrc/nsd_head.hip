@@ -1,0 +1,292 @@
+// nsd_head.hip -- attention pooling over time + LayerNorm + dense head (+ softmax / CE), forward and backward.
+//
+// Replaces lines 35-39 of EEG_LSTM.forward (Neuro-Alpha-App/Utilities/lstm_eeg_model.py):
+//   scores = attn(out).squeeze(-1); weights = softmax(scores, dim=1); out = (out*weights[...,None]).sum(1)
+//   out = ln(out); return fc(out)          fc = Linear(H,F) -> RReLU -> Dropout -> Linear(F,K)
+// and the class softmax of SimplePredictor.predict (lstm_eeg_model.py:97).
+//
+// One 256-thread workgroup per trial (grid-strided over trials).  The [T,H] sequence of a trial (48 KB at
+// T=250,H=48) is read twice per pass (scores, weighted sum); rows are contiguous so every wave reads whole
+// 128-B lines.  Reductions over T / H use wave shuffles + one LDS hop.  Shape-generic in T,H,F,K.
+#include "nsd_args.h"
+
+#define HEAD_NT 256
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float *red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+
+// dynamic LDS layout (floats): sc[T] | vecH[4][H] | vecF[2][F] | vecK[K] | part[max(H,256)... see below] | red[8]
+__device__ __forceinline__ void weighted_rowsum(const float *seq, const float *w_t, int T, int H, float *part,
+                                                float *out /*LDS [H]*/) {
+    // out[j] = sum_t w_t[t] * seq[t][j].  Lanes run along j (coalesced rows), parts run along t.
+    const int HL = H < HEAD_NT ? H : HEAD_NT;
+    const int nparts = HEAD_NT / HL;
+    const int lane_j = threadIdx.x % HL, p = threadIdx.x / HL;
+    for (int j0 = 0; j0 < H; j0 += HL) {
+        const int j = j0 + lane_j;
+        float acc = 0.f;
+        if (p < nparts && j < H)
+            for (int t = p; t < T; t += nparts) acc = fmaf(w_t[t], seq[(size_t)t * H + j], acc);
+        __syncthreads();
+        if (p < nparts) part[p * HL + lane_j] = acc;
+        __syncthreads();
+        if (threadIdx.x < HL && j0 + threadIdx.x < H) {
+            float s = 0.f;
+            for (int q = 0; q < nparts; ++q) s += part[q * HL + threadIdx.x];
+            out[j0 + threadIdx.x] = s;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(HEAD_NT) void head_fwd_kernel(HeadArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int T = a.T, H = a.H, F = a.F, K = a.K;
+    float *sc = lds;                  // [T]
+    float *vaw = sc + T;              // [H] attn weights
+    float *vp = vaw + H;              // [H] pooled
+    float *vln = vp + H;              // [H] ln out
+    float *vz = vln + H;              // [F]
+    float *vlg = vz + F;              // [K]
+    float *part = vlg + K;            // [256]
+    float *red = part + HEAD_NT;      // [8]
+    const int tid = threadIdx.x;
+
+    for (int j = tid; j < H; j += HEAD_NT) vaw[j] = a.attn_w[j];
+    const float ab = a.attn_b[0];
+    __syncthreads();
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float *seq = a.top + (size_t)b * T * H;
+        // scores over time (lstm_eeg_model.py:35)
+        float lmax = -INFINITY;
+        for (int t = tid; t < T; t += HEAD_NT) {
+            const float *row = seq + (size_t)t * H;
+            float s = ab;
+            if ((H & 3) == 0) {
+                for (int j = 0; j < H; j += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(row + j);
+                    s = fmaf(v.x, vaw[j], s); s = fmaf(v.y, vaw[j + 1], s);
+                    s = fmaf(v.z, vaw[j + 2], s); s = fmaf(v.w, vaw[j + 3], s);
+                }
+            } else {
+                for (int j = 0; j < H; ++j) s = fmaf(row[j], vaw[j], s);
+            }
+            sc[t] = s;
+            lmax = fmaxf(lmax, s);
+        }
+        const float mx = block_max(lmax, red);
+        // softmax over TIME (lstm_eeg_model.py:36)
+        float lsum = 0.f;
+        for (int t = tid; t < T; t += HEAD_NT) { const float e = __expf(sc[t] - mx); sc[t] = e; lsum += e; }
+        const float den = block_sum(lsum, red);
+        const float rden = 1.0f / den;
+        for (int t = tid; t < T; t += HEAD_NT) {
+            const float al = sc[t] * rden;
+            sc[t] = al;
+            if (a.alpha) a.alpha[(size_t)b * T + t] = al;
+        }
+        __syncthreads();
+        // weighted sum over time (lstm_eeg_model.py:37)
+        weighted_rowsum(seq, sc, T, H, part, vp);
+        // LayerNorm (lstm_eeg_model.py:38): biased variance, eps inside the sqrt
+        float ls = 0.f;
+        for (int j = tid; j < H; j += HEAD_NT) { ls += vp[j]; if (a.pooled) a.pooled[(size_t)b * H + j] = vp[j]; }
+        const float mu = block_sum(ls, red) / (float)H;
+        float lv = 0.f;
+        for (int j = tid; j < H; j += HEAD_NT) { const float d = vp[j] - mu; lv += d * d; }
+        const float var = block_sum(lv, red) / (float)H;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        for (int j = tid; j < H; j += HEAD_NT) vln[j] = (vp[j] - mu) * rstd * a.ln_w[j] + a.ln_b[j];
+        __syncthreads();
+        // fc.0 -> RReLU -> Dropout (lstm_eeg_model.py:26-28)
+        for (int f = tid; f < F; f += HEAD_NT) {
+            float acc = a.fc0_b[f];
+            const float *w = a.fc0_w + (size_t)f * H;
+            for (int j = 0; j < H; ++j) acc = fmaf(w[j], vln[j], acc);
+            if (a.fc0_pre) a.fc0_pre[(size_t)b * F + f] = acc;
+            const float sl = a.rrelu_slope ? a.rrelu_slope[(size_t)b * F + f] : a.eval_slope;
+            float v = acc >= 0.f ? acc : acc * sl;
+            if (a.drop_head) v *= a.drop_head[(size_t)b * F + f];
+            vz[f] = v;
+        }
+        __syncthreads();
+        // fc.3 (lstm_eeg_model.py:29) and optional class softmax (lstm_eeg_model.py:97)
+        for (int k = tid; k < K; k += HEAD_NT) {
+            float acc = a.fc3_b[k];
+            const float *w = a.fc3_w + (size_t)k * F;
+            for (int f = 0; f < F; ++f) acc = fmaf(w[f], vz[f], acc);
+            vlg[k] = acc;
+            a.logits[(size_t)b * K + k] = acc;
+        }
+        __syncthreads();
+        if (a.probs && tid == 0) {
+            float m2 = vlg[0];
+            for (int k = 1; k < K; ++k) m2 = fmaxf(m2, vlg[k]);
+            float d = 0.f;
+            for (int k = 0; k < K; ++k) d += __expf(vlg[k] - m2);
+            for (int k = 0; k < K; ++k) a.probs[(size_t)b * K + k] = __expf(vlg[k] - m2) / d;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(HEAD_NT) void head_bwd_kernel(HeadArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int T = a.T, H = a.H, F = a.F, K = a.K;
+    float *sc = lds;                  // [T]  alpha, later dscore
+    float *vaw = sc + T;              // [H]
+    float *vx = vaw + H;              // [H] xhat
+    float *vln = vx + H;              // [H] ln out
+    float *vdp = vln + H;             // [H] d pooled
+    float *vz = vdp + H;              // [F] activated fc0 output
+    float *vdz = vz + F;              // [F]
+    float *vdl = vdz + F;             // [K]
+    float *part = vdl + K;            // [256]
+    float *red = part + HEAD_NT;      // [8]
+    const int tid = threadIdx.x;
+
+    for (int j = tid; j < H; j += HEAD_NT) vaw[j] = a.attn_w[j];
+    __syncthreads();
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float *seq = a.top + (size_t)b * T * H;
+        float *slab = a.hslabs + (size_t)b * a.Ph;
+        // dlogits (given, or mean-CE from labels)
+        if (tid == 0) {
+            if (a.dlogits) {
+                for (int k = 0; k < K; ++k) vdl[k] = a.dlogits[(size_t)b * K + k];
+            } else {
+                const float *lg = a.logits_in + (size_t)b * K;
+                const int y = a.labels[b];
+                float m2 = lg[0];
+                for (int k = 1; k < K; ++k) m2 = fmaxf(m2, lg[k]);
+                float d = 0.f;
+                for (int k = 0; k < K; ++k) d += expf(lg[k] - m2);
+                for (int k = 0; k < K; ++k) vdl[k] = (expf(lg[k] - m2) / d - (k == y ? 1.f : 0.f)) * a.scale;
+                if (a.loss) a.loss[b] = -((lg[y] - m2) - logf(d));
+            }
+        }
+        // recompute LayerNorm statistics from the saved pooled vector
+        float ls = 0.f;
+        for (int j = tid; j < H; j += HEAD_NT) { vdp[j] = a.pooled[(size_t)b * H + j]; ls += vdp[j]; }
+        const float mu = block_sum(ls, red) / (float)H;
+        float lv = 0.f;
+        for (int j = tid; j < H; j += HEAD_NT) { const float d = vdp[j] - mu; lv += d * d; }
+        const float var = block_sum(lv, red) / (float)H;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        for (int j = tid; j < H; j += HEAD_NT) {
+            const float xh = (vdp[j] - mu) * rstd;
+            vx[j] = xh;
+            vln[j] = xh * a.ln_w[j] + a.ln_b[j];
+        }
+        // activated fc.0 output, and dz through fc.3 / dropout / RReLU
+        for (int f = tid; f < F; f += HEAD_NT) {
+            const float pre = a.fc0_pre[(size_t)b * F + f];
+            const float sl = a.rrelu_slope ? a.rrelu_slope[(size_t)b * F + f] : a.eval_slope;
+            const float mk = a.drop_head ? a.drop_head[(size_t)b * F + f] : 1.f;
+            vz[f] = (pre >= 0.f ? pre : pre * sl) * mk;
+        }
+        __syncthreads();
+        for (int f = tid; f < F; f += HEAD_NT) {
+            const float pre = a.fc0_pre[(size_t)b * F + f];
+            const float sl = a.rrelu_slope ? a.rrelu_slope[(size_t)b * F + f] : a.eval_slope;
+            const float mk = a.drop_head ? a.drop_head[(size_t)b * F + f] : 1.f;
+            float d = 0.f;
+            for (int k = 0; k < K; ++k) d = fmaf(a.fc3_w[(size_t)k * F + f], vdl[k], d);
+            d *= mk;
+            d = pre >= 0.f ? d : d * sl;
+            vdz[f] = d;
+            slab[a.o_fc0_b + f] = d;
+        }
+        for (int e = tid; e < K * F; e += HEAD_NT) slab[a.o_fc3_w + e] = vdl[e / F] * vz[e % F];
+        for (int k = tid; k < K; k += HEAD_NT) slab[a.o_fc3_b + k] = vdl[k];
+        __syncthreads();
+        for (int e = tid; e < F * H; e += HEAD_NT) slab[a.o_fc0_w + e] = vdz[e / H] * vln[e % H];
+        // d ln_out, LayerNorm backward
+        float l1 = 0.f, l2 = 0.f;
+        for (int j = tid; j < H; j += HEAD_NT) {
+            float d = 0.f;
+            for (int f = 0; f < F; ++f) d = fmaf(a.fc0_w[(size_t)f * H + j], vdz[f], d);
+            slab[a.o_ln_w + j] = d * vx[j];
+            slab[a.o_ln_b + j] = d;
+            const float dxh = d * a.ln_w[j];
+            vdp[j] = dxh;
+            l1 += dxh; l2 += dxh * vx[j];
+        }
+        const float m1 = block_sum(l1, red) / (float)H;
+        const float m2 = block_sum(l2, red) / (float)H;
+        for (int j = tid; j < H; j += HEAD_NT) {
+            const float d = rstd * (vdp[j] - m1 - vx[j] * m2);
+            vdp[j] = d;
+            a.dpooled[(size_t)b * H + j] = d;
+        }
+        __syncthreads();
+        // attention backward: dalpha_t = dp . out_t ; ds = alpha * (dalpha - sum alpha*dalpha)
+        float lsd = 0.f;
+        for (int t = tid; t < T; t += HEAD_NT) {
+            const float *row = seq + (size_t)t * H;
+            float d = 0.f;
+            for (int j = 0; j < H; ++j) d = fmaf(row[j], vdp[j], d);
+            const float al = a.alpha[(size_t)b * T + t];
+            sc[t] = d;
+            lsd = fmaf(al, d, lsd);
+        }
+        const float sdot = block_sum(lsd, red);
+        float lb = 0.f;
+        for (int t = tid; t < T; t += HEAD_NT) {
+            const float ds = a.alpha[(size_t)b * T + t] * (sc[t] - sdot);
+            sc[t] = ds;
+            a.dscore[(size_t)b * T + t] = ds;
+            lb += ds;
+        }
+        const float dab = block_sum(lb, red);
+        if (tid == 0) slab[a.o_attn_b] = dab;
+        // d attn.weight[j] = sum_t ds_t * out_t[j]
+        weighted_rowsum(seq, sc, T, H, part, vx);
+        for (int j = tid; j < H; j += HEAD_NT) slab[a.o_attn_w + j] = vx[j];
+        __syncthreads();
+    }
+}
+
+static size_t head_lds_bytes(int T, int H, int F, int K, bool bwd) {
+    size_t n = (size_t)T + (bwd ? 4 : 3) * (size_t)H + (bwd ? 2 : 1) * (size_t)F + K + HEAD_NT + 8;
+    return n * sizeof(float);
+}
+
+int nsd_head_launch(const HeadArgs &a, bool bwd, hipStream_t st) {
+    if (a.B <= 0) return NSD_OK;
+    const size_t lds = head_lds_bytes(a.T, a.H, a.F, a.K, bwd);
+    if (lds > 160 * 1024 || a.H > HEAD_NT * 8) {
+        nsd_set_error("head: T=%d H=%d needs %zu B of LDS (max 163840)", a.T, a.H, lds);
+        return NSD_E_INVALID;
+    }
+    const int cap = 8 * nsd_num_cus();
+    const int grid = a.B < cap ? a.B : cap;
+    if (bwd) {
+        if (lds > 64 * 1024)
+            hipFuncSetAttribute((const void *)head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(HEAD_NT), lds, st, a);
+    } else {
+        if (lds > 64 * 1024)
+            hipFuncSetAttribute((const void *)head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(head_fwd_kernel, dim3(grid), dim3(HEAD_NT), lds, st, a);
+    }
+    NSD_CHECK_LAUNCH(bwd ? "head_bwd" : "head_fwd");
+    return NSD_OK;
+}

@@ -1,0 +1,159 @@
+// nsd_misc.hip -- small memory-bound kernels around the LSTM path: per-channel z-score, slab reduction,
+// Adam, counter-based dropout / RReLU-noise streams, loss sum.
+#include "nsd_args.h"
+
+// ---------------------------------------------------------------------------------------------
+// z-score: y = (x - mean_T) / (std_T(ddof=0) + 1e-6) per trial and channel.
+// Replaces normalize_eeg (Neuro-Alpha-App/Frontend/app.py:166-170).  One 256-thread workgroup per trial;
+// lanes run along the contiguous [t][c] axis (coalesced), each thread owns channel tid % C.
+// ---------------------------------------------------------------------------------------------
+#define ZS_NT 256
+__global__ __launch_bounds__(ZS_NT) void zscore_kernel(const float *x, float *y, int B, int T, int C) {
+    extern __shared__ float zl[];          // [ZS_NT] partials + [2*C] stats
+    float *stat = zl + ZS_NT;
+    const int tid = threadIdx.x;
+    const int act = (ZS_NT / C) * C;       // threads taking part; each keeps one channel
+    const int ch = tid % C;
+    const int rows = act / C;              // time steps covered per sweep
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const float *xb = x + (size_t)b * T * C;
+        float *yb = y + (size_t)b * T * C;
+        float s = 0.f;
+        if (tid < act) for (int t = tid / C; t < T; t += rows) s += xb[(size_t)t * C + ch];
+        zl[tid] = s;
+        __syncthreads();
+        if (tid < C) { float m = 0.f; for (int q = 0; q < rows; ++q) m += zl[q * C + tid]; stat[tid] = m / (float)T; }
+        __syncthreads();
+        const float mu = stat[ch];
+        float v = 0.f;
+        if (tid < act) for (int t = tid / C; t < T; t += rows) { const float d = xb[(size_t)t * C + ch] - mu; v = fmaf(d, d, v); }
+        __syncthreads();
+        zl[tid] = v;
+        __syncthreads();
+        if (tid < C) { float m = 0.f; for (int q = 0; q < rows; ++q) m += zl[q * C + tid]; stat[C + tid] = 1.0f / (sqrtf(m / (float)T) + 1e-6f); }
+        __syncthreads();
+        const float rs = stat[C + ch];
+        if (tid < act) for (int t = tid / C; t < T; t += rows) yb[(size_t)t * C + ch] = (xb[(size_t)t * C + ch] - mu) * rs;
+        __syncthreads();
+    }
+}
+
+int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t st) {
+    if (B <= 0) return NSD_OK;
+    if (C < 1 || C > ZS_NT || T < 1) { nsd_set_error("zscore: bad shape T=%d C=%d", T, C); return NSD_E_INVALID; }
+    const int cap = 8 * nsd_num_cus();
+    hipLaunchKernelGGL(zscore_kernel, dim3(B < cap ? B : cap), dim3(ZS_NT), (ZS_NT + 2 * C) * sizeof(float), st, x, y, B, T, C);
+    NSD_CHECK_LAUNCH("zscore");
+    return NSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient reduction: grads[e] (+)= sum over the per-workgroup LSTM slabs (e < P_lstm) or over the
+// per-trial head slabs (e >= P_lstm).  Column sums: consecutive threads read consecutive floats.
+// ---------------------------------------------------------------------------------------------
+__global__ void grad_reduce_kernel(const float *slabs, long slab_stride, int n_slabs, long p_lstm,
+                                   const float *hslabs, long ph, int n_hslabs, float *grads, int accumulate) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p_lstm + ph) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float *p; long stride; int n;
+    if (e < p_lstm) { p = slabs + e; stride = slab_stride; n = n_slabs; }
+    else { p = hslabs + (e - p_lstm); stride = ph; n = n_hslabs; }
+    int q = 0;
+    for (; q + 3 < n; q += 4) {
+        s0 += p[(size_t)q * stride]; s1 += p[(size_t)(q + 1) * stride];
+        s2 += p[(size_t)(q + 2) * stride]; s3 += p[(size_t)(q + 3) * stride];
+    }
+    for (; q < n; ++q) s0 += p[(size_t)q * stride];
+    const float s = (s0 + s1) + (s2 + s3);
+    grads[e] = accumulate ? grads[e] + s : s;
+}
+
+int nsd_grad_reduce_launch(const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs,
+                           long ph, int n_hslabs, float *grads, int accumulate, hipStream_t st) {
+    const long n = p_lstm + ph;
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, slab_stride,
+                       n_slabs, p_lstm, hslabs, ph, n_hslabs, grads, accumulate);
+    NSD_CHECK_LAUNCH("grad_reduce");
+    return NSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, amsgrad=False).  g is multiplied by grad_scale first (1/world_size after a
+// SUM all-reduce).
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_kernel(long n, float *p, const float *g, float *m, float *v, float lr_over_bc1, float rsqrt_bc2,
+                            float beta1, float beta2, float eps, float wd, float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = fmaf(wd, pi, g[i] * gscale);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        p[i] = pi - lr_over_bc1 * (mi / denom);
+    }
+}
+
+int nsd_adam_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
+                    float wd, float gscale, int step, hipStream_t st) {
+    if (n <= 0) return NSD_OK;
+    if (step < 1) { nsd_set_error("adam: step must be >= 1"); return NSD_E_INVALID; }
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, p, g, m, v, (float)(lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), b1, b2, eps, wd, gscale);
+    NSD_CHECK_LAUNCH("adam");
+    return NSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based random streams (bit-identical to oracle/nsd_oracle.c)
+// ---------------------------------------------------------------------------------------------
+__global__ void dropout_mask_kernel(uint64_t seed, uint32_t stream_id, uint32_t thr, float keep, long n, float *out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = nsd_rand_u32(seed, stream_id, (uint64_t)i) >= thr ? keep : 0.f;
+}
+__global__ void rrelu_noise_kernel(uint64_t seed, uint32_t stream_id, long n, float *out) {
+    const float lower = 0.125f, upper = (float)(1.0 / 3.0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float u = (float)(nsd_rand_u32(seed, stream_id, (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+        out[i] = lower + (upper - lower) * u;
+    }
+}
+
+int nsd_dropout_mask_launch(uint64_t seed, uint32_t stream_id, float p, long n, float *out, hipStream_t st) {
+    if (n <= 0) return NSD_OK;
+    if (!(p >= 0.f && p < 1.f)) { nsd_set_error("dropout: p=%f out of [0,1)", p); return NSD_E_INVALID; }
+    double t = (double)p * 4294967296.0; if (t > 4294967295.0) t = 4294967295.0;
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, stream_id, (uint32_t)t,
+                       1.0f / (1.0f - p), n, out);
+    NSD_CHECK_LAUNCH("dropout_mask");
+    return NSD_OK;
+}
+int nsd_rrelu_noise_launch(uint64_t seed, uint32_t stream_id, long n, float *out, hipStream_t st) {
+    if (n <= 0) return NSD_OK;
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rrelu_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, stream_id, n, out);
+    NSD_CHECK_LAUNCH("rrelu_noise");
+    return NSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss sum (deterministic single workgroup)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_sum_kernel(const float *loss, int B, float *out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) s += loss[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+int nsd_loss_sum_launch(const float *loss, int B, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(256), 0, st, loss, B, out);
+    NSD_CHECK_LAUNCH("loss_sum");
+    return NSD_OK;
+}

@@ -1,0 +1,243 @@
+"""Drop-in counterpart of the reference's Neuro-Alpha-App/Utilities/lstm_eeg_model.py, running on MI355X.
+
+Same public names, constructor signatures, defaults and state_dict keys as the reference
+(`EEG_LSTM` lstm_eeg_model.py:13-39, `SimplePredictor` :42-101, `CLASS_NAMES` :11), so the reference's
+checkpoint loads with strict=True and `tester.run_trials` / the Streamlit app can import this module
+instead.  The arithmetic is NOT torch's: forward / backward call the hand-written HIP kernels of
+libnsd_hip.so through the C ABI (include/nsd.h).  The nn.Linear / nn.LayerNorm sub-modules below only
+hold parameters under the reference's names; their own forward() is never used.
+
+There is no CPU implementation: parameters and inputs must be on the GPU, otherwise forward raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import NsdError
+
+CLASS_NAMES = ["Food", "Water", "BG-Noise"]   # verbatim from lstm_eeg_model.py:11
+
+
+class _StackedLSTMParams(nn.Module):
+    """Parameter container with torch.nn.LSTM's parameter names, shapes and default init."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        k = 1.0 / math.sqrt(hidden_size)
+        for l in range(num_layers):
+            I = input_size if l == 0 else hidden_size
+            for name, shape in ((f"weight_ih_l{l}", (4 * hidden_size, I)), (f"weight_hh_l{l}", (4 * hidden_size, hidden_size)),
+                                (f"bias_ih_l{l}", (4 * hidden_size,)), (f"bias_hh_l{l}", (4 * hidden_size,))):
+                self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+
+    def extra_repr(self) -> str:
+        return f"{self.input_size}, {self.hidden_size}, num_layers={self.num_layers}, batch_first=True"
+
+
+class _EEGFunction(torch.autograd.Function):
+    """Whole-model autograd node: x, 16 parameters -> logits.  Backward returns the parameter gradients as
+    views of one flat vector produced by the HIP backward kernels."""
+
+    @staticmethod
+    def forward(ctx, module: "EEG_LSTM", x: torch.Tensor, masks, *params):
+        spec, flat = module.spec, module._flat
+        B, T, _ = x.shape
+        ws = ops.new_workspace(spec, B, T, x.device)
+        drop_lstm, rrelu_slope, drop_head = masks
+        logits, _ = ops.train_forward(spec, flat, x, ws, drop_lstm=drop_lstm, rrelu_slope=rrelu_slope,
+                                      drop_head=drop_head, residual=module.residual)
+        ctx.module, ctx.ws, ctx.masks = module, ws, masks
+        ctx.save_for_backward(x, logits)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        module = ctx.module
+        spec = module.spec
+        x, logits = ctx.saved_tensors
+        drop_lstm, rrelu_slope, drop_head = ctx.masks
+        g = ops.train_backward(spec, module._flat, x, ctx.ws, logits, dlogits=dlogits.contiguous().float(),
+                               drop_lstm=drop_lstm, rrelu_slope=rrelu_slope, drop_head=drop_head,
+                               residual=module.residual)
+        offs, shapes = spec.offsets(), spec.shapes()
+        grads = tuple(g[offs[n]:offs[n] + math.prod(shapes[n])].view(shapes[n]) for n in spec.names())
+        ctx.ws = None
+        return (None, None, None) + grads
+
+
+class EEG_LSTM(nn.Module):
+    """2-layer LSTM -> attention pooling over time -> LayerNorm -> Linear/RReLU/Dropout/Linear.
+
+    Signature and defaults of the reference (lstm_eeg_model.py:14).  Keyword-only extensions, all
+    default OFF so that reference checkpoints reproduce reference logits:
+      residual   add the layer input to the output of every LSTM layer l>=1 (README's "residual stack")
+      normalize  per-channel z-score of the window before the LSTM (Frontend/app.py:166-170 semantics)
+    """
+
+    def __init__(self, input_size=8, hidden_size=48, num_layers=2, num_classes=3, dropout=0.60, *,
+                 residual: bool = False, normalize: bool = False):
+        super().__init__()
+        self.spec = ops.ModelSpec(C=input_size, H=hidden_size, L=num_layers, K=num_classes, F=ops.FC_HIDDEN)
+        self.dropout_p = float(dropout) if num_layers > 1 else 0.0   # nn.LSTM drops only between layers (:21)
+        self.head_dropout_p = float(dropout)
+        self.residual, self.normalize = bool(residual), bool(normalize)
+        self.lstm = _StackedLSTMParams(input_size, hidden_size, num_layers)
+        self.ln = nn.LayerNorm(hidden_size)
+        self.attn = nn.Linear(hidden_size, 1)
+        self.fc = nn.Sequential(
+            nn.Linear(hidden_size, ops.FC_HIDDEN),
+            nn.RReLU(),
+            nn.Dropout(dropout),
+            nn.Linear(ops.FC_HIDDEN, num_classes),
+        )
+        self._flat: Optional[torch.Tensor] = None
+        self._seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        self._step = 0
+        self._mask_override = None    # tests inject explicit (drop_lstm, rrelu_slope, drop_head)
+
+    # ---- flat parameter storage: all 16 tensors are views into one contiguous vector -----------------
+    def _named_in_order(self):
+        byname = dict(self.named_parameters())
+        return [(n, byname[n]) for n in self.spec.names()]
+
+    def flatten_parameters(self) -> torch.Tensor:
+        """(Re)pack the parameters into one flat fp32 vector in state_dict order; the kernels read it
+        directly and the optimizer / gradient all-reduce work on it as a single buffer."""
+        named = self._named_in_order()
+        dev = named[0][1].device
+        flat = torch.empty(self.spec.param_count, dtype=torch.float32, device=dev)
+        offs = self.spec.offsets()
+        with torch.no_grad():
+            for n, p in named:
+                seg = flat[offs[n]:offs[n] + p.numel()].view(p.shape)
+                seg.copy_(p.detach().to(torch.float32))
+                p.data = seg
+        self._flat = flat
+        return flat
+
+    def _flat_ok(self) -> bool:
+        f = self._flat
+        if f is None:
+            return False
+        base, offs = f.data_ptr(), self.spec.offsets()
+        return all(p.data_ptr() == base + 4 * offs[n] and p.dtype == torch.float32 for n, p in self._named_in_order())
+
+    def flat_parameters(self) -> torch.Tensor:
+        if not self._flat_ok():
+            self.flatten_parameters()
+        return self._flat
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._flat = None        # .to()/.cuda() re-created the storages
+        return out
+
+    # ---- forward --------------------------------------------------------------------------------------
+    def _train_masks(self, B: int, T: int, device):
+        if self._mask_override is not None:
+            return self._mask_override
+        self._step += 1
+        base = self._step * 4
+        sp = self.spec
+        drop_lstm = (ops.dropout_mask(self._seed, base, self.dropout_p, (sp.L - 1, B, T, sp.H), device)
+                     if self.dropout_p > 0 and sp.L > 1 else None)
+        rrelu = ops.rrelu_noise(self._seed, base + 1, (B, sp.F), device)
+        drop_head = (ops.dropout_mask(self._seed, base + 2, self.head_dropout_p, (B, sp.F), device)
+                     if self.head_dropout_p > 0 else None)
+        return drop_lstm, rrelu, drop_head
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # x: [B, T, C] -> logits [B, num_classes]  (no softmax, as lstm_eeg_model.py:32-39)
+        if x.dim() != 3 or x.shape[-1] != self.spec.C:
+            raise ValueError(f"Expected x of shape [B, T, {self.spec.C}], got {tuple(x.shape)}")
+        flat = self.flat_parameters()
+        if not flat.is_cuda or not x.is_cuda:
+            raise NsdError("EEG_LSTM runs only on the MI355X HIP path: move the module and the input to the GPU "
+                           f"(module on {flat.device}, input on {x.device}); there is no CPU fallback")
+        x = x.contiguous().float()     # predict() hands over a transposed view (preprocessor.py:34)
+        if self.normalize:
+            x = ops.zscore(x)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not self.training and not need_grad:
+            logits, _ = ops.infer(self.spec, flat, x, residual=self.residual, want_probs=False)
+            return logits
+        masks = self._train_masks(x.shape[0], x.shape[1], x.device) if self.training else (None, None, None)
+        params = [p for _, p in self._named_in_order()]
+        return _EEGFunction.apply(self, x, masks, *params)
+
+    @torch.no_grad()
+    def predict_proba(self, x: torch.Tensor) -> torch.Tensor:
+        """Eval-mode class probabilities with the softmax fused into the head kernel (lstm_eeg_model.py:97)."""
+        x = x.contiguous().float()
+        if self.normalize:
+            x = ops.zscore(x)
+        _, probs = ops.infer(self.spec, self.flat_parameters(), x, residual=self.residual, want_probs=True)
+        return probs
+
+
+def _default_preprocessor(sr: int, tailoring_lambda: float):
+    """The reference filters every window with the third-party MindsAI filter (preprocessor.py:21-36),
+    which is out of scope here (non-commercial licence, host-side numpy).  When this module is dropped
+    into the reference tree the reference's own PreProcessor is importable and is used unchanged;
+    otherwise windows are passed through (same shape / dtype contract, same ValueError)."""
+    try:
+        from preprocessor import PreProcessor  # type: ignore  (reference tree on sys.path)
+        return PreProcessor(sr=sr, tailoring_lambda=tailoring_lambda)
+    except Exception:
+        return _IdentityPreProcessor(sr, tailoring_lambda)
+
+
+class _IdentityPreProcessor:
+    def __init__(self, sr: int, tailoring_lambda: float = 1.25e-29):
+        self.sr, self.tailoring_lambda = sr, tailoring_lambda
+
+    def transform(self, chunk_samples_by_channels: np.ndarray) -> np.ndarray:
+        x = np.asarray(chunk_samples_by_channels)
+        if x.ndim != 2:
+            raise ValueError(f"Expected 2D array [samples, channels], got {x.shape}")
+        return x.astype(np.float32, copy=False)
+
+
+class SimplePredictor:
+    """Mirror of the reference's SimplePredictor (lstm_eeg_model.py:42-101): preprocess a [T,C] window,
+    run the model, softmax, return (probs float32[K], label).
+
+    `device` keeps the reference's keyword and default ("cpu", what tester.py:83 passes) but only names
+    where the caller's arrays live: numpy in, numpy out.  The model itself always runs on the GPU
+    (`gpu` argument, default "cuda"); if none is available construction fails loudly.
+    """
+
+    def __init__(self, pth_path: str, sr: int, channel_order=None, input_size: int = 8, hidden_size: int = 48,
+                 num_layers: int = 2, num_classes: int = 3, dropout: float = 0.60, device: str = "cpu",
+                 tailoring_lambda: float = 1.25e-29, class_names=None, *, preprocess=None, gpu: str = "cuda",
+                 residual: bool = False, normalize: bool = False):
+        self.device = torch.device(device)
+        self.class_names = class_names or CLASS_NAMES
+        self.pre = preprocess if preprocess is not None else _default_preprocessor(sr, tailoring_lambda)
+        if not torch.cuda.is_available():
+            raise NsdError("SimplePredictor needs an MI355X: torch.cuda.is_available() is False and the HIP path has "
+                           "no CPU fallback")
+        self.gpu = torch.device(gpu)
+        self.model = EEG_LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                              num_classes=num_classes, dropout=dropout, residual=residual, normalize=normalize)
+        state = torch.load(pth_path, map_location="cpu", weights_only=True)
+        if isinstance(state, dict) and "state_dict" in state:     # both forms, as lstm_eeg_model.py:79-80
+            state = state["state_dict"]
+        self.model.load_state_dict(state, strict=True)
+        self.model.to(self.gpu).eval()
+        self.model.flatten_parameters()
+
+    def predict(self, chunk_TxC: np.ndarray):
+        """chunk_TxC: [T, C] float32 window -> (probs np.float32[K], label str)."""
+        x = self.pre.transform(chunk_TxC)
+        x_t = torch.from_numpy(np.ascontiguousarray(x[None, ...], dtype=np.float32)).to(self.gpu, non_blocking=True)
+        probs = self.model.predict_proba(x_t)[0].cpu().numpy().astype(np.float32)
+        y_idx = int(np.argmax(probs))
+        return probs, self.class_names[y_idx]

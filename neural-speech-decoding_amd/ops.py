@@ -1,0 +1,231 @@
+"""Tensor-level wrappers over the C ABI (include/nsd.h).  PyTorch is only the plumbing here: it owns the
+device buffers and the HIP stream; every number is produced by the kernels in csrc/.
+
+All functions require CUDA(HIP) fp32 tensors and raise otherwise -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Dims, NsdError, WsLayout, check
+
+FC_HIDDEN = 32   # width of fc.0 in the reference (lstm_eeg_model.py:26)
+
+
+@dataclass(frozen=True)
+class ModelSpec:
+    """Static shape of an EEG_LSTM (reference ctor kwargs, lstm_eeg_model.py:14)."""
+    C: int = 8
+    H: int = 48
+    L: int = 2
+    K: int = 3
+    F: int = FC_HIDDEN
+
+    def dims(self, B: int, T: int) -> Dims:
+        return Dims(B, T, self.C, self.H, self.L, self.K, self.F)
+
+    @property
+    def param_count(self) -> int:
+        n = _lib.lib().nsd_param_count(self.C, self.H, self.L, self.K, self.F)
+        if n < 0:
+            raise NsdError(f"bad model dims {self}")
+        return int(n)
+
+    def names(self) -> List[str]:
+        out = []
+        for l in range(self.L):
+            out += [f"lstm.weight_ih_l{l}", f"lstm.weight_hh_l{l}", f"lstm.bias_ih_l{l}", f"lstm.bias_hh_l{l}"]
+        return out + ["ln.weight", "ln.bias", "attn.weight", "attn.bias",
+                      "fc.0.weight", "fc.0.bias", "fc.3.weight", "fc.3.bias"]
+
+    def shapes(self) -> Dict[str, Tuple[int, ...]]:
+        s = {}
+        for l in range(self.L):
+            I = self.C if l == 0 else self.H
+            s[f"lstm.weight_ih_l{l}"] = (4 * self.H, I)
+            s[f"lstm.weight_hh_l{l}"] = (4 * self.H, self.H)
+            s[f"lstm.bias_ih_l{l}"] = (4 * self.H,)
+            s[f"lstm.bias_hh_l{l}"] = (4 * self.H,)
+        s.update({"ln.weight": (self.H,), "ln.bias": (self.H,), "attn.weight": (1, self.H), "attn.bias": (1,),
+                  "fc.0.weight": (self.F, self.H), "fc.0.bias": (self.F,),
+                  "fc.3.weight": (self.K, self.F), "fc.3.bias": (self.K,)})
+        return s
+
+    def offsets(self) -> Dict[str, int]:
+        n = 4 * self.L + 8
+        offs = (C.c_int64 * n)()
+        check(_lib.lib().nsd_param_layout(self.C, self.H, self.L, self.K, self.F, offs), "nsd_param_layout")
+        return dict(zip(self.names(), [int(o) for o in offs]))
+
+    def fast_path(self) -> bool:
+        d = self.dims(1, 1)
+        return bool(_lib.lib().nsd_fast_path(C.byref(d)))
+
+
+def _dev_f32(t: Optional[torch.Tensor], name: str, shape=None) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NsdError(f"{name}: expected a tensor on the MI355X (cuda/hip device), got device={t.device}; "
+                       "the HIP path has no CPU fallback")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise NsdError(f"{name}: expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise NsdError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace_layout(spec: ModelSpec, B: int, T: int) -> Tuple[int, WsLayout]:
+    d, w = spec.dims(B, T), WsLayout()
+    n = _lib.lib().nsd_workspace_bytes(C.byref(d), C.byref(w))
+    if n < 0:
+        check(int(n), "nsd_workspace_bytes")
+    return int(n), w
+
+
+def new_workspace(spec: ModelSpec, B: int, T: int, device) -> torch.Tensor:
+    nbytes, _ = workspace_layout(spec, B, T)
+    return torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=device)
+
+
+def ws_view(ws: torch.Tensor, spec: ModelSpec, B: int, T: int, region: str) -> torch.Tensor:
+    """A shaped view of one workspace region (used by tests to inspect intermediates)."""
+    _, w = workspace_layout(spec, B, T)
+    H, L, F = spec.H, spec.L, spec.F
+    shapes = {"hseq": (L, B, T, H), "cseq": (L, B, T, H), "gact": (L, B, T, H, 4), "inseq": (max(L - 1, 0), B, T, H),
+              "top": (B, T, H), "alpha": (B, T), "pooled": (B, H), "fc0_pre": (B, F), "dscore": (B, T),
+              "dpooled": (B, H), "loss": (B,)}
+    shp = shapes[region]
+    n = 1
+    for v in shp:
+        n *= v
+    off = getattr(w, region)
+    return ws[off:off + n].view(shp)
+
+
+def zscore(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(x - mean_T) / (std_T + 1e-6) per trial and channel; x [B,T,C] or [T,C].  (app.py:166-170)"""
+    squeeze = x.dim() == 2
+    x3 = x.unsqueeze(0) if squeeze else x
+    if x3.dim() != 3:
+        raise ValueError(f"Expected [B,T,C] or [T,C], got {tuple(x.shape)}")
+    x3 = x3.contiguous()
+    y = torch.empty_like(x3) if out is None else out
+    B, T, Cc = x3.shape
+    check(_lib.lib().nsd_zscore_fwd(_dev_f32(x3, "x"), _dev_f32(y, "y", x3.shape), B, T, Cc, _stream()), "nsd_zscore_fwd")
+    return y[0] if squeeze else y
+
+
+def infer(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, *, residual: bool = False,
+          want_probs: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Eval-mode forward: logits [B,K] (+ softmax probabilities)."""
+    B, T, Cc = x.shape
+    if Cc != spec.C:
+        raise NsdError(f"x has {Cc} channels, model expects {spec.C}")
+    d = spec.dims(B, T)
+    logits = torch.empty((B, spec.K), dtype=torch.float32, device=x.device)
+    probs = torch.empty_like(logits) if want_probs else None
+    nscr = _lib.lib().nsd_infer_scratch_bytes(C.byref(d))
+    scratch = torch.empty(max(int(nscr) // 4, 1), dtype=torch.float32, device=x.device)
+    check(_lib.lib().nsd_infer(C.byref(d), _dev_f32(flat, "params", (spec.param_count,)), _dev_f32(x, "x"),
+                               _lib.NSD_FLAG_RESIDUAL if residual else 0, _dev_f32(logits, "logits"),
+                               _dev_f32(probs, "probs"), scratch.data_ptr(), _stream()), "nsd_infer")
+    return logits, probs
+
+
+def train_forward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: torch.Tensor, *,
+                  drop_lstm: Optional[torch.Tensor] = None, rrelu_slope: Optional[torch.Tensor] = None,
+                  drop_head: Optional[torch.Tensor] = None, residual: bool = False,
+                  want_probs: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Train-mode forward keeping activations in `ws` (from new_workspace)."""
+    B, T, Cc = x.shape
+    d = spec.dims(B, T)
+    flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0)
+    L = _lib.lib()
+    pp = _dev_f32(flat, "params", (spec.param_count,))
+    nbytes, _ = workspace_layout(spec, B, T)
+    if ws.numel() * 4 < nbytes:
+        raise NsdError(f"workspace too small: {ws.numel() * 4} < {nbytes} bytes")
+    check(L.nsd_lstm_fwd(C.byref(d), pp, _dev_f32(x, "x", (B, T, spec.C)),
+                         _dev_f32(drop_lstm, "drop_lstm", (spec.L - 1, B, T, spec.H)), flags,
+                         _dev_f32(ws, "workspace"), _stream()), "nsd_lstm_fwd")
+    logits = torch.empty((B, spec.K), dtype=torch.float32, device=x.device)
+    probs = torch.empty_like(logits) if want_probs else None
+    check(L.nsd_head_fwd(C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope", (B, spec.F)),
+                         _dev_f32(drop_head, "drop_head", (B, spec.F)), ws.data_ptr(), logits.data_ptr(),
+                         _dev_f32(probs, "probs"), _stream()), "nsd_head_fwd")
+    return logits, probs
+
+
+def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: torch.Tensor, logits: torch.Tensor, *,
+                   dlogits: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                   scale: Optional[float] = None, drop_lstm=None, rrelu_slope=None, drop_head=None,
+                   residual: bool = False, grads: Optional[torch.Tensor] = None,
+                   accumulate: bool = False) -> torch.Tensor:
+    """Backward through head + LSTM; returns the flat gradient vector (same layout as the parameters).
+    Give either dlogits [B,K], or int32 labels [B] (+ scale, default 1/B) for fused mean cross-entropy."""
+    B, T, _ = x.shape
+    d = spec.dims(B, T)
+    L = _lib.lib()
+    pp = _dev_f32(flat, "params", (spec.param_count,))
+    if dlogits is None:
+        if labels is None:
+            raise NsdError("train_backward needs dlogits or labels")
+        if labels.dtype != torch.int32 or not labels.is_cuda or not labels.is_contiguous():
+            raise NsdError("labels must be a contiguous int32 tensor on the device")
+        lab_ptr = labels.data_ptr()
+    else:
+        lab_ptr = None
+    scale = (1.0 / max(B, 1)) if scale is None else float(scale)
+    flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0)
+    check(L.nsd_head_bwd(C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head"),
+                         _dev_f32(logits, "logits", (B, spec.K)), _dev_f32(dlogits, "dlogits", (B, spec.K)),
+                         lab_ptr, scale, ws.data_ptr(), _stream()), "nsd_head_bwd")
+    check(L.nsd_lstm_bwd(C.byref(d), pp, _dev_f32(x, "x"), _dev_f32(drop_lstm, "drop_lstm"), flags,
+                         ws.data_ptr(), None, _stream()), "nsd_lstm_bwd")
+    if grads is None:
+        grads = torch.empty(spec.param_count, dtype=torch.float32, device=x.device)
+        accumulate = False
+    check(L.nsd_grad_reduce(C.byref(d), ws.data_ptr(), _dev_f32(grads, "grads", (spec.param_count,)),
+                            1 if accumulate else 0, _stream()), "nsd_grad_reduce")
+    return grads
+
+
+def loss_sum(spec: ModelSpec, ws: torch.Tensor, B: int, T: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Sum of the per-trial CE losses written by the labels form of train_backward (device scalar)."""
+    d = spec.dims(B, T)
+    out = torch.empty(1, dtype=torch.float32, device=ws.device) if out is None else out
+    check(_lib.lib().nsd_loss_sum(C.byref(d), ws.data_ptr(), out.data_ptr(), _stream()), "nsd_loss_sum")
+    return out
+
+
+def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, step: int, lr: float = 1e-3,
+              beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0,
+              grad_scale: float = 1.0) -> None:
+    n = p.numel()
+    check(_lib.lib().nsd_adam_step(n, _dev_f32(p, "p"), _dev_f32(g, "g", p.shape), _dev_f32(m, "m", p.shape),
+                                   _dev_f32(v, "v", p.shape), lr, beta1, beta2, eps, weight_decay, grad_scale,
+                                   step, _stream()), "nsd_adam_step")
+
+
+def dropout_mask(seed: int, stream_id: int, p: float, shape, device) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.lib().nsd_dropout_mask(seed & 0xFFFFFFFFFFFFFFFF, stream_id, p, out.numel(), _dev_f32(out, "out"),
+                                      _stream()), "nsd_dropout_mask")
+    return out
+
+
+def rrelu_noise(seed: int, stream_id: int, shape, device) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.lib().nsd_rrelu_noise(seed & 0xFFFFFFFFFFFFFFFF, stream_id, out.numel(), _dev_f32(out, "out"),
+                                     _stream()), "nsd_rrelu_noise")
+    return out

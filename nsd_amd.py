@@ -1,0 +1,11 @@
+"""Import shim: `import nsd_amd` loads the package that lives in `neural-speech-decoding_amd/`
+(the directory name the project layout prescribes is not a valid Python identifier)."""
+import importlib.util as _ilu
+import os as _os
+import sys as _sys
+
+_dir = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "neural-speech-decoding_amd")
+_spec = _ilu.spec_from_file_location("nsd_amd", _os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = _ilu.module_from_spec(_spec)
+_sys.modules["nsd_amd"] = _mod
+_spec.loader.exec_module(_mod)
