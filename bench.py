@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""EEG-trials/sec of the train step (fwd + bwd + Adam [+ gradient all-reduce]) on N MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload at N=1 = BASELINE.json configs[1] ("cfg2"): the reference's 3-class model (C=8, H=48, L=2, K=3,
+fp32, the reference checkpoint's weights when tests/golden/weights_3class.npz is present), synthetic
+windows x = 2.7*N(0,1) of 8 ch x 250 steps, batch 256 per GPU, dropout 0.6 + RReLU noise ON (they are
+part of the reference's train() step).  For N>1 every rank keeps 256 trials (weak scaling) and the flat
+gradient (127 KB) is summed with one RCCL all-reduce per step.
+
+One JSON line on rank 0.  Besides the driver's contract it carries
+  roofline      for the dominant kernel (longest average launch): algorithmic FLOP per launch / measured
+                launch time against the fp32 peak (157.3 TFLOP/s; vector == f32-MFMA rate on gfx950), with
+                the HBM view next to it (algorithmic bytes per launch / time against 8 TB/s)
+  cpu_baseline  the same train step on PyTorch-CPU (oneDNN LSTM, all host cores), bounded to ~15 s
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_per_trial(T, C, H, L=2, K=3):
+    """SURVEY 8(d) contract figures for the fp32 H=48 path (per trial)."""
+    macs_step = 0
+    for l in range(L):
+        I = C if l == 0 else H
+        macs_step += 4 * H * (I + H)
+    fwd_flop = 2 * T * macs_step + 2 * T * H * 2
+    x_bytes = T * C * 4
+    hc_bytes = L * T * 2 * H * 4            # h and c per layer-step
+    return {
+        "flop_fwd": fwd_flop, "flop_bwd": 2 * fwd_flop, "flop_train": 3 * fwd_flop,
+        "bytes_fwd_kernel": x_bytes + hc_bytes,            # x read, h/c written once
+        "bytes_bwd_kernel": x_bytes + hc_bytes,            # x read again (dW_ih), h/c read once
+        "bytes_train": 2 * x_bytes + 2 * hc_bytes + K * 4,
+    }
+
+
+class KernelTimer:
+    """HIP events (torch.cuda.Event on the stream the kernels are launched on) around selected C-ABI launches."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = {n: [] for n in names}
+
+    @contextlib.contextmanager
+    def __call__(self, name):
+        if name not in self.names:
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self.events[name].append((a, b))
+
+    def mean_us(self):
+        return {n: (1e3 * sum(a.elapsed_time(b) for a, b in ev) / len(ev)) if ev else None for n, ev in self.events.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--T", type=int, default=250)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events")
+    args = ap.parse_args()
+
+    import nsd_amd
+    from nsd_amd import ops
+    from nsd_amd.trainer import Trainer, init_distributed
+
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    nsd_amd.load_library()
+
+    B, T, C, H, L, K = args.batch_per_gpu, args.T, 8, 48, 2, 3
+    model = nsd_amd.EEG_LSTM(C, H, L, K, dropout=0.60)
+    wpath = os.path.join(ROOT, "tests", "golden", "weights_3class.npz")
+    if os.path.exists(wpath):
+        w = np.load(wpath)
+        model.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files}, strict=True)
+        weights = "reference checkpoint"
+    else:
+        weights = "random init"
+    model.to(dev).train()
+    trainer = Trainer(model, lr=1e-3, seed=1234, stochastic=True)
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = (2.7 * torch.randn(B, T, C, generator=g)).to(dev)
+    y = torch.randint(0, K, (B,), generator=g).to(torch.int32).to(dev)
+
+    timer = None
+    if not args.no_kernel_timing:
+        timer = KernelTimer(["nsd_lstm_fwd", "nsd_lstm_bwd", "nsd_head_fwd", "nsd_head_bwd", "nsd_grad_reduce", "nsd_adam_step"])
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"warm-up: {args.warmup} steps of B={B}/GPU T={T} on {world} GPU(s)")
+    for _ in range(args.warmup):
+        trainer.step(x, y)
+    torch.cuda.synchronize()
+    note("timing")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if timer:
+        ops.set_launch_hook(timer)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.set_launch_hook(None)
+    loss = trainer.last_loss()
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        alg = algorithmic_per_trial(T, C, H, L, K)
+        ms_per_step = 1e3 * dt / args.steps
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "EEG-trials/sec (train fwd+bwd)", "value": round(value, 1), "unit": "trials/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2: 3-class EEG_LSTM train step (dropout 0.6 + RReLU noise, CE, Adam), "
+                                   f"8ch x {T}-step windows, batch {B}/GPU, H=48 L=2 fp32",
+                       "batch_per_gpu": B, "global_batch": B * world, "T": T, "C": C, "H": H, "L": L, "K": K,
+                       "weights": weights, "parallelism": f"dp{world}", "loss_last_step": round(loss, 5)},
+        }
+        if timer:
+            us = timer.mean_us()
+            flop = {"nsd_lstm_fwd": alg["flop_fwd"], "nsd_lstm_bwd": alg["flop_bwd"]}
+            byts = {"nsd_lstm_fwd": alg["bytes_fwd_kernel"], "nsd_lstm_bwd": alg["bytes_bwd_kernel"]}
+            dom = max(("nsd_lstm_fwd", "nsd_lstm_bwd"), key=lambda n: us[n] or 0.0)
+            t_s = us[dom] * 1e-6
+            tf = flop[dom] * B / t_s / 1e12
+            gbs = byts[dom] * B / t_s / 1e9
+            out["roofline"] = {
+                "kernel": {"nsd_lstm_fwd": "lstm2_fwd_kernel<48,NB>", "nsd_lstm_bwd": "lstm2_bwd_kernel<48,NB>"}[dom],
+                "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(us[dom], 2), "algorithmic_flop_per_launch": flop[dom] * B,
+                "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": byts[dom] * B},
+                "note": "fp32 path: arithmetic intensity ~110 FLOP/B >> ridge (~20), so the compute roof binds; "
+                        "peak = 157.3 TFLOP/s fp32 (vector == f32 MFMA rate)",
+            }
+            out["kernels_us"] = {k: (round(v, 2) if v is not None else None) for k, v in us.items()}
+            step_alg = alg["flop_train"] * B / (ms_per_step * 1e-3) / 1e12
+            out["step_frac_of_fp32_peak"] = round(step_alg / FP32_PEAK_TFLOPS, 4)
+            out["step_hbm_frac"] = round(alg["bytes_train"] * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        note(f"GPU: {value:.0f} trials/s, {ms_per_step:.3f} ms/step")
+        if world == 1 and not args.no_cpu_baseline:
+            note("timing the PyTorch-CPU baseline")
+            from oracle.torch_ref import time_cpu_train
+            cpu = time_cpu_train(B=B, T=T, C=C, H=H, L=L, K=K, budget_s=args.cpu_budget_s)
+            out["cpu_baseline"] = {"value": round(cpu["trials_per_s"], 1), "unit": "trials/s", "cores": cpu["threads"],
+                                   "kind": "port",
+                                   "sample": f"{cpu['steps']} train steps of the same workload (B={B}, T={T}) on PyTorch-CPU "
+                                             f"{torch.__version__} (stock nn.LSTM/oneDNN re-declaration of the reference module), "
+                                             f"median {cpu['ms_per_step']:.1f} ms/step"}
+            out["speedup_vs_cpu"] = round(value / cpu["trials_per_s"], 1)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

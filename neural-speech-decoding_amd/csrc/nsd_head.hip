@@ -176,9 +176,10 @@ __global__ __launch_bounds__(HEAD_NT) void head_bwd_kernel(HeadArgs a) {
                 const int y = a.labels[b];
                 float m2 = lg[0];
                 for (int k = 1; k < K; ++k) m2 = fmaxf(m2, lg[k]);
-                float d = 0.f;
-                for (int k = 0; k < K; ++k) d += expf(lg[k] - m2);
-                for (int k = 0; k < K; ++k) vdl[k] = (expf(lg[k] - m2) / d - (k == y ? 1.f : 0.f)) * a.scale;
+                // softmax - onehot without cancellation: for the label class p_y - 1 = -(sum_{k != y} e_k) / d
+                float d = 0.f, rest = 0.f;
+                for (int k = 0; k < K; ++k) { const float e = expf(lg[k] - m2); d += e; if (k != y) rest += e; }
+                for (int k = 0; k < K; ++k) vdl[k] = (k == y ? -rest / d : expf(lg[k] - m2) / d) * a.scale;
                 if (a.loss) a.loss[b] = -((lg[y] - m2) - logf(d));
             }
         }

@@ -59,7 +59,7 @@ class ModelSpec:
     def offsets(self) -> Dict[str, int]:
         n = 4 * self.L + 8
         offs = (C.c_int64 * n)()
-        check(_lib.lib().nsd_param_layout(self.C, self.H, self.L, self.K, self.F, offs), "nsd_param_layout")
+        _call("nsd_param_layout", self.C, self.H, self.L, self.K, self.F, offs)
         return dict(zip(self.names(), [int(o) for o in offs]))
 
     def fast_path(self) -> bool:
@@ -82,6 +82,24 @@ def _dev_f32(t: Optional[torch.Tensor], name: str, shape=None) -> Optional[int]:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+_launch_hook = None
+
+
+def set_launch_hook(hook) -> None:
+    """bench.py: hook(name) -> context manager entered around each C-ABI launch (HIP-event timing)."""
+    global _launch_hook
+    _launch_hook = hook
+
+
+def _call(name: str, *args) -> None:
+    fn = getattr(_lib.lib(), name)
+    if _launch_hook is None:
+        check(fn(*args), name)
+    else:
+        with _launch_hook(name):
+            check(fn(*args), name)
 
 
 def workspace_layout(spec: ModelSpec, B: int, T: int) -> Tuple[int, WsLayout]:
@@ -121,7 +139,7 @@ def zscore(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     x3 = x3.contiguous()
     y = torch.empty_like(x3) if out is None else out
     B, T, Cc = x3.shape
-    check(_lib.lib().nsd_zscore_fwd(_dev_f32(x3, "x"), _dev_f32(y, "y", x3.shape), B, T, Cc, _stream()), "nsd_zscore_fwd")
+    _call("nsd_zscore_fwd", _dev_f32(x3, "x"), _dev_f32(y, "y", x3.shape), B, T, Cc, _stream())
     return y[0] if squeeze else y
 
 
@@ -134,11 +152,14 @@ def infer(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, *, residual: boo
     d = spec.dims(B, T)
     logits = torch.empty((B, spec.K), dtype=torch.float32, device=x.device)
     probs = torch.empty_like(logits) if want_probs else None
+    if B == 0:                      # empty batch: nothing to launch (empty tensors have no device pointer)
+        _dev_f32(flat, "params", (spec.param_count,)); _dev_f32(x, "x")
+        return logits, probs
     nscr = _lib.lib().nsd_infer_scratch_bytes(C.byref(d))
     scratch = torch.empty(max(int(nscr) // 4, 1), dtype=torch.float32, device=x.device)
-    check(_lib.lib().nsd_infer(C.byref(d), _dev_f32(flat, "params", (spec.param_count,)), _dev_f32(x, "x"),
+    _call("nsd_infer", C.byref(d), _dev_f32(flat, "params", (spec.param_count,)), _dev_f32(x, "x"),
                                _lib.NSD_FLAG_RESIDUAL if residual else 0, _dev_f32(logits, "logits"),
-                               _dev_f32(probs, "probs"), scratch.data_ptr(), _stream()), "nsd_infer")
+                               _dev_f32(probs, "probs"), scratch.data_ptr(), _stream())
     return logits, probs
 
 
@@ -155,14 +176,14 @@ def train_forward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: torc
     nbytes, _ = workspace_layout(spec, B, T)
     if ws.numel() * 4 < nbytes:
         raise NsdError(f"workspace too small: {ws.numel() * 4} < {nbytes} bytes")
-    check(L.nsd_lstm_fwd(C.byref(d), pp, _dev_f32(x, "x", (B, T, spec.C)),
+    _call("nsd_lstm_fwd", C.byref(d), pp, _dev_f32(x, "x", (B, T, spec.C)),
                          _dev_f32(drop_lstm, "drop_lstm", (spec.L - 1, B, T, spec.H)), flags,
-                         _dev_f32(ws, "workspace"), _stream()), "nsd_lstm_fwd")
+                         _dev_f32(ws, "workspace"), _stream())
     logits = torch.empty((B, spec.K), dtype=torch.float32, device=x.device)
     probs = torch.empty_like(logits) if want_probs else None
-    check(L.nsd_head_fwd(C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope", (B, spec.F)),
+    _call("nsd_head_fwd", C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope", (B, spec.F)),
                          _dev_f32(drop_head, "drop_head", (B, spec.F)), ws.data_ptr(), logits.data_ptr(),
-                         _dev_f32(probs, "probs"), _stream()), "nsd_head_fwd")
+                         _dev_f32(probs, "probs"), _stream())
     return logits, probs
 
 
@@ -187,16 +208,16 @@ def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: tor
         lab_ptr = None
     scale = (1.0 / max(B, 1)) if scale is None else float(scale)
     flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0)
-    check(L.nsd_head_bwd(C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head"),
+    _call("nsd_head_bwd", C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head"),
                          _dev_f32(logits, "logits", (B, spec.K)), _dev_f32(dlogits, "dlogits", (B, spec.K)),
-                         lab_ptr, scale, ws.data_ptr(), _stream()), "nsd_head_bwd")
-    check(L.nsd_lstm_bwd(C.byref(d), pp, _dev_f32(x, "x"), _dev_f32(drop_lstm, "drop_lstm"), flags,
-                         ws.data_ptr(), None, _stream()), "nsd_lstm_bwd")
+                         lab_ptr, scale, ws.data_ptr(), _stream())
+    _call("nsd_lstm_bwd", C.byref(d), pp, _dev_f32(x, "x"), _dev_f32(drop_lstm, "drop_lstm"), flags,
+                         ws.data_ptr(), None, _stream())
     if grads is None:
         grads = torch.empty(spec.param_count, dtype=torch.float32, device=x.device)
         accumulate = False
-    check(L.nsd_grad_reduce(C.byref(d), ws.data_ptr(), _dev_f32(grads, "grads", (spec.param_count,)),
-                            1 if accumulate else 0, _stream()), "nsd_grad_reduce")
+    _call("nsd_grad_reduce", C.byref(d), ws.data_ptr(), _dev_f32(grads, "grads", (spec.param_count,)),
+                            1 if accumulate else 0, _stream())
     return grads
 
 
@@ -204,7 +225,7 @@ def loss_sum(spec: ModelSpec, ws: torch.Tensor, B: int, T: int, out: Optional[to
     """Sum of the per-trial CE losses written by the labels form of train_backward (device scalar)."""
     d = spec.dims(B, T)
     out = torch.empty(1, dtype=torch.float32, device=ws.device) if out is None else out
-    check(_lib.lib().nsd_loss_sum(C.byref(d), ws.data_ptr(), out.data_ptr(), _stream()), "nsd_loss_sum")
+    _call("nsd_loss_sum", C.byref(d), ws.data_ptr(), out.data_ptr(), _stream())
     return out
 
 
@@ -212,20 +233,20 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0,
               grad_scale: float = 1.0) -> None:
     n = p.numel()
-    check(_lib.lib().nsd_adam_step(n, _dev_f32(p, "p"), _dev_f32(g, "g", p.shape), _dev_f32(m, "m", p.shape),
+    _call("nsd_adam_step", n, _dev_f32(p, "p"), _dev_f32(g, "g", p.shape), _dev_f32(m, "m", p.shape),
                                    _dev_f32(v, "v", p.shape), lr, beta1, beta2, eps, weight_decay, grad_scale,
-                                   step, _stream()), "nsd_adam_step")
+                                   step, _stream())
 
 
 def dropout_mask(seed: int, stream_id: int, p: float, shape, device) -> torch.Tensor:
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    check(_lib.lib().nsd_dropout_mask(seed & 0xFFFFFFFFFFFFFFFF, stream_id, p, out.numel(), _dev_f32(out, "out"),
-                                      _stream()), "nsd_dropout_mask")
+    _call("nsd_dropout_mask", seed & 0xFFFFFFFFFFFFFFFF, stream_id, p, out.numel(), _dev_f32(out, "out"),
+                                      _stream())
     return out
 
 
 def rrelu_noise(seed: int, stream_id: int, shape, device) -> torch.Tensor:
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    check(_lib.lib().nsd_rrelu_noise(seed & 0xFFFFFFFFFFFFFFFF, stream_id, out.numel(), _dev_f32(out, "out"),
-                                     _stream()), "nsd_rrelu_noise")
+    _call("nsd_rrelu_noise", seed & 0xFFFFFFFFFFFFFFFF, stream_id, out.numel(), _dev_f32(out, "out"),
+                                     _stream())
     return out

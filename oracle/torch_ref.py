@@ -96,14 +96,39 @@ class TorchRefEEG(nn.Module):
         return self.dense_b(z)
 
 
+def host_cores() -> int:
+    """CPU cores this process may really use: the cgroup quota if there is one (a GPU box exposes all
+    host CPUs in the affinity mask but grants a share of them), else the affinity mask."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, math.ceil(float(quota) / period)))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("NSD_CPU_THREADS")
+    if env:
+        n = int(env)
+    elif n > 32:
+        n = 16      # no quota visible: gpurun's documented CPU share for a one-GPU box
+    return max(1, n)
+
+
 def time_cpu_train(B=256, T=250, C=8, H=48, L=2, K=3, threads: Optional[int] = None,
                    budget_s: float = 15.0, min_steps: int = 3, seed: int = 1234):
     """CPU baseline: CE train step (zero_grad, fwd with dropout+RReLU noise, bwd, Adam lr=1e-3)
     on synthetic x = 2.7*randn.  Runs whole steps until ~budget_s of CPU time is spent.
     Returns dict(trials_per_s, ms_per_step, steps, threads)."""
-    import os
     import time
-    threads = threads or os.cpu_count() or 1
+    threads = threads or host_cores()
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(seed)
     x = 2.7 * torch.randn(B, T, C, generator=g)

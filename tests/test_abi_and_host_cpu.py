@@ -1,0 +1,167 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/nsd.h declares,
+layouts agree with the oracle, the Python facade keeps the reference's surface, the producer protocol
+works, and the product path refuses to run without the HIP device (no fallback)."""
+import os
+import re
+import time
+from multiprocessing import Queue
+
+import numpy as np
+import pytest
+import torch
+
+import nsd_amd
+from nsd_amd import _lib, ops
+from oracle import nsd_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "nsd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nsd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes parsed"
+    L = nsd_amd.load_library()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in nsd.h but not exported"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert L.nsd_version() == 100
+
+
+@pytest.mark.parametrize("dims", [orc.Dims(), orc.Dims(H=256, K=5), orc.Dims(C=64, H=512, L=3, K=5), orc.Dims(L=1)])
+def test_param_layout_matches_oracle_and_reference_order(dims):
+    spec = ops.ModelSpec(C=dims.C, H=dims.H, L=dims.L, K=dims.K, F=dims.F)
+    assert spec.param_count == orc.param_count(dims)
+    assert spec.offsets() == orc.layout(dims)
+    assert spec.names() == orc.param_names(dims) and spec.shapes() == orc.param_shapes(dims)
+
+
+def test_reference_sizes():
+    assert ops.ModelSpec().param_count == 31764
+    assert ops.ModelSpec(H=256, K=5).param_count == 807878
+    assert ops.ModelSpec().fast_path() and not ops.ModelSpec(H=256).fast_path()
+    assert ops.ModelSpec(C=0).dims(1, 1).C == 0
+    with pytest.raises(nsd_amd.NsdError):
+        _ = ops.ModelSpec(C=0).param_count
+
+
+def test_workspace_layout_is_disjoint_and_aligned():
+    spec = ops.ModelSpec()
+    nbytes, w = ops.workspace_layout(spec, 256, 250)
+    regs = ["hseq", "cseq", "gact", "inseq", "top", "alpha", "pooled", "fc0_pre", "dscore", "dpooled", "loss", "slabs", "hslabs"]
+    offs = [getattr(w, r) for r in regs]
+    assert offs == sorted(offs) and all(o % 4 == 0 for o in offs) and nbytes == 4 * w.total
+    B, T, H = 256, 250, 48
+    assert w.cseq - w.hseq >= 2 * B * T * H and w.inseq - w.gact >= 8 * B * T * H
+    assert w.total - w.hslabs >= B * (31764 - 29952)
+    # algorithmic bytes/trial of the training path: h and c per layer-step, written once + read once
+    assert 2 * (2 * T * 2 * H * 4) + 2 * T * 8 * 4 + 12 == 400012
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    L = nsd_amd.load_library()
+    import ctypes as C
+    d = _lib.Dims(4, 10, 8, 48, 2, 3, 32)
+    assert L.nsd_infer(C.byref(d), None, None, 0, None, None, None, None) == -1
+    assert b"null" in L.nsd_last_error()
+    bad = _lib.Dims(4, 0, 8, 48, 2, 3, 32)
+    assert L.nsd_workspace_bytes(C.byref(bad), None) < 0
+    assert L.nsd_adam_step(-1, None, None, None, None, 0, 0, 0, 0, 0, 1, 1, None) == -1
+    assert L.nsd_param_count(8, 48, 9, 3, 32) < 0                  # more than NSD_MAX_LAYERS
+
+
+def test_facade_surface_matches_reference(ref_state):
+    import inspect
+    sig = inspect.signature(nsd_amd.EEG_LSTM.__init__)
+    assert [(k, v.default) for k, v in list(sig.parameters.items())[1:6]] == [
+        ("input_size", 8), ("hidden_size", 48), ("num_layers", 2), ("num_classes", 3), ("dropout", 0.60)]
+    sp = inspect.signature(nsd_amd.SimplePredictor.__init__)
+    names = list(sp.parameters)[1:12]
+    assert names == ["pth_path", "sr", "channel_order", "input_size", "hidden_size", "num_layers", "num_classes",
+                     "dropout", "device", "tailoring_lambda", "class_names"]
+    assert sp.parameters["device"].default == "cpu" and sp.parameters["tailoring_lambda"].default == 1.25e-29
+    rt = inspect.signature(nsd_amd.run_trials)
+    assert [(k, v.default) for k, v in list(rt.parameters.items())[:6]] == [
+        ("trials", 10), ("serial_port", nsd_amd.DEFAULT_SERIAL), ("num_channels", 8), ("window_seconds", 5.0),
+        ("model_path", nsd_amd.DEFAULT_MODEL), ("verbose", True)]
+    assert nsd_amd.CLASS_NAMES == ["Food", "Water", "BG-Noise"]
+    r = nsd_amd.TrialResult(trials=0, avg_probs=None)
+    assert r.avg_chunk is None
+
+    m = nsd_amd.EEG_LSTM()
+    assert list(m.state_dict().keys()) == list(ref_state.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in ref_state.items()}, strict=True)
+    flat = m.flat_parameters()
+    assert np.array_equal(flat.numpy(), orc.flatten_state(ref_state, orc.Dims()))
+    with torch.no_grad():
+        m.attn.bias.add_(1.0)                                       # parameters are views of the flat vector
+    assert flat[ops.ModelSpec().offsets()["attn.bias"]].item() == pytest.approx(float(ref_state["attn.bias"][0]) + 1.0)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"bogus": torch.zeros(1)}, strict=True)
+
+
+def test_no_cpu_fallback():
+    m = nsd_amd.EEG_LSTM()
+    with pytest.raises(nsd_amd.NsdError, match="no CPU fallback"):
+        m(torch.zeros(2, 10, 8))
+    with pytest.raises(nsd_amd.NsdError):
+        ops.zscore(torch.zeros(2, 10, 8))
+    if not torch.cuda.is_available():
+        with pytest.raises(nsd_amd.NsdError, match="MI355X"):
+            nsd_amd.SimplePredictor("missing.pth", sr=125)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "neural-speech-decoding_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("nsd_oracle.c (nsd_oracle_rand_u32)", ""), fn
+
+
+def _drain(q, n, timeout=20.0):
+    out, t0 = [], time.time()
+    while len(out) < n and time.time() - t0 < timeout:
+        try:
+            out.append(q.get(timeout=0.5))
+        except Exception:
+            pass
+    return out
+
+
+def test_replay_producer_protocol(tmp_path, golden):
+    g = golden("real_trials")
+    for i in range(3):
+        np.savetxt(tmp_path / f"water_{i}.csv", g["x"][i], fmt="%.7f", delimiter=",")
+    q = Queue(maxsize=8)
+    p = nsd_amd.StreamingProcess(serial_port=f"replay:{tmp_path}", num_channels=8, window_seconds=5.0, out_queue=q)
+    p.start()
+    try:
+        time.sleep(0.2)
+        assert q.empty()                                   # nothing until recording_flag is raised
+        p.recording_flag.value = True
+        items = _drain(q, 4)
+        assert len(items) == 4
+        for k, it in enumerate(items):
+            assert set(it) == {"sr", "channels", "data", "t_emit"} and it["sr"] == 125
+            assert it["data"].dtype == np.float32 and it["data"].shape == (625, 8)
+            assert np.allclose(it["data"], g["x"][k % 3], atol=1e-6)   # %.7f round trip, files cycle in order
+    finally:
+        p.stop(); p.join(timeout=5.0)
+        if p.is_alive():
+            p.terminate()
+
+
+def test_synthetic_producer_and_dead_producer():
+    q = Queue(maxsize=8)
+    p = nsd_amd.StreamingProcess(serial_port="synthetic:3", num_channels=4, window_seconds=1.0, out_queue=q, start_recording=True)
+    p.start()
+    try:
+        it = _drain(q, 1)[0]
+        assert it["data"].shape == (125, 4) and np.isfinite(it["data"]).all()
+    finally:
+        p.stop(); p.join(timeout=5.0)
+    with pytest.raises(RuntimeError, match="Producer exited unexpectedly"):
+        nsd_amd.run_trials(trials=1, serial_port="/dev/cu.usbserial-FTB6SPL3", model_path="unused", verbose=False,
+                           queue_timeout=0.5)

@@ -1,0 +1,368 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors captured
+from the reference.  Needs a real MI355X: run with `pytest -m gpu`.
+
+Tolerances: class logits within 1e-4 (north_star), argmax identical; gradients within 2e-4 of the
+largest entry of each tensor (the oneDNN reference and an independent fp32 restatement agree to ~2e-6
+relative); integer / mask streams bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsd_oracle as orc
+from tests.golden.make_goldens import SYNTH_SHAPES, counter_masks, synth_labels, synth_params, synth_x
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+D = orc.Dims()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def nsd():
+    import nsd_amd
+    nsd_amd.load_library()          # raises if libnsd_hip.so is missing: no fallback
+    return nsd_amd
+
+
+def _model(nsd, dev, state, **kw):
+    H = state["lstm.weight_hh_l0"].shape[1]
+    L = sum(1 for k in state if k.startswith("lstm.weight_hh_l"))
+    m = nsd.EEG_LSTM(input_size=state["lstm.weight_ih_l0"].shape[1], hidden_size=H, num_layers=L,
+                     num_classes=state["fc.3.weight"].shape[0], **kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()}, strict=True)
+    return m.to(dev)
+
+
+def _t(a, dev):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _grad_close(got_flat, ref_flat, d, rtol=2e-4):
+    got, ref = orc.unflatten(got_flat, d), orc.unflatten(ref_flat, d)
+    for k in orc.param_names(d):
+        err = np.abs(got[k] - ref[k]).max()
+        if k == "attn.bias":
+            assert err < 2e-6, (k, err)
+        else:
+            assert err <= rtol * max(np.abs(ref[k]).max(), 1e-6) + 1e-7, (k, err, np.abs(ref[k]).max())
+
+
+# ---------------------------------------------------------------------------------------------------
+# inference
+# ---------------------------------------------------------------------------------------------------
+def test_real_trials_match_reference(nsd, dev, golden, ref_state):
+    g = golden("real_trials")
+    m = _model(nsd, dev, ref_state).eval()
+    x = _t(g["x"], dev)
+    with torch.no_grad():
+        lg = m(x).cpu().numpy()
+        pr = m.predict_proba(x).cpu().numpy()
+        single = torch.cat([m(x[i:i + 1]) for i in range(x.shape[0])]).cpu().numpy()
+    assert np.abs(lg - g["logits"]).max() < LOGIT_TOL
+    assert np.abs(single - g["logits_single"]).max() < LOGIT_TOL
+    assert np.array_equal(lg.argmax(-1), g["argmax"]) and np.array_equal(single.argmax(-1), g["argmax"])
+    assert np.abs(pr - g["probs"]).max() < 1e-5
+    assert np.array_equal(lg, single)      # batch-invariant bit for bit (each trial is computed independently)
+
+
+@pytest.mark.parametrize("B,T", SYNTH_SHAPES)
+def test_synthetic_shapes_match_reference(nsd, dev, golden, ref_state, B, T):
+    ref = golden("synthetic")[f"logits_{B}x{T}"]
+    m = _model(nsd, dev, ref_state).eval()
+    with torch.no_grad():
+        lg = m(_t(synth_x(B, T), dev)).cpu().numpy()
+    assert np.abs(lg - ref).max() < LOGIT_TOL
+    assert np.array_equal(lg.argmax(-1), ref.argmax(-1))
+
+
+def test_empty_batch_and_bad_shapes(nsd, dev, ref_state):
+    m = _model(nsd, dev, ref_state).eval()
+    with torch.no_grad():
+        assert tuple(m(torch.zeros(0, 50, 8, device=dev)).shape) == (0, 3)
+    with pytest.raises(ValueError):
+        m(torch.zeros(4, 50, 7, device=dev))
+    with pytest.raises(nsd.NsdError):
+        m(torch.zeros(4, 50, 8))                       # CPU input: fails loudly, no fallback
+    with pytest.raises(nsd.NsdError):
+        nsd.EEG_LSTM()(torch.zeros(1, 5, 8))          # CPU module
+
+
+def test_noncontiguous_input_like_predict(nsd, dev, ref_state, golden):
+    g = golden("real_trials")
+    m = _model(nsd, dev, ref_state).eval()
+    xt = _t(np.ascontiguousarray(g["x"][:3].transpose(0, 2, 1)), dev).transpose(1, 2)   # [B,T,C] view of [B,C,T]
+    assert not xt.is_contiguous()
+    with torch.no_grad():
+        lg = m(xt).cpu().numpy()
+    assert np.abs(lg - g["logits"][:3]).max() < LOGIT_TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# training forward: per-stage intermediates kept in the workspace
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,masked", [(7, 33, False), (5, 70, True), (1, 1, False), (3, 2, True)])
+def test_train_forward_intermediates(nsd, dev, ref_state, B, T, masked):
+    from nsd_amd import ops
+    flat_np = orc.flatten_state(ref_state, D)
+    x = synth_x(B, T, seed=3)
+    dl, sl, dh = counter_masks(B, T, 48, 32, seed=B * 100 + T) if masked else (None, None, None)
+    ref = orc.forward(flat_np, x, D, drop_lstm=dl, rrelu_slope=sl, drop_head=dh, saves=True)
+    spec = ops.ModelSpec()
+    flat, xt = _t(flat_np, dev), _t(x, dev)
+    ws = ops.new_workspace(spec, B, T, dev)
+    logits, probs = ops.train_forward(spec, flat, xt, ws, drop_lstm=_t(dl, dev), rrelu_slope=_t(sl, dev),
+                                      drop_head=_t(dh, dev), want_probs=True)
+    v = lambda r: ops.ws_view(ws, spec, B, T, r).cpu().numpy()
+    assert np.abs(v("hseq") - ref["hseq"]).max() < 2e-5
+    assert np.abs(v("cseq") - ref["cseq"]).max() < 5e-5
+    gact = v("gact").transpose(0, 1, 2, 4, 3)          # [L,B,T,H,4] -> [L,B,T,4,H]
+    assert np.abs(gact - ref["gates"]).max() < 2e-5
+    assert np.abs(v("alpha") - ref["alpha"]).max() < 1e-6
+    assert np.abs(v("pooled") - ref["pooled"]).max() < 2e-5
+    assert np.abs(v("fc0_pre") - ref["fc0_pre"]).max() < 5e-5
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL
+    assert np.abs(probs.cpu().numpy() - ref["probs"]).max() < 1e-5
+    if masked:
+        assert np.abs(v("inseq")[0] - ref["hseq"][0] * dl[0]).max() < 5e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# gradients
+# ---------------------------------------------------------------------------------------------------
+def _hip_loss_grads(nsd, dev, flat_np, x, y, spec=None, scale=None, **masks):
+    from nsd_amd import ops
+    spec = spec or ops.ModelSpec()
+    B, T, _ = x.shape
+    flat, xt = _t(flat_np, dev), _t(x, dev)
+    ws = ops.new_workspace(spec, B, T, dev)
+    mk = {k: _t(v, dev) for k, v in masks.items() if k != "residual"}
+    res = masks.get("residual", False)
+    logits, _ = ops.train_forward(spec, flat, xt, ws, residual=res, **mk)
+    g = ops.train_backward(spec, flat, xt, ws, logits, labels=_t(y.astype(np.int32), dev), scale=scale, residual=res, **mk)
+    loss = float(ops.loss_sum(spec, ws, B, T).item()) / B
+    return loss, g.cpu().numpy(), logits.cpu().numpy()
+
+
+def test_gradients_vs_reference_goldens(nsd, dev, golden, ref_state):
+    g = golden("grads_32x250")
+    flat_np = orc.flatten_state(ref_state, D)
+    x, y = synth_x(32, 250), synth_labels(32)
+    loss, grads, _ = _hip_loss_grads(nsd, dev, flat_np, x, y)
+    assert abs(loss - float(g["eval.loss"])) < 2e-5
+    _grad_close(grads, orc.flatten_state({k: g["eval." + k] for k in orc.param_names(D)}, D), D)
+    dl, sl, dh = counter_masks(32, 250, 48, 32)
+    loss, grads, _ = _hip_loss_grads(nsd, dev, flat_np, x, y, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    assert abs(loss - float(g["masked.loss"])) < 5e-5
+    _grad_close(grads, orc.flatten_state({k: g["masked." + k] for k in orc.param_names(D)}, D), D)
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 3), (9, 64), (5, 33), (300, 20), (700, 9)])
+def test_gradients_vs_oracle_ragged_shapes(nsd, dev, ref_state, B, T):
+    # B > 256 exercises the 2- and 4-trials-per-workgroup kernels and partial trial groups
+    flat_np = orc.flatten_state(ref_state, D)
+    x, y = synth_x(B, T, seed=B + T), synth_labels(B, seed=B + T)
+    dl, sl, dh = counter_masks(B, T, 48, 32, seed=7 * B + T)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, D, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, x, y, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL
+    assert abs(loss - loss_ref) < 5e-5
+    _grad_close(grads, g_ref, D, rtol=3e-4)
+
+
+def test_residual_extension(nsd, dev, golden):
+    e = golden("extensions")
+    flat_np = orc.flatten_state(synth_params(8, 48, 2, 3, seed=7), D)
+    x, y = synth_x(5, 40, seed=5), synth_labels(5, seed=5)
+    loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, x, y, residual=True)
+    assert np.abs(logits - e["residual.logits"]).max() < 2e-5
+    _grad_close(grads, orc.flatten_state({k: e["residual.grad." + k] for k in orc.param_names(D)}, D), D)
+    m = _model(nsd, dev, synth_params(8, 48, 2, 3, seed=7), residual=True).eval()
+    with torch.no_grad():
+        assert np.abs(m(_t(x, dev)).cpu().numpy() - e["residual.logits"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("H,C,K", [(32, 8, 3), (64, 8, 5), (48, 5, 4), (48, 1, 2)])
+def test_other_fast_path_shapes_vs_oracle(nsd, dev, H, C, K):
+    from nsd_amd import ops
+    d = orc.Dims(C=C, H=H, L=2, K=K)
+    spec = ops.ModelSpec(C=C, H=H, L=2, K=K)
+    assert spec.param_count == orc.param_count(d) and spec.offsets() == orc.layout(d)
+    flat_np = orc.flatten_state(synth_params(C, H, 2, K, seed=H + C), d)
+    B, T = 6, 45
+    x, y = synth_x(B, T, C=C, seed=H), synth_labels(B, K=K, seed=H)
+    dl, sl, dh = counter_masks(B, T, H, 32, seed=H)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, d, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, x, y, spec=spec, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
+    _grad_close(grads, g_ref, d, rtol=3e-4)
+
+
+def test_unsupported_shape_fails_loudly(nsd, dev):
+    from nsd_amd import ops
+    spec = ops.ModelSpec(H=256, K=5)       # cfg3 shape: not covered by the fused kernels yet
+    flat = torch.zeros(spec.param_count, device=dev)
+    with pytest.raises(nsd.NsdError, match="not covered"):
+        ops.infer(spec, flat, torch.zeros(2, 10, 8, device=dev))
+
+
+# ---------------------------------------------------------------------------------------------------
+# full BASELINE sizes through size-independent properties
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_properties(nsd, dev, ref_state):
+    """cfg2 (B=256) and cfg4-per-GPU (B=1024), T=250: (a) logits of a big batch equal the logits of its
+    sub-batches bit for bit across the 1/2/4-trials-per-workgroup kernels; (b) gradients are linear:
+    grad(batch) == grad(first half) + grad(second half) with a common scale; (c) a permutation of the
+    trials permutes the logits and leaves the summed gradient unchanged to rounding."""
+    from nsd_amd import ops
+    spec = ops.ModelSpec()
+    flat = _t(orc.flatten_state(ref_state, D), dev)
+    B, T = 1024, 250
+    x, y = _t(synth_x(B, T, seed=77), dev), _t(synth_labels(B, seed=77), dev)
+    m = _model(nsd, dev, ref_state).eval()
+    with torch.no_grad():
+        big = m(x)
+        assert torch.equal(big[:256], m(x[:256])) and torch.equal(big[256:768], m(x[256:768]))
+        assert torch.equal(big[1000:1001], m(x[1000:1001]))
+
+    def grads(xs, ys, scale):
+        ws = ops.new_workspace(spec, xs.shape[0], T, dev)
+        lg, _ = ops.train_forward(spec, flat, xs, ws)
+        return ops.train_backward(spec, flat, xs, ws, lg, labels=ys, scale=scale)
+
+    g_all = grads(x, y, 1.0 / B)
+    g_sum = grads(x[:512].contiguous(), y[:512].contiguous(), 1.0 / B) + grads(x[512:].contiguous(), y[512:].contiguous(), 1.0 / B)
+    scale = g_all.abs().max().item()
+    assert (g_all - g_sum).abs().max().item() < 2e-5 * scale
+    perm = torch.from_numpy(np.random.RandomState(1).permutation(B)).to(dev)
+    with torch.no_grad():
+        assert torch.equal(m(x[perm].contiguous()), big[perm])
+    g_perm = grads(x[perm].contiguous(), y[perm].contiguous(), 1.0 / B)
+    assert (g_all - g_perm).abs().max().item() < 2e-5 * scale
+
+
+# ---------------------------------------------------------------------------------------------------
+# small kernels
+# ---------------------------------------------------------------------------------------------------
+def test_zscore(nsd, dev, golden):
+    from nsd_amd import ops
+    z = golden("zscore")
+    got = ops.zscore(_t(z["chunk"], dev)).cpu().numpy()
+    assert np.abs(got - z["normalized"]).max() < 2e-5
+    x = synth_x(9, 77, C=5, seed=2)
+    assert np.abs(ops.zscore(_t(x, dev)).cpu().numpy() - orc.zscore(x)).max() < 2e-5
+    const = np.ones((2, 10, 8), np.float32)            # zero variance: eps keeps it finite
+    assert np.array_equal(ops.zscore(_t(const, dev)).cpu().numpy(), np.zeros_like(const))
+
+
+def test_counter_streams_bit_exact(nsd, dev):
+    from nsd_amd import ops
+    for seed, stream in [(0, 0), (12345678901234, 3), (2**63 + 5, 4000000000)]:
+        a = ops.dropout_mask(seed, stream, 0.6, (3, 1000), dev).cpu().numpy()
+        assert np.array_equal(a, orc.dropout_mask(seed, stream, 0.6, (3, 1000)))
+        b = ops.rrelu_noise(seed, stream, (777,), dev).cpu().numpy()
+        assert np.array_equal(b, orc.rrelu_noise(seed, stream, (777,)))
+
+
+def test_adam_matches_oracle_and_torch(nsd, dev):
+    from nsd_amd import ops
+    rs = np.random.RandomState(0)
+    n = 31764
+    p0 = rs.standard_normal(n).astype(np.float32)
+    po, mo, vo = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    p, m, v = _t(p0, dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([pt], lr=1e-3)
+    for step in range(1, 8):
+        g = rs.standard_normal(n).astype(np.float32)
+        ops.adam_step(p, _t(g, dev), m, v, step=step, lr=1e-3)
+        orc.adam(po, g, mo, vo, lr=1e-3, step=step)
+        pt.grad = torch.from_numpy(g.copy())
+        opt.step()
+    assert np.abs(p.cpu().numpy() - po).max() < 1e-6
+    assert np.abs(p.cpu().numpy() - pt.detach().numpy()).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# module / predictor / harness surface
+# ---------------------------------------------------------------------------------------------------
+def test_module_autograd_and_state_dict(nsd, dev, golden, ref_state):
+    g = golden("grads_32x250")
+    m = _model(nsd, dev, ref_state)
+    assert list(m.state_dict().keys()) == list(ref_state.keys())
+    m.eval()                                   # eval-mode RReLU, no dropout, but gradients requested
+    x, y = _t(synth_x(32, 250), dev), _t(synth_labels(32).astype(np.int64), dev)
+    loss = torch.nn.functional.cross_entropy(m(x), y)
+    loss.backward()
+    assert abs(loss.item() - float(g["eval.loss"])) < 2e-5
+    for k, p in m.named_parameters():
+        r = g["eval." + k]
+        tol = 2e-6 if k == "attn.bias" else 2e-4 * max(np.abs(r).max(), 1e-6) + 1e-7
+        assert np.abs(p.grad.cpu().numpy() - r).max() <= tol, k
+    # a torch optimizer step on the Parameters is visible to the kernels (views of one flat vector)
+    before = m.flat_parameters().clone()
+    torch.optim.SGD(m.parameters(), lr=0.1).step()
+    assert not torch.equal(before, m.flat_parameters())
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    m2 = nsd.EEG_LSTM().to(dev)
+    m2.load_state_dict(sd, strict=True)
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x), m2(x))
+
+
+def test_train_mode_is_stochastic_and_seeded(nsd, dev, ref_state):
+    torch.manual_seed(5)
+    m = _model(nsd, dev, ref_state).train()
+    x = _t(synth_x(8, 50), dev)
+    a, b = m(x), m(x)
+    assert not torch.equal(a, b)               # fresh dropout / RReLU noise every call
+    torch.manual_seed(5)
+    m2 = _model(nsd, dev, ref_state).train()
+    assert torch.equal(m2(x), a)               # same seed -> same stream
+    a.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def _write_pth(tmp_path, ref_state, wrapped=False):
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in ref_state.items()}
+    p = os.path.join(tmp_path, "model.pth")
+    torch.save({"state_dict": sd} if wrapped else sd, p)
+    return p
+
+
+@pytest.mark.parametrize("wrapped", [False, True])
+def test_simple_predictor(nsd, dev, golden, ref_state, tmp_path, wrapped):
+    g = golden("real_trials")
+    pred = nsd.SimplePredictor(_write_pth(str(tmp_path), ref_state, wrapped), sr=125, device="cpu",
+                               class_names=["Food", "Water", "None"])
+    for i in (0, 7, 15):
+        probs, label = pred.predict(g["x"][i])
+        assert probs.dtype == np.float32 and probs.shape == (3,)
+        assert np.abs(probs - g["probs"][i]).max() < 1e-5
+        assert label == ["Food", "Water", "None"][int(g["argmax"][i])]
+    with pytest.raises(ValueError):
+        pred.predict(np.zeros((2, 3, 4), np.float32))
+
+
+def test_run_trials_replay(nsd, dev, golden, ref_state, tmp_path):
+    g = golden("real_trials")
+    d = tmp_path / "trials"
+    d.mkdir()
+    for i in range(4):
+        np.savetxt(d / f"food_{i:02d}.csv", g["x"][i], fmt="%.7f", delimiter=",")
+    res = nsd.run_trials(trials=4, serial_port=f"replay:{d}", model_path=_write_pth(str(tmp_path), ref_state),
+                         verbose=False, queue_timeout=20.0)
+    assert res.trials == 4 and res.avg_probs.shape == (3,) and res.avg_chunk.shape == (625, 8)
+    assert np.abs(res.avg_probs - g["probs"][:4].mean(0)).max() < 1e-5
+    assert np.abs(res.avg_chunk - g["x"][:4].mean(0)).max() < 1e-5
+    with pytest.raises(RuntimeError, match="Producer exited unexpectedly"):
+        nsd.run_trials(trials=1, serial_port="/dev/does-not-exist", model_path="unused", verbose=False, queue_timeout=0.5)
