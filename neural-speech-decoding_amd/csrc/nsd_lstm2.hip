@@ -500,9 +500,12 @@ static int launch_bwd_h(const Lstm2BwdArgs &a, int nb, int grid, hipStream_t st)
     return 0;
 }
 
+// the backward kernels keep at most 2 trials per workgroup (register budget); larger batches loop
+static int pick_nb_bwd(int B) { const int nb = pick_nb(B); return nb > 2 ? 2 : nb; }
+
 // number of workgroups (== slabs written) the backward kernel uses for batch B
 int nsd_lstm2_bwd_grid(int B) {
-    const int nb = pick_nb(B);
+    const int nb = pick_nb_bwd(B);
     const int ngrp = (B + nb - 1) / nb;
     const int cus = nsd_num_cus();
     return ngrp < cus ? ngrp : cus;
@@ -525,12 +528,12 @@ int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st) {
 }
 
 int nsd_lstm2_bwd_launch(const Lstm2BwdArgs &a, int H, hipStream_t st) {
-    const int nb = pick_nb(a.B);
+    const int nb = pick_nb_bwd(a.B);
     const int grid = nsd_lstm2_bwd_grid(a.B);
     if (grid <= 0) return NSD_OK;
     switch (H) {
     case 32: launch_bwd_h<32>(a, nb, grid, st); break;
-    case 48: launch_bwd_h<48>(a, nb, grid, st); break;
+    case 48: return nsd_lstm2_bwd48_launch(a, nb, grid, st);   // role-split kernel (nsd_lstm2_bwd48.hip)
     case 64: launch_bwd_h<64>(a, nb, grid, st); break;
     default: nsd_set_error("lstm2 bwd: unsupported H=%d", H); return NSD_E_INVALID;
     }

@@ -1,0 +1,341 @@
+// nsd_lstm2_bwd48.hip -- BPTT of the two-layer H=48 LSTM, role-split workgroup (gfx950).
+//
+// Replaces autograd through self.lstm(x) (Neuro-Alpha-App/Utilities/lstm_eeg_model.py:34) for the reference
+// model shape (H=48, L=2, C<=8).  One 960-thread workgroup (15 waves) owns NB trials and walks time
+// backwards with ONE barrier per step; the waves have different jobs so that only the true recurrence
+// is on the critical path and every register array stays small:
+//
+//   waves 0-2   "chain 1"  layer-1 cell backward: dh_rec = W_hh1^T da1[t+1] (48 FMA/lane, weights in VGPRs,
+//                          operands broadcast from LDS, DPP quad reduction) then the element-wise cell
+//                          backward for step t -> da1[t] into an LDS ring.
+//   waves 3-5   "chain 0"  the same for layer 0, two steps behind layer 1.
+//   waves 6-8   "x1"       d_in1[t] = W_ih1^T da1[t] (the gradient handed to layer 0) and dW_ih0 (K=8, VALU).
+//   waves 9-14  "dW"       weight gradients dW_hh1, dW_ih1, dW_hh0 = sum_t da[t] (x) operand[t] as
+//                          v_mfma_f32_16x16x4_f32 with K = 4 time steps per instruction: A = da tiles from
+//                          the LDS ring, B = h / input rows straight from the activations saved in HBM
+//                          (prefetched one 4-step group ahead).  The matrix pipe is otherwise idle, so
+//                          these 27 648 MAC/step cost the chain nothing.
+//
+// LDS: da ring [2 layers][8 steps][NB][192] + d_in1 double buffer.  HBM traffic = saved activations read
+// once (gates, c, h, in1, x) + one slab of partial gradients per workgroup at the end.
+#include "nsd_args.h"
+
+namespace {
+
+constexpr int H = 48;
+constexpr int G4 = 192;
+constexpr int KS = 12;
+constexpr int RING = 8;
+constexpr int NTHREADS = 960;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+struct Smem {
+    float ring[2][RING][NB][G4];   // [layer][macro step % RING][trial][gate*48+unit]
+    float din1[2][NB][H];
+};
+
+__device__ __forceinline__ void step_barrier() { __syncthreads(); }
+
+// ------------------------------------------------------------------------------------------------
+// chain waves: layer = 1 (t = T-1-m) or 0 (t = T+1-m)
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int layer, const int r,
+                                           const int n_steps) {
+    const int j = r >> 2, s = r & 3;
+    const int T = a.T, B = a.B;
+    const float *gact = layer == 0 ? a.gact0 : a.gact1;
+    const float *cseq = layer == 0 ? a.cseq0 : a.cseq1;
+    const float *whh = layer == 0 ? a.w_hh0 : a.w_hh1;
+    float whT[H];
+#pragma unroll
+    for (int q = 0; q < H; ++q) whT[q] = whh[(size_t)(s * H + q) * H + j];
+    const float awj = a.attn_w[j];
+    float db = 0.f;
+
+    const int ngrp = (B + NB - 1) / NB;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b0 = grp * NB;
+        float dc[NB], dhrec[NB], ct[NB], dpj[NB], cprev[NB], aux0[NB], aux1[NB];
+        float4 gcur[NB];
+
+        auto load_step = [&](int t, int n, float4 &g4, float &cp, float &x0, float &x1) {
+            const int b = b0 + n;
+            g4 = make_float4(0.f, 0.f, 0.f, 0.f); cp = 0.f; x0 = 0.f; x1 = 0.f;
+            if (b < B && t >= 0 && t < T) {
+                const size_t idx = ((size_t)b * T + t) * H + j;
+                g4 = *reinterpret_cast<const float4 *>(gact + idx * 4);
+                if (t > 0) cp = cseq[idx - H];
+                if (layer == 1) { x0 = a.alpha[(size_t)b * T + t]; x1 = a.dscore[(size_t)b * T + t]; }
+                else            { x0 = a.mask ? a.mask[idx] : 1.f; }
+            }
+        };
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int b = b0 + n;
+            dc[n] = 0.f; dhrec[n] = 0.f;
+            dpj[n] = (layer == 1 && b < B) ? a.dpooled[(size_t)b * H + j] : 0.f;
+            ct[n] = (b < B) ? cseq[((size_t)b * T + (T - 1)) * H + j] : 0.f;
+            load_step(T - 1, n, gcur[n], cprev[n], aux0[n], aux1[n]);
+        }
+
+        for (int m = 0; m < n_steps; ++m) {
+            const int t = layer == 1 ? (T - 1 - m) : (T + 1 - m);
+            const bool active = (t >= 0 && t < T);
+            const bool prev_active = (t + 1 >= 0 && t + 1 < T);
+            // prefetch the saved activations of the next step (t-1)
+            float4 gnx[NB]; float cpn[NB], a0n[NB], a1n[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) load_step(t - 1, n, gnx[n], cpn[n], a0n[n], a1n[n]);
+
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                if (prev_active) {
+                    const float *dv = &sm.ring[layer][(m - 1) & (RING - 1)][n][s * H];
+                    float rec0 = 0.f, rec1 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < H / 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(dv + 4 * q);
+                        rec0 = fmaf(whT[4 * q], v.x, rec0); rec1 = fmaf(whT[4 * q + 1], v.y, rec1);
+                        rec0 = fmaf(whT[4 * q + 2], v.z, rec0); rec1 = fmaf(whT[4 * q + 3], v.w, rec1);
+                    }
+                    dhrec[n] = quad_sum(rec0 + rec1);
+                }
+                if (active) {
+                    const float ig = gcur[n].x, fg = gcur[n].y, gg = gcur[n].z, og = gcur[n].w;
+                    float dout;
+                    if (layer == 1) dout = fmaf(aux0[n], dpj[n], aux1[n] * awj);
+                    else            dout = sm.din1[(m - 1) & 1][n][j] * aux0[n];
+                    const float dht = dout + dhrec[n];
+                    const float tc = fast_tanh(ct[n]);
+                    const float dct = fmaf(dht * og, 1.f - tc * tc, dc[n]);
+                    const float da_i = dct * gg * ig * (1.f - ig);
+                    const float da_f = dct * cprev[n] * fg * (1.f - fg);
+                    const float da_g = dct * ig * (1.f - gg * gg);
+                    const float da_o = dht * tc * og * (1.f - og);
+                    dc[n] = dct * fg;
+                    const float mine = s == 0 ? da_i : s == 1 ? da_f : s == 2 ? da_g : da_o;
+                    sm.ring[layer][m & (RING - 1)][n][s * H + j] = mine;
+                    db += mine;
+                }
+                if (t <= T - 1) {        // this layer has started: rotate to step t-1
+                    ct[n] = cprev[n];
+                    gcur[n] = gnx[n]; cprev[n] = cpn[n]; aux0[n] = a0n[n]; aux1[n] = a1n[n];
+                }
+            }
+            step_barrier();
+        }
+    }
+    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    if (layer == 0) { slab[a.o_b_ih0 + s * H + j] = db; slab[a.o_b_hh0 + s * H + j] = db; }
+    else            { slab[a.o_b_ih1 + s * H + j] = db; slab[a.o_b_hh1 + s * H + j] = db; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// x1 waves: d_in1[t] = W_ih1^T da1[t] (+ residual pass-through) for layer 0, and dW_ih0 (K = C <= 8)
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int r, const int n_steps) {
+    const int j = r >> 2, s = r & 3;
+    const int T = a.T, B = a.B, C = a.C;
+    float wiT[H];
+#pragma unroll
+    for (int q = 0; q < H; ++q) wiT[q] = a.w_ih1[(size_t)(s * H + q) * H + j];
+    float dWih0[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { dWih0[g][0] = 0.f; dWih0[g][1] = 0.f; }
+    const float awj = a.attn_w[j];
+    const int c0 = 2 * s, c1 = 2 * s + 1;
+
+    const int ngrp = (B + NB - 1) / NB;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b0 = grp * NB;
+        float xc0[NB], xc1[NB], dpj[NB];
+        auto load_x = [&](int t, int n, float &v0, float &v1) {
+            const int b = b0 + n;
+            v0 = 0.f; v1 = 0.f;
+            if (b < B && t >= 0 && t < T) {
+                const float *xp = a.x + ((size_t)b * T + t) * C;
+                if (c0 < C) v0 = xp[c0];
+                if (c1 < C) v1 = xp[c1];
+            }
+        };
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            xc0[n] = 0.f; xc1[n] = 0.f;      // x for t0p(m=0) = T+2: out of range
+            dpj[n] = (a.residual && b0 + n < B) ? a.dpooled[(size_t)(b0 + n) * H + j] : 0.f;
+        }
+        for (int m = 0; m < n_steps; ++m) {
+            const int t1p = T - m;          // layer-1 step whose da1 was written at macro step m-1
+            const int t0p = T + 2 - m;      // layer-0 step whose da0 was written at macro step m-1
+            float xn0[NB], xn1[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) load_x(t0p - 1, n, xn0[n], xn1[n]);
+            const int e = (m - 1) & (RING - 1);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                if (t1p >= 0 && t1p < T) {
+                    const float *dv = &sm.ring[1][e][n][s * H];
+                    float i0 = 0.f, i1 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < H / 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(dv + 4 * q);
+                        i0 = fmaf(wiT[4 * q], v.x, i0); i1 = fmaf(wiT[4 * q + 1], v.y, i1);
+                        i0 = fmaf(wiT[4 * q + 2], v.z, i0); i1 = fmaf(wiT[4 * q + 3], v.w, i1);
+                    }
+                    float inp = quad_sum(i0 + i1);
+                    if (a.residual && b0 + n < B) {
+                        const size_t bt = (size_t)(b0 + n) * T + t1p;
+                        inp += fmaf(a.alpha[bt], dpj[n], a.dscore[bt] * awj);
+                    }
+                    if (s == 0) sm.din1[m & 1][n][j] = inp;
+                }
+                if (t0p >= 0 && t0p < T) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float d = sm.ring[0][e][n][g * H + j];
+                        dWih0[g][0] = fmaf(d, xc0[n], dWih0[g][0]);
+                        dWih0[g][1] = fmaf(d, xc1[n], dWih0[g][1]);
+                    }
+                }
+                xc0[n] = xn0[n]; xc1[n] = xn1[n];
+            }
+            step_barrier();
+        }
+    }
+    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (c0 < C) slab[a.o_w_ih0 + (size_t)(g * H + j) * C + c0] = dWih0[g][0];
+        if (c1 < C) slab[a.o_w_ih0 + (size_t)(g * H + j) * C + c1] = dWih0[g][1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW waves: three [192,48] outer-product sums on the matrix pipe, K = 4 time steps per MFMA
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+struct DwState {
+    f32x4 acc[3][2][3];      // [matrix: W_hh1, W_ih1, W_hh0][row tile][column tile]
+    float bq[3][NB][3];      // prefetched B operands of the 4-step group being formed
+};
+
+// B operand of matrix Q for the 4 macro steps of group G: lane (col i = lane&15, k = lane>>4)
+template <int Q, int NB>
+__device__ __forceinline__ void dw_prefetch(const Lstm2BwdArgs &a, DwState<NB> &st, const int G, const int b0,
+                                            const int lane) {
+    const int T = a.T, B = a.B;
+    const int i = lane & 15, k = lane >> 4;
+    const int mm = 4 * G + k;
+    // row of the saved sequence that pairs with da[t]:  W_hh1: h1[t-1], W_ih1: in1[t], W_hh0: h0[t-1]
+    const int t = (Q == 2) ? (T + 1 - mm) : (T - 1 - mm);
+    const int tt = (Q == 1) ? t : t - 1;
+    const bool ok = (t >= 0 && t < T && tt >= 0);
+    const float *src = Q == 0 ? a.hseq1 : Q == 1 ? a.in1seq : a.hseq0;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int b = b0 + n;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+            st.bq[Q][n][nt] = (ok && b < B) ? src[((size_t)b * T + tt) * H + 16 * nt + i] : 0.f;
+    }
+}
+
+template <int Q, int NB>
+__device__ __forceinline__ void dw_compute(const Lstm2BwdArgs &a, Smem<NB> &sm, DwState<NB> &st, const int G,
+                                           const int dwid, const int lane) {
+    // group G (macro steps 4G..4G+3) is complete in the ring; its B operands sit in st.bq[Q]
+    const int T = a.T;
+    const int i = lane & 15, k = lane >> 4;
+    const int mm = 4 * G + k;
+    constexpr int layer = (Q == 2) ? 0 : 1;
+    const int t = layer == 1 ? (T - 1 - mm) : (T + 1 - mm);
+    const bool ok = (t >= 0 && t < T);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        float av[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float v = sm.ring[layer][mm & (RING - 1)][n][32 * dwid + 16 * mt + i];
+            av[mt] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+                st.acc[Q][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], st.bq[Q][n][nt], st.acc[Q][mt][nt], 0, 0, 0);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int dwid, const int lane,
+                                        const int n_groups) {
+    DwState<NB> st;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) st.acc[q][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ngrp = (a.B + NB - 1) / NB;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b0 = grp * NB;
+        for (int G = 0; G < n_groups; ++G) {
+            // macro step 4G+0 : finish matrix 0 of group G-1, start fetching matrix 0 of group G; etc.
+            if (G > 0) dw_compute<0, NB>(a, sm, st, G - 1, dwid, lane);
+            dw_prefetch<0, NB>(a, st, G, b0, lane);
+            step_barrier();
+            if (G > 0) dw_compute<1, NB>(a, sm, st, G - 1, dwid, lane);
+            dw_prefetch<1, NB>(a, st, G, b0, lane);
+            step_barrier();
+            if (G > 0) dw_compute<2, NB>(a, sm, st, G - 1, dwid, lane);
+            dw_prefetch<2, NB>(a, st, G, b0, lane);
+            step_barrier();
+            step_barrier();
+        }
+    }
+    // accumulator tile -> slab: lane holds rows 4*(lane>>4)+r, column lane&15 of each 16x16 tile
+    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    const long base[3] = {a.o_w_hh1, a.o_w_ih1, a.o_w_hh0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = 32 * dwid + 16 * mt + 4 * (lane >> 4) + rr;
+                    const int col = 16 * nt + (lane & 15);
+                    slab[base[q] + (size_t)row * H + col] = st.acc[q][mt][nt][rr];
+                }
+}
+
+template <int NB>
+__global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
+    __shared__ __align__(16) Smem<NB> sm;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // every role runs the same number of barriers: 4 per 4-step group, groups cover macro steps 0..T+2
+    // plus one more group so that the dW waves can drain the last one
+    const int n_groups = (a.T + 2) / 4 + 2;
+    const int n_steps = 4 * n_groups;
+    if (wave < 3)       chain_role<NB>(a, sm, 1, tid, n_steps);
+    else if (wave < 6)  chain_role<NB>(a, sm, 0, tid - 192, n_steps);
+    else if (wave < 9)  x1_role<NB>(a, sm, tid - 384, n_steps);
+    else                dw_role<NB>(a, sm, wave - 9, tid & 63, n_groups);
+}
+
+}  // namespace
+
+int nsd_lstm2_bwd48_launch(const Lstm2BwdArgs &a, int nb, int grid, hipStream_t st) {
+    switch (nb) {
+    case 1: hipLaunchKernelGGL((lstm2_bwd48_kernel<1>), dim3(grid), dim3(NTHREADS), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((lstm2_bwd48_kernel<2>), dim3(grid), dim3(NTHREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL((lstm2_bwd48_kernel<4>), dim3(grid), dim3(NTHREADS), 0, st, a); break;
+    }
+    NSD_CHECK_LAUNCH("lstm2_bwd48");
+    return NSD_OK;
+}
