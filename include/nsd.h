@@ -65,6 +65,7 @@ typedef struct nsd_ws_layout {
     int64_t dscore;    /* [B,T]       d loss / d attention score  (head_bwd -> lstm_bwd) */
     int64_t dpooled;   /* [B,H]       d loss / d pooled           (head_bwd -> lstm_bwd) */
     int64_t loss;      /* [B]         per-trial CE loss                                */
+    int64_t adpack;    /* [B,T,4]     {alpha, dscore, 0, 0} per step: 16-byte records for the LSTM backward's LDS-DMA */
     int64_t slabs;     /* [n_slabs,P_lstm] per-workgroup partial gradients of the LSTM stack */
     int64_t n_slabs;
     int64_t hslabs;    /* [B,P_head]  per-trial gradients of ln/attn/fc                  */

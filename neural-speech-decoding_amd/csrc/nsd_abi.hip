@@ -78,6 +78,7 @@ static nsd_ws_layout make_ws(const nsd_dims *d, bool have_device) {
     w.dscore = p;  p = align4(p + B * T);
     w.dpooled = p; p = align4(p + B * H);
     w.loss = p;    p = align4(p + B);
+    w.adpack = p;  p = align4(p + B * T * 4);
     // LSTM slabs: one per backward workgroup (<= #CUs); head slabs: one per trial, stored behind them.
     // Without a device (symbol / layout checks on CPU) assume the MI355X's 256 CUs.
     int64_t nsl = B < 256 ? B : 256;
@@ -258,6 +259,7 @@ int nsd_head_bwd(const nsd_dims *d, const float *params, const float *rrelu_slop
     h.logits_in = logits; h.dlogits = dlogits; h.labels = labels; h.scale = scale;
     h.loss = workspace + w.loss; h.dscore = workspace + w.dscore; h.dpooled = workspace + w.dpooled;
     h.hslabs = workspace + w.hslabs;
+    h.adpack = workspace + w.adpack;
     return nsd_head_launch(h, true, (hipStream_t)stream);
 }
 
@@ -282,6 +284,7 @@ int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const f
     a.gact0 = workspace + w.gact; a.gact1 = workspace + w.gact + 4 * BTH;
     a.in1seq = workspace + w.inseq;
     a.alpha = workspace + w.alpha; a.dscore = workspace + w.dscore; a.dpooled = workspace + w.dpooled;
+    a.dsc_pack = workspace + w.adpack;
     a.slabs = workspace + w.slabs;
     a.slab_stride = align4(pl.lstm_total);
     a.o_w_ih0 = pl.w_ih[0]; a.o_w_hh0 = pl.w_hh[0]; a.o_b_ih0 = pl.b_ih[0]; a.o_b_hh0 = pl.b_hh[0];

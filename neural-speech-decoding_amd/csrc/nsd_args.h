@@ -16,6 +16,7 @@ struct Lstm2BwdArgs {
     const float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1;
     const float *in1seq;
     const float *alpha, *dscore, *dpooled;
+    const float *dsc_pack;                   // [B,T,4] {alpha, dscore, 0, 0}: 16-byte records for LDS-DMA
     float *slabs;
     long slab_stride;
     long o_w_ih0, o_w_hh0, o_b_ih0, o_b_hh0, o_w_ih1, o_w_hh1, o_b_ih1, o_b_hh1;
@@ -32,6 +33,7 @@ struct HeadArgs {
     const int32_t *labels;
     float scale;
     float *loss, *dscore, *dpooled;
+    float *adpack;                           // [B,T,4] {alpha, dscore, 0, 0} (backward only, may be null)
     float *hslabs;
     long o_ln_w, o_ln_b, o_attn_w, o_attn_b, o_fc0_w, o_fc0_b, o_fc3_w, o_fc3_b;
     long Ph;

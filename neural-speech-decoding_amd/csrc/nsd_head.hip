@@ -254,6 +254,8 @@ __global__ __launch_bounds__(HEAD_NT) void head_bwd_kernel(HeadArgs a) {
             const float ds = a.alpha[(size_t)b * T + t] * (sc[t] - sdot);
             sc[t] = ds;
             a.dscore[(size_t)b * T + t] = ds;
+            if (a.adpack)
+                *reinterpret_cast<float4 *>(a.adpack + ((size_t)b * T + t) * 4) = make_float4(a.alpha[(size_t)b * T + t], ds, 0.f, 0.f);
             lb += ds;
         }
         const float dab = block_sum(lb, red);

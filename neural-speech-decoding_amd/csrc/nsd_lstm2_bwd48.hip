@@ -24,15 +24,24 @@ namespace {
 
 constexpr int H = 48;
 constexpr int G4 = 192;
-constexpr int KS = 12;
 constexpr int RING = 8;
-constexpr int NTHREADS = 960;
+constexpr int NTHREADS = 1024;
+constexpr int CHUNK = 8;            // macro steps per staged chunk of saved activations
+constexpr int REC = 288;            // floats per (layer, step) record: gates[192] | c[t-1][48] | aux[48]
+constexpr int REC4 = REC / 4;
+constexpr int STAGE_F4 = 2 * CHUNK * REC4;     // float4 per trial per chunk (both layers) = 1152 = 18 x 64 lanes
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The saved activations a chain wave needs at a step (its unit's 4 activated gates, c[t-1], and the
+// per-step scalars) are NOT fetched from HBM by the chain itself: a dependent global load per step would
+// put the memory latency (>= 1 us under load) on the recurrence.  A dedicated loader wave streams them one
+// 8-step chunk ahead with LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous) into a double-buffered
+// LDS stage; the chain only does LDS reads.
 template <int NB>
 struct Smem {
-    float ring[2][RING][NB][G4];   // [layer][macro step % RING][trial][gate*48+unit]
+    float ring[2][RING][NB][G4];           // [layer][macro step % RING][trial][gate*48+unit]
     float din1[2][NB][H];
+    float stage[2][NB][2][CHUNK][REC];     // [buffer][trial][layer][step in chunk][record]  (linear per trial)
 };
 
 __device__ __forceinline__ void step_barrier() { __syncthreads(); }
@@ -45,7 +54,6 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
                                            const int n_steps) {
     const int j = r >> 2, s = r & 3;
     const int T = a.T, B = a.B;
-    const float *gact = layer == 0 ? a.gact0 : a.gact1;
     const float *cseq = layer == 0 ? a.cseq0 : a.cseq1;
     const float *whh = layer == 0 ? a.w_hh0 : a.w_hh1;
     float whT[H];
@@ -57,37 +65,30 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
-        float dc[NB], dhrec[NB], ct[NB], dpj[NB], cprev[NB], aux0[NB], aux1[NB];
-        float4 gcur[NB];
-
-        auto load_step = [&](int t, int n, float4 &g4, float &cp, float &x0, float &x1) {
-            const int b = b0 + n;
-            g4 = make_float4(0.f, 0.f, 0.f, 0.f); cp = 0.f; x0 = 0.f; x1 = 0.f;
-            if (b < B && t >= 0 && t < T) {
-                const size_t idx = ((size_t)b * T + t) * H + j;
-                g4 = *reinterpret_cast<const float4 *>(gact + idx * 4);
-                if (t > 0) cp = cseq[idx - H];
-                if (layer == 1) { x0 = a.alpha[(size_t)b * T + t]; x1 = a.dscore[(size_t)b * T + t]; }
-                else            { x0 = a.mask ? a.mask[idx] : 1.f; }
-            }
-        };
+        float dc[NB], dhrec[NB], ct[NB], dpj[NB];
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const int b = b0 + n;
             dc[n] = 0.f; dhrec[n] = 0.f;
             dpj[n] = (layer == 1 && b < B) ? a.dpooled[(size_t)b * H + j] : 0.f;
-            ct[n] = (b < B) ? cseq[((size_t)b * T + (T - 1)) * H + j] : 0.f;
-            load_step(T - 1, n, gcur[n], cprev[n], aux0[n], aux1[n]);
+            ct[n] = (b < B) ? cseq[((size_t)b * T + (T - 1)) * H + j] : 0.f;   // c[T-1] of the first step
         }
+        step_barrier();      // chunk 0 of the stage has been written by the x1 waves
 
         for (int m = 0; m < n_steps; ++m) {
             const int t = layer == 1 ? (T - 1 - m) : (T + 1 - m);
             const bool active = (t >= 0 && t < T);
             const bool prev_active = (t + 1 >= 0 && t + 1 < T);
-            // prefetch the saved activations of the next step (t-1)
-            float4 gnx[NB]; float cpn[NB], a0n[NB], a1n[NB];
+            // this step's record from the LDS stage (issued first, consumed after the mat-vec)
+            float4 gcur[NB]; float cprev[NB], aux0[NB], aux1[NB];
 #pragma unroll
-            for (int n = 0; n < NB; ++n) load_step(t - 1, n, gnx[n], cpn[n], a0n[n], a1n[n]);
+            for (int n = 0; n < NB; ++n) {
+                const float *rec = &sm.stage[(m / CHUNK) & 1][n][layer][m & (CHUNK - 1)][0];
+                gcur[n] = *reinterpret_cast<const float4 *>(rec + 4 * j);
+                cprev[n] = t > 0 ? rec[192 + j] : 0.f;
+                aux0[n] = layer == 1 ? rec[240] : (a.mask ? rec[240 + j] : 1.f);
+                aux1[n] = rec[241];
+            }
 
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
@@ -102,7 +103,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
                     }
                     dhrec[n] = quad_sum(rec0 + rec1);
                 }
-                if (active) {
+                if (active && b0 + n < B) {
                     const float ig = gcur[n].x, fg = gcur[n].y, gg = gcur[n].z, og = gcur[n].w;
                     float dout;
                     if (layer == 1) dout = fmaf(aux0[n], dpj[n], aux1[n] * awj);
@@ -118,10 +119,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
                     const float mine = s == 0 ? da_i : s == 1 ? da_f : s == 2 ? da_g : da_o;
                     sm.ring[layer][m & (RING - 1)][n][s * H + j] = mine;
                     db += mine;
-                }
-                if (t <= T - 1) {        // this layer has started: rotate to step t-1
-                    ct[n] = cprev[n];
-                    gcur[n] = gnx[n]; cprev[n] = cpn[n]; aux0[n] = a0n[n]; aux1[n] = a1n[n];
+                    ct[n] = cprev[n];    // c[t-1] is the cell state of the next step handled
                 }
             }
             step_barrier();
@@ -166,6 +164,8 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
             xc0[n] = 0.f; xc1[n] = 0.f;      // x for t0p(m=0) = T+2: out of range
             dpj[n] = (a.residual && b0 + n < B) ? a.dpooled[(size_t)(b0 + n) * H + j] : 0.f;
         }
+        step_barrier();
+
         for (int m = 0; m < n_steps; ++m) {
             const int t1p = T - m;          // layer-1 step whose da1 was written at macro step m-1
             const int t0p = T + 2 - m;      // layer-0 step whose da0 was written at macro step m-1
@@ -282,6 +282,7 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
+        step_barrier();      // pairs with the stage-initialisation barrier of the other roles
         for (int G = 0; G < n_groups; ++G) {
             // macro step 4G+0 : finish matrix 0 of group G-1, start fetching matrix 0 of group G; etc.
             if (G > 0) dw_compute<0, NB>(a, sm, st, G - 1, dwid, lane);
@@ -313,6 +314,58 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
                 }
 }
 
+// ------------------------------------------------------------------------------------------------
+// loader wave: LDS-DMA stream of the saved activations, one chunk ahead of the chain
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void loader_issue(const Lstm2BwdArgs &a, Smem<NB> &sm, const int chunk, const int buf,
+                                             const int b0, const int lane) {
+    const int T = a.T;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int b = b0 + n;
+#pragma unroll
+        for (int q = 0; q < STAGE_F4 / 64; ++q) {
+            const int e = q * 64 + lane;                 // float4 index inside the trial's chunk image
+            const int layer = e / (CHUNK * REC4);
+            const int rem = e - layer * (CHUNK * REC4);
+            const int k = rem / REC4, w = rem - k * REC4;
+            const int mm = chunk * CHUNK + k;
+            const int t = layer == 1 ? (T - 1 - mm) : (T + 1 - mm);
+            const float *src = nullptr;
+            if (b < a.B && t >= 0 && t < T) {
+                const size_t row = (size_t)b * T + t;
+                if (w < 48)            src = (layer == 0 ? a.gact0 : a.gact1) + (row * H + w) * 4;
+                else if (w < 60)     { if (t > 0) src = (layer == 0 ? a.cseq0 : a.cseq1) + (row - 1) * H + (w - 48) * 4; }
+                else if (layer == 0) { if (a.mask) src = a.mask + row * H + (w - 60) * 4; }
+                else if (w == 60)      src = a.dsc_pack + row * 4;   // {alpha, dscore, -, -}
+            }
+            // LDS destination = wave-uniform base + lane*16: the image is linear in e
+            if (src)
+                __builtin_amdgcn_global_load_lds((const void *)src,
+                                                 (__attribute__((address_space(3))) void *)(&sm.stage[buf][n][0][0][0] + q * 256),
+                                                 16, 0, 0);
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int lane, const int n_steps) {
+    const int ngrp = (a.B + NB - 1) / NB;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b0 = grp * NB;
+        loader_issue<NB>(a, sm, 0, 0, b0, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int m = 0; m < n_steps; ++m) {
+            const int chunk = m / CHUNK, kk = m & (CHUNK - 1);
+            if (kk == 0) loader_issue<NB>(a, sm, chunk + 1, (chunk + 1) & 1, b0, lane);
+            if (kk == CHUNK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     __shared__ __align__(16) Smem<NB> sm;
@@ -325,7 +378,8 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     if (wave < 3)       chain_role<NB>(a, sm, 1, tid, n_steps);
     else if (wave < 6)  chain_role<NB>(a, sm, 0, tid - 192, n_steps);
     else if (wave < 9)  x1_role<NB>(a, sm, tid - 384, n_steps);
-    else                dw_role<NB>(a, sm, wave - 9, tid & 63, n_groups);
+    else if (wave < 15) dw_role<NB>(a, sm, wave - 9, tid & 63, n_groups);
+    else                loader_role<NB>(a, sm, tid & 63, n_steps);
 }
 
 }  // namespace
@@ -334,7 +388,7 @@ int nsd_lstm2_bwd48_launch(const Lstm2BwdArgs &a, int nb, int grid, hipStream_t 
     switch (nb) {
     case 1: hipLaunchKernelGGL((lstm2_bwd48_kernel<1>), dim3(grid), dim3(NTHREADS), 0, st, a); break;
     case 2: hipLaunchKernelGGL((lstm2_bwd48_kernel<2>), dim3(grid), dim3(NTHREADS), 0, st, a); break;
-    default: hipLaunchKernelGGL((lstm2_bwd48_kernel<4>), dim3(grid), dim3(NTHREADS), 0, st, a); break;
+    default: nsd_set_error("lstm2_bwd48: NB=%d not built (register / LDS budget)", nb); return NSD_E_INVALID;
     }
     NSD_CHECK_LAUNCH("lstm2_bwd48");
     return NSD_OK;

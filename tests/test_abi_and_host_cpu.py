@@ -49,7 +49,7 @@ def test_reference_sizes():
 def test_workspace_layout_is_disjoint_and_aligned():
     spec = ops.ModelSpec()
     nbytes, w = ops.workspace_layout(spec, 256, 250)
-    regs = ["hseq", "cseq", "gact", "inseq", "top", "alpha", "pooled", "fc0_pre", "dscore", "dpooled", "loss", "slabs", "hslabs"]
+    regs = ["hseq", "cseq", "gact", "inseq", "top", "alpha", "pooled", "fc0_pre", "dscore", "dpooled", "loss", "adpack", "slabs", "hslabs"]
     offs = [getattr(w, r) for r in regs]
     assert offs == sorted(offs) and all(o % 4 == 0 for o in offs) and nbytes == 4 * w.total
     B, T, H = 256, 250, 48
