@@ -2,6 +2,7 @@
 // Argument validation, parameter / workspace layout, kernel dispatch.  No allocation, no synchronisation.
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include "nsd_args.h"
 
 // ---- error text -------------------------------------------------------------------------------------------
@@ -153,6 +154,7 @@ static int build_lstm_fwd(const nsd_dims *d, const float *params, const float *x
     a.mask = drop_lstm;
     a.B = d->B; a.T = d->T; a.C = d->C;
     a.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
+    { const char *ab_ = getenv("NSD_ABLATE"); a.ablate = ab_ ? atoi(ab_) : 0; }
     const int64_t BTH = (int64_t)d->B * d->T * d->H;
     if (train) {
         a.hseq0 = ws + w.hseq; a.hseq1 = ws + w.hseq + BTH;
@@ -291,6 +293,7 @@ int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const f
     a.o_w_ih1 = pl.w_ih[1]; a.o_w_hh1 = pl.w_hh[1]; a.o_b_ih1 = pl.b_ih[1]; a.o_b_hh1 = pl.b_hh[1];
     a.B = d->B; a.T = d->T; a.C = d->C;
     a.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
+    { const char *ab_ = getenv("NSD_ABLATE"); a.ablate = ab_ ? atoi(ab_) : 0; }
     return nsd_lstm2_bwd_launch(a, d->H, (hipStream_t)stream);
 }
 

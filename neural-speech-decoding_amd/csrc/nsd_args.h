@@ -8,6 +8,7 @@ struct Lstm2FwdArgs {
     const float *mask;
     float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
     int B, T, C, residual;
+    int ablate;                              // timing experiments only (env NSD_ABLATE); 0 in production
 };
 struct Lstm2BwdArgs {
     const float *x;
@@ -21,6 +22,7 @@ struct Lstm2BwdArgs {
     long slab_stride;
     long o_w_ih0, o_w_hh0, o_b_ih0, o_b_hh0, o_w_ih1, o_w_hh1, o_b_ih1, o_b_hh1;
     int B, T, C, residual;
+    int ablate;                              // timing experiments only (env NSD_ABLATE); 0 in production
 };
 struct HeadArgs {
     const float *top;

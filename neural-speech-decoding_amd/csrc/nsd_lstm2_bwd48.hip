@@ -42,6 +42,7 @@ struct Smem {
     float ring[2][RING][NB][G4];           // [layer][macro step % RING][trial][gate*48+unit]
     float din1[2][NB][H];
     float stage[2][NB][2][CHUNK][REC];     // [buffer][trial][layer][step in chunk][record]  (linear per trial)
+    float xst[2][NB][CHUNK][8];            // x[T+2-m] rows for the x1 waves (dW_ih0), same chunking
 };
 
 __device__ __forceinline__ void step_barrier() { __syncthreads(); }
@@ -92,7 +93,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
 
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
-                if (prev_active) {
+                if (prev_active && !(a.ablate & 4)) {
                     const float *dv = &sm.ring[layer][(m - 1) & (RING - 1)][n][s * H];
                     float rec0 = 0.f, rec1 = 0.f;
 #pragma unroll
@@ -103,13 +104,14 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
                     }
                     dhrec[n] = quad_sum(rec0 + rec1);
                 }
+                if (active && b0 + n >= B) sm.ring[layer][m & (RING - 1)][n][s * H + j] = 0.f;
                 if (active && b0 + n < B) {
                     const float ig = gcur[n].x, fg = gcur[n].y, gg = gcur[n].z, og = gcur[n].w;
                     float dout;
                     if (layer == 1) dout = fmaf(aux0[n], dpj[n], aux1[n] * awj);
                     else            dout = sm.din1[(m - 1) & 1][n][j] * aux0[n];
                     const float dht = dout + dhrec[n];
-                    const float tc = fast_tanh(ct[n]);
+                    const float tc = (a.ablate & 8) ? ct[n] : fast_tanh(ct[n]);
                     const float dct = fmaf(dht * og, 1.f - tc * tc, dc[n]);
                     const float da_i = dct * gg * ig * (1.f - ig);
                     const float da_f = dct * cprev[n] * fg * (1.f - fg);
@@ -149,33 +151,19 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
-        float xc0[NB], xc1[NB], dpj[NB];
-        auto load_x = [&](int t, int n, float &v0, float &v1) {
-            const int b = b0 + n;
-            v0 = 0.f; v1 = 0.f;
-            if (b < B && t >= 0 && t < T) {
-                const float *xp = a.x + ((size_t)b * T + t) * C;
-                if (c0 < C) v0 = xp[c0];
-                if (c1 < C) v1 = xp[c1];
-            }
-        };
+        float dpj[NB];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            xc0[n] = 0.f; xc1[n] = 0.f;      // x for t0p(m=0) = T+2: out of range
-            dpj[n] = (a.residual && b0 + n < B) ? a.dpooled[(size_t)(b0 + n) * H + j] : 0.f;
-        }
+        for (int n = 0; n < NB; ++n) dpj[n] = (a.residual && b0 + n < B) ? a.dpooled[(size_t)(b0 + n) * H + j] : 0.f;
         step_barrier();
 
         for (int m = 0; m < n_steps; ++m) {
             const int t1p = T - m;          // layer-1 step whose da1 was written at macro step m-1
             const int t0p = T + 2 - m;      // layer-0 step whose da0 was written at macro step m-1
-            float xn0[NB], xn1[NB];
-#pragma unroll
-            for (int n = 0; n < NB; ++n) load_x(t0p - 1, n, xn0[n], xn1[n]);
             const int e = (m - 1) & (RING - 1);
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
-                if (t1p >= 0 && t1p < T) {
+                const float2 xv = *reinterpret_cast<const float2 *>(&sm.xst[(m / CHUNK) & 1][n][m & (CHUNK - 1)][2 * s]);
+                if (t1p >= 0 && t1p < T && !(a.ablate & 2)) {
                     const float *dv = &sm.ring[1][e][n][s * H];
                     float i0 = 0.f, i1 = 0.f;
 #pragma unroll
@@ -186,20 +174,20 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
                     }
                     float inp = quad_sum(i0 + i1);
                     if (a.residual && b0 + n < B) {
-                        const size_t bt = (size_t)(b0 + n) * T + t1p;
-                        inp += fmaf(a.alpha[bt], dpj[n], a.dscore[bt] * awj);
+                        // dout1[t1p] = alpha*dpooled + dscore*attn_w: the scalars sit in the record of macro step m-1
+                        const float *recp = &sm.stage[((m - 1) / CHUNK) & 1][n][1][(m - 1) & (CHUNK - 1)][0];
+                        inp += fmaf(recp[240], dpj[n], recp[241] * awj);
                     }
                     if (s == 0) sm.din1[m & 1][n][j] = inp;
                 }
-                if (t0p >= 0 && t0p < T) {
+                if (t0p >= 0 && t0p < T && b0 + n < B) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float d = sm.ring[0][e][n][g * H + j];
-                        dWih0[g][0] = fmaf(d, xc0[n], dWih0[g][0]);
-                        dWih0[g][1] = fmaf(d, xc1[n], dWih0[g][1]);
+                        dWih0[g][0] = fmaf(d, xv.x, dWih0[g][0]);
+                        dWih0[g][1] = fmaf(d, xv.y, dWih0[g][1]);
                     }
                 }
-                xc0[n] = xn0[n]; xc1[n] = xn1[n];
             }
             step_barrier();
         }
@@ -285,13 +273,13 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
         step_barrier();      // pairs with the stage-initialisation barrier of the other roles
         for (int G = 0; G < n_groups; ++G) {
             // macro step 4G+0 : finish matrix 0 of group G-1, start fetching matrix 0 of group G; etc.
-            if (G > 0) dw_compute<0, NB>(a, sm, st, G - 1, dwid, lane);
+            if (G > 0 && !(a.ablate & 1)) dw_compute<0, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<0, NB>(a, st, G, b0, lane);
             step_barrier();
-            if (G > 0) dw_compute<1, NB>(a, sm, st, G - 1, dwid, lane);
+            if (G > 0 && !(a.ablate & 1)) dw_compute<1, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<1, NB>(a, st, G, b0, lane);
             step_barrier();
-            if (G > 0) dw_compute<2, NB>(a, sm, st, G - 1, dwid, lane);
+            if (G > 0 && !(a.ablate & 1)) dw_compute<2, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<2, NB>(a, st, G, b0, lane);
             step_barrier();
             step_barrier();
@@ -315,52 +303,114 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// loader wave: LDS-DMA stream of the saved activations, one chunk ahead of the chain
+// loader wave: LDS-DMA stream of the saved activations, one chunk ahead of the chain.
+// A chunk image is 18 wave-wide 1 KB pieces per trial (+ one 256 B piece of x rows).  What a lane copies
+// in piece q never changes except for the time index, so the address recipe is decoded ONCE per lane
+// (base pointer, bytes per time step, t of chunk 0, lowest valid t) and a piece costs a handful of VALU
+// instructions + the DMA issue: the loader must never be the wave the step barrier waits for.
 // ------------------------------------------------------------------------------------------------
+constexpr int NQ = STAGE_F4 / 64;        // 18
+
+struct LdDesc {
+    const char *base;     // address of (trial 0, t = 0) for this lane's 16 bytes
+    int row_bytes;        // bytes per time step of the source array (0 = lane never copies)
+    int t0;               // time index in chunk 0
+};
+
 template <int NB>
-__device__ __forceinline__ void loader_issue(const Lstm2BwdArgs &a, Smem<NB> &sm, const int chunk, const int buf,
-                                             const int b0, const int lane) {
+__device__ __forceinline__ void loader_decode(const Lstm2BwdArgs &a, const int lane, LdDesc (&d)[NQ]) {
+    const int T = a.T;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = q * 64 + lane;
+        const int layer = e / (CHUNK * REC4);
+        const int rem = e - layer * (CHUNK * REC4);
+        const int k = rem / REC4, w = rem - k * REC4;
+        d[q].t0 = layer == 1 ? (T - 1 - k) : (T + 1 - k);
+        d[q].row_bytes = 0;
+        d[q].base = nullptr;
+        if (w < 48) {
+            d[q].base = (const char *)((layer == 0 ? a.gact0 : a.gact1) + w * 4); d[q].row_bytes = H * 16;
+        } else if (w < 60) {     // c[t-1]; at t = 0 this reads the 192 bytes in front of the trial's c rows, which
+                                 // lie inside the workspace (hseq precedes cseq) and are ignored by the chain
+            d[q].base = (const char *)((layer == 0 ? a.cseq0 : a.cseq1) + (w - 48) * 4) - H * 4; d[q].row_bytes = H * 4;
+        } else if (layer == 0) {
+            if (a.mask) { d[q].base = (const char *)(a.mask + (w - 60) * 4); d[q].row_bytes = H * 4; }
+        } else if (w == 60) {
+            d[q].base = (const char *)a.dsc_pack; d[q].row_bytes = 16;
+        }
+    }
+}
+
+template <int NB, int Q0, int Q1>
+__device__ __forceinline__ void loader_issue(const Lstm2BwdArgs &a, Smem<NB> &sm, const LdDesc (&d)[NQ], const int chunk,
+                                             const int buf, const int b0) {
     const int T = a.T;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int b = b0 + n;
+        if (b < a.B) {
 #pragma unroll
-        for (int q = 0; q < STAGE_F4 / 64; ++q) {
-            const int e = q * 64 + lane;                 // float4 index inside the trial's chunk image
-            const int layer = e / (CHUNK * REC4);
-            const int rem = e - layer * (CHUNK * REC4);
-            const int k = rem / REC4, w = rem - k * REC4;
-            const int mm = chunk * CHUNK + k;
-            const int t = layer == 1 ? (T - 1 - mm) : (T + 1 - mm);
-            const float *src = nullptr;
-            if (b < a.B && t >= 0 && t < T) {
-                const size_t row = (size_t)b * T + t;
-                if (w < 48)            src = (layer == 0 ? a.gact0 : a.gact1) + (row * H + w) * 4;
-                else if (w < 60)     { if (t > 0) src = (layer == 0 ? a.cseq0 : a.cseq1) + (row - 1) * H + (w - 48) * 4; }
-                else if (layer == 0) { if (a.mask) src = a.mask + row * H + (w - 60) * 4; }
-                else if (w == 60)      src = a.dsc_pack + row * 4;   // {alpha, dscore, -, -}
+            for (int q = Q0; q < Q1; ++q) {
+                const int t = d[q].t0 - CHUNK * chunk;
+                if (d[q].row_bytes != 0 && (unsigned)t < (unsigned)T) {
+                    const char *src = d[q].base + (size_t)((unsigned)(b * T + t)) * (unsigned)d[q].row_bytes;
+                    // LDS destination = wave-uniform base + lane*16: the chunk image is linear in e = q*64 + lane
+                    __builtin_amdgcn_global_load_lds((const void *)src,
+                                                     (__attribute__((address_space(3))) void *)(&sm.stage[buf][n][0][0][0] + q * 256),
+                                                     16, 0, 0);
+                }
             }
-            // LDS destination = wave-uniform base + lane*16: the image is linear in e
-            if (src)
-                __builtin_amdgcn_global_load_lds((const void *)src,
-                                                 (__attribute__((address_space(3))) void *)(&sm.stage[buf][n][0][0][0] + q * 256),
-                                                 16, 0, 0);
         }
+    }
+}
+
+// x rows for the x1 waves (dW_ih0): lane (k = lane>>3, ch = lane&7) moves x[T+2-mm][ch] of macro step
+// mm = chunk*8+k with a 4-byte LDS-DMA (no ordinary load in this wave: hipcc drains every DMA in flight
+// before an ordinary VMEM load, which would stall the step barrier)
+template <int NB>
+__device__ __forceinline__ void loader_issue_x(const Lstm2BwdArgs &a, Smem<NB> &sm, const int chunk, const int buf,
+                                               const int b0, const int lane) {
+    const int T = a.T, k = lane >> 3, ch = lane & 7;
+    const int tx = T + 2 - (chunk * CHUNK + k);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int b = b0 + n;
+        if (b < a.B && tx >= 0 && tx < T && ch < a.C)
+            __builtin_amdgcn_global_load_lds((const void *)(a.x + ((size_t)b * T + tx) * a.C + ch),
+                                             (__attribute__((address_space(3))) void *)&sm.xst[buf][n][0][0], 4, 0, 0);
     }
 }
 
 template <int NB>
 __device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int lane, const int n_steps) {
+    LdDesc d[NQ];
+    loader_decode<NB>(a, lane, d);
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
-        loader_issue<NB>(a, sm, 0, 0, b0, lane);
+        loader_issue<NB, 0, NQ>(a, sm, d, 0, 0, b0);
+        loader_issue_x<NB>(a, sm, 0, 0, b0, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        for (int m = 0; m < n_steps; ++m) {
-            const int chunk = m / CHUNK, kk = m & (CHUNK - 1);
-            if (kk == 0) loader_issue<NB>(a, sm, chunk + 1, (chunk + 1) & 1, b0, lane);
-            if (kk == CHUNK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int m0 = 0; m0 < n_steps; m0 += CHUNK) {
+            const int chunk = m0 / CHUNK, nb = (chunk + 1) & 1;
+            const bool on = !(a.ablate & 16);
+            // next chunk: 3 pieces per step during steps 0..5 (+ x rows at step 0); all landed before step 7 ends
+            if (on) { loader_issue<NB, 0, 3>(a, sm, d, chunk + 1, nb, b0); loader_issue_x<NB>(a, sm, chunk + 1, nb, b0, lane); }
+            __builtin_amdgcn_s_barrier();
+            if (on) loader_issue<NB, 3, 6>(a, sm, d, chunk + 1, nb, b0);
+            __builtin_amdgcn_s_barrier();
+            if (on) loader_issue<NB, 6, 9>(a, sm, d, chunk + 1, nb, b0);
+            __builtin_amdgcn_s_barrier();
+            if (on) loader_issue<NB, 9, 12>(a, sm, d, chunk + 1, nb, b0);
+            __builtin_amdgcn_s_barrier();
+            if (on) loader_issue<NB, 12, 15>(a, sm, d, chunk + 1, nb, b0);
+            __builtin_amdgcn_s_barrier();
+            if (on) loader_issue<NB, 15, 18>(a, sm, d, chunk + 1, nb, b0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
     }
@@ -373,7 +423,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // every role runs the same number of barriers: 4 per 4-step group, groups cover macro steps 0..T+2
     // plus one more group so that the dW waves can drain the last one
-    const int n_groups = (a.T + 2) / 4 + 2;
+    const int n_groups = (((a.T + 2) / 4 + 2) + 1) & ~1;    // even: the loader walks whole 8-step chunks
     const int n_steps = 4 * n_groups;
     if (wave < 3)       chain_role<NB>(a, sm, 1, tid, n_steps);
     else if (wave < 6)  chain_role<NB>(a, sm, 0, tid - 192, n_steps);

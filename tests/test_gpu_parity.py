@@ -165,7 +165,7 @@ def test_gradients_vs_reference_goldens(nsd, dev, golden, ref_state):
     _grad_close(grads, orc.flatten_state({k: g["masked." + k] for k in orc.param_names(D)}, D), D)
 
 
-@pytest.mark.parametrize("B,T", [(1, 1), (2, 3), (9, 64), (5, 33), (300, 20), (700, 9)])
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 3), (9, 64), (5, 33), (300, 20), (301, 6), (700, 9), (1027, 5)])
 def test_gradients_vs_oracle_ragged_shapes(nsd, dev, ref_state, B, T):
     # B > 256 exercises the 2- and 4-trials-per-workgroup kernels and partial trial groups
     flat_np = orc.flatten_state(ref_state, D)

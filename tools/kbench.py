@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of the LSTM forward / backward launches (HIP events), optionally under the
+NSD_ABLATE timing switches of csrc (results are wrong under ablation; only the clock matters).
+
+    python tools/kbench.py [--B 256] [--T 250] [--iters 20] [--ablate 0,1,2,4,8,16]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=256)
+    ap.add_argument("--T", type=int, default=250)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--ablate", default="0")
+    ap.add_argument("--mask", type=int, default=1)
+    args = ap.parse_args()
+    import nsd_amd
+    from nsd_amd import ops
+    dev = torch.device("cuda:0")
+    spec = ops.ModelSpec()
+    w = np.load(os.path.join(ROOT, "tests", "golden", "weights_3class.npz"))
+    m = nsd_amd.EEG_LSTM()
+    m.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files})
+    m.to(dev)
+    flat = m.flat_parameters()
+    B, T = args.B, args.T
+    g = torch.Generator().manual_seed(0)
+    x = (2.7 * torch.randn(B, T, 8, generator=g)).to(dev)
+    y = torch.randint(0, 3, (B,), generator=g).to(torch.int32).to(dev)
+    ws = ops.new_workspace(spec, B, T, dev)
+    dl = ops.dropout_mask(1, 0, 0.6, (1, B, T, 48), dev) if args.mask else None
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+        return ts[len(ts) // 2], ts[0]
+
+    import ctypes as C
+    from nsd_amd import _lib
+    L = _lib.lib()
+    d = spec.dims(B, T)
+    st = torch.cuda.current_stream().cuda_stream
+    flags = _lib.NSD_FLAG_TRAIN
+    pp, xp, wsp = flat.data_ptr(), x.data_ptr(), ws.data_ptr()
+    dlp = dl.data_ptr() if dl is not None else None
+    for ab in [int(v) for v in args.ablate.split(",")]:
+        os.environ["NSD_ABLATE"] = str(ab)
+        logits, _ = ops.train_forward(spec, flat, x, ws, drop_lstm=dl)
+        ops.train_backward(spec, flat, x, ws, logits, labels=y, drop_lstm=dl)
+        f_med, f_min = timed(lambda: L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, st), args.iters)
+        b_med, b_min = timed(lambda: L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st), args.iters)
+        print(f"ablate={ab:3d}  B={B} T={T}  lstm_fwd {f_med:8.1f} us (min {f_min:.1f})   lstm_bwd {b_med:8.1f} us (min {b_min:.1f})", flush=True)
+    os.environ["NSD_ABLATE"] = "0"
+
+
+if __name__ == "__main__":
+    main()
