@@ -155,6 +155,12 @@ int nsd_adam_step(int64_t n, float *p, const float *g, float *m, float *v, float
 int nsd_dropout_mask(uint64_t seed, uint32_t stream_id, float p, int64_t n, float *out, void *stream);
 int nsd_rrelu_noise(uint64_t seed, uint32_t stream_id, int64_t n, float *out, void *stream);
 
+/*
+ * Diagnostics: when set to a device buffer of >= 64 int64, the LSTM backward kernel's workgroup 0 stores per wave
+ * {cycles working, cycles waiting at the step barrier}.  NULL (default) switches the stamps off.
+ */
+int nsd_debug_profile_buffer(void *device_int64_buffer);
+
 #ifdef __cplusplus
 }
 #endif

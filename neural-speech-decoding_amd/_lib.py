@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnsd_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("NSD_LIB", "libnsd_hip.so"))   # NSD_LIB=libnsd_hip_prof.so: diagnostic build
 CSRC = os.path.join(_HERE, "csrc")
 
 NSD_FLAG_RESIDUAL = 1
@@ -52,6 +52,7 @@ SYMBOLS = {
     "nsd_adam_step": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [C.c_int32, _vp]),
     "nsd_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint32, C.c_float, C.c_int64, _fp, _vp]),
     "nsd_rrelu_noise": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int64, _fp, _vp]),
+    "nsd_debug_profile_buffer": (C.c_int, [_vp]),
 }
 
 

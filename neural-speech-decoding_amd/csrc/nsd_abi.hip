@@ -92,6 +92,8 @@ static nsd_ws_layout make_ws(const nsd_dims *d, bool have_device) {
     return w;
 }
 
+static long long *g_dbg = nullptr;
+
 static bool device_present() {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess && n > 0;
@@ -287,6 +289,7 @@ int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const f
     a.in1seq = workspace + w.inseq;
     a.alpha = workspace + w.alpha; a.dscore = workspace + w.dscore; a.dpooled = workspace + w.dpooled;
     a.dsc_pack = workspace + w.adpack;
+    a.dbg = g_dbg;
     a.slabs = workspace + w.slabs;
     a.slab_stride = align4(pl.lstm_total);
     a.o_w_ih0 = pl.w_ih[0]; a.o_w_hh0 = pl.w_hh[0]; a.o_b_ih0 = pl.b_ih[0]; a.o_b_hh0 = pl.b_hh[0];
@@ -319,6 +322,8 @@ int nsd_adam_step(int64_t n, float *p, const float *g, float *m, float *v, float
     if (n < 0 || !p || !g || !m || !v) { nsd_set_error("adam: null pointer or n<0"); return NSD_E_INVALID; }
     return nsd_adam_launch(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step, (hipStream_t)stream);
 }
+
+int nsd_debug_profile_buffer(void *p) { g_dbg = (long long *)p; return NSD_OK; }
 
 int nsd_dropout_mask(uint64_t seed, uint32_t stream_id, float p, int64_t n, float *out, void *stream) {
     if (n < 0 || !out) { nsd_set_error("dropout_mask: null pointer or n<0"); return NSD_E_INVALID; }

@@ -21,6 +21,7 @@ struct Lstm2BwdArgs {
     float *slabs;
     long slab_stride;
     long o_w_ih0, o_w_hh0, o_b_ih0, o_b_hh0, o_w_ih1, o_w_hh1, o_b_ih1, o_b_hh1;
+    long long *dbg;                          // diagnostic build of the schedule: per-wave {work, wait} cycle sums of workgroup 0 (null = off)
     int B, T, C, residual;
     int ablate;                              // timing experiments only (env NSD_ABLATE); 0 in production
 };

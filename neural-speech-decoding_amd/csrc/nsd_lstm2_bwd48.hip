@@ -45,7 +45,35 @@ struct Smem {
     float xst[2][NB][CHUNK][8];            // x[T+2-m] rows for the x1 waves (dW_ih0), same chunking
 };
 
-__device__ __forceinline__ void step_barrier() { __syncthreads(); }
+// step barrier with optional cycle stamps: only in the diagnostic build (-DNSD_PROFILE=1, libnsd_hip_prof.so);
+// the shipped kernel contains no stamp
+#ifndef NSD_PROFILE
+#define NSD_PROFILE 0
+#endif
+constexpr bool kProfile = NSD_PROFILE != 0;
+struct Prof {
+    long long work, wait, last;
+    bool on;
+};
+__device__ __forceinline__ Prof prof_init(const Lstm2BwdArgs &a) {
+    Prof p; p.work = 0; p.wait = 0; p.on = kProfile && (a.dbg != nullptr) && blockIdx.x == 0; p.last = p.on ? clock64() : 0; return p;
+}
+template <bool RAW>
+__device__ __forceinline__ void step_barrier(Prof &p) {
+    if (kProfile && p.on) {
+        const long long t = clock64();
+        p.work += t - p.last;
+        if (RAW) __builtin_amdgcn_s_barrier(); else __syncthreads();
+        const long long t2 = clock64();
+        p.wait += t2 - t;
+        p.last = t2;
+    } else {
+        if (RAW) __builtin_amdgcn_s_barrier(); else __syncthreads();
+    }
+}
+__device__ __forceinline__ void prof_store(const Lstm2BwdArgs &a, const Prof &p) {
+    if (kProfile && p.on && (threadIdx.x & 63) == 0) { a.dbg[2 * (threadIdx.x >> 6)] = p.work; a.dbg[2 * (threadIdx.x >> 6) + 1] = p.wait; }
+}
 
 // ------------------------------------------------------------------------------------------------
 // chain waves: layer = 1 (t = T-1-m) or 0 (t = T+1-m)
@@ -62,6 +90,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
     for (int q = 0; q < H; ++q) whT[q] = whh[(size_t)(s * H + q) * H + j];
     const float awj = a.attn_w[j];
     float db = 0.f;
+    Prof prof = prof_init(a);
 
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
@@ -74,7 +103,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
             dpj[n] = (layer == 1 && b < B) ? a.dpooled[(size_t)b * H + j] : 0.f;
             ct[n] = (b < B) ? cseq[((size_t)b * T + (T - 1)) * H + j] : 0.f;   // c[T-1] of the first step
         }
-        step_barrier();      // chunk 0 of the stage has been written by the x1 waves
+        step_barrier<false>(prof);      // chunk 0 of the stage has been written by the x1 waves
 
         for (int m = 0; m < n_steps; ++m) {
             const int t = layer == 1 ? (T - 1 - m) : (T + 1 - m);
@@ -124,10 +153,11 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
                     ct[n] = cprev[n];    // c[t-1] is the cell state of the next step handled
                 }
             }
-            step_barrier();
+            step_barrier<false>(prof);
         }
     }
     float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    prof_store(a, prof);
     if (layer == 0) { slab[a.o_b_ih0 + s * H + j] = db; slab[a.o_b_hh0 + s * H + j] = db; }
     else            { slab[a.o_b_ih1 + s * H + j] = db; slab[a.o_b_hh1 + s * H + j] = db; }
 }
@@ -147,6 +177,7 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
     for (int g = 0; g < 4; ++g) { dWih0[g][0] = 0.f; dWih0[g][1] = 0.f; }
     const float awj = a.attn_w[j];
     const int c0 = 2 * s, c1 = 2 * s + 1;
+    Prof prof = prof_init(a);
 
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
@@ -154,7 +185,7 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
         float dpj[NB];
 #pragma unroll
         for (int n = 0; n < NB; ++n) dpj[n] = (a.residual && b0 + n < B) ? a.dpooled[(size_t)(b0 + n) * H + j] : 0.f;
-        step_barrier();
+        step_barrier<false>(prof);
 
         for (int m = 0; m < n_steps; ++m) {
             const int t1p = T - m;          // layer-1 step whose da1 was written at macro step m-1
@@ -189,9 +220,10 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
                     }
                 }
             }
-            step_barrier();
+            step_barrier<false>(prof);
         }
     }
+    prof_store(a, prof);
     float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -260,6 +292,7 @@ template <int NB>
 __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int dwid, const int lane,
                                         const int n_groups) {
     DwState<NB> st;
+    Prof prof = prof_init(a);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -270,21 +303,22 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
-        step_barrier();      // pairs with the stage-initialisation barrier of the other roles
+        step_barrier<false>(prof);      // pairs with the stage-initialisation barrier of the other roles
         for (int G = 0; G < n_groups; ++G) {
             // macro step 4G+0 : finish matrix 0 of group G-1, start fetching matrix 0 of group G; etc.
             if (G > 0 && !(a.ablate & 1)) dw_compute<0, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<0, NB>(a, st, G, b0, lane);
-            step_barrier();
+            step_barrier<false>(prof);
             if (G > 0 && !(a.ablate & 1)) dw_compute<1, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<1, NB>(a, st, G, b0, lane);
-            step_barrier();
+            step_barrier<false>(prof);
             if (G > 0 && !(a.ablate & 1)) dw_compute<2, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<2, NB>(a, st, G, b0, lane);
-            step_barrier();
-            step_barrier();
+            step_barrier<false>(prof);
+            step_barrier<false>(prof);
         }
     }
+    prof_store(a, prof);
     // accumulator tile -> slab: lane holds rows 4*(lane>>4)+r, column lane&15 of each 16x16 tile
     float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
     const long base[3] = {a.o_w_hh1, a.o_w_ih1, a.o_w_hh0};
@@ -386,34 +420,36 @@ template <int NB>
 __device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int lane, const int n_steps) {
     LdDesc d[NQ];
     loader_decode<NB>(a, lane, d);
+    Prof prof = prof_init(a);
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
         loader_issue<NB, 0, NQ>(a, sm, d, 0, 0, b0);
         loader_issue_x<NB>(a, sm, 0, 0, b0, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        step_barrier<true>(prof);
         for (int m0 = 0; m0 < n_steps; m0 += CHUNK) {
             const int chunk = m0 / CHUNK, nb = (chunk + 1) & 1;
             const bool on = !(a.ablate & 16);
             // next chunk: 3 pieces per step during steps 0..5 (+ x rows at step 0); all landed before step 7 ends
             if (on) { loader_issue<NB, 0, 3>(a, sm, d, chunk + 1, nb, b0); loader_issue_x<NB>(a, sm, chunk + 1, nb, b0, lane); }
-            __builtin_amdgcn_s_barrier();
+            step_barrier<true>(prof);
             if (on) loader_issue<NB, 3, 6>(a, sm, d, chunk + 1, nb, b0);
-            __builtin_amdgcn_s_barrier();
+            step_barrier<true>(prof);
             if (on) loader_issue<NB, 6, 9>(a, sm, d, chunk + 1, nb, b0);
-            __builtin_amdgcn_s_barrier();
+            step_barrier<true>(prof);
             if (on) loader_issue<NB, 9, 12>(a, sm, d, chunk + 1, nb, b0);
-            __builtin_amdgcn_s_barrier();
+            step_barrier<true>(prof);
             if (on) loader_issue<NB, 12, 15>(a, sm, d, chunk + 1, nb, b0);
-            __builtin_amdgcn_s_barrier();
+            step_barrier<true>(prof);
             if (on) loader_issue<NB, 15, 18>(a, sm, d, chunk + 1, nb, b0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
+            step_barrier<true>(prof);
+            step_barrier<true>(prof);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            step_barrier<true>(prof);
         }
     }
+    prof_store(a, prof);
 }
 
 template <int NB>

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ablate", default="0")
     ap.add_argument("--mask", type=int, default=1)
+    ap.add_argument("--prof", action="store_true")
     args = ap.parse_args()
     import nsd_amd
     from nsd_amd import ops
@@ -65,6 +66,17 @@ def main():
         f_med, f_min = timed(lambda: L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, st), args.iters)
         b_med, b_min = timed(lambda: L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st), args.iters)
         print(f"ablate={ab:3d}  B={B} T={T}  lstm_fwd {f_med:8.1f} us (min {f_min:.1f})   lstm_bwd {b_med:8.1f} us (min {b_min:.1f})", flush=True)
+        if args.prof:
+            dbg = torch.zeros(64, dtype=torch.int64, device=dev)
+            L.nsd_debug_profile_buffer(dbg.data_ptr())
+            L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st)
+            torch.cuda.synchronize()
+            L.nsd_debug_profile_buffer(None)
+            v = dbg.cpu().numpy().reshape(32, 2)
+            roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1"] * 3 + ["dW"] * 6 + ["loader"]
+            nst = 4 * ((((T + 2) // 4 + 2) + 1) & ~1)
+            for wv, role in enumerate(roles):
+                print(f"    wave {wv:2d} {role:7s} work {v[wv,0]/nst:7.0f} cyc/step   wait {v[wv,1]/nst:7.0f} cyc/step")
     os.environ["NSD_ABLATE"] = "0"
 
 
