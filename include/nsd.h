@@ -153,6 +153,10 @@ int nsd_adam_step(int64_t n, float *p, const float *g, float *m, float *v, float
  *   nsd_dropout_mask: out[i] = keep ? 1/(1-p) : 0       nsd_rrelu_noise: out[i] ~ U(1/8, 1/3)
  */
 int nsd_dropout_mask(uint64_t seed, uint32_t stream_id, float p, int64_t n, float *out, void *stream);
+/* the three streams of one train step in one launch: drop_lstm[n_lstm] = stream base, rrelu_slope[n_head] = base+1,
+ * drop_head[n_head] = base+2 (bit-identical to the three separate calls) */
+int nsd_train_masks(uint64_t seed, uint32_t base_stream, float p_lstm, float p_head, int64_t n_lstm, float *drop_lstm,
+                    int64_t n_head, float *rrelu_slope, float *drop_head, void *stream);
 int nsd_rrelu_noise(uint64_t seed, uint32_t stream_id, int64_t n, float *out, void *stream);
 
 /*

@@ -323,6 +323,16 @@ int nsd_adam_step(int64_t n, float *p, const float *g, float *m, float *v, float
     return nsd_adam_launch(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step, (hipStream_t)stream);
 }
 
+int nsd_train_masks(uint64_t seed, uint32_t base_stream, float p_lstm, float p_head, int64_t n_lstm, float *drop_lstm,
+                    int64_t n_head, float *rrelu_slope, float *drop_head, void *stream) {
+    if (n_lstm < 0 || n_head < 0 || (n_lstm > 0 && !drop_lstm) || (n_head > 0 && (!rrelu_slope || !drop_head))) {
+        nsd_set_error("train_masks: null pointer or negative size");
+        return NSD_E_INVALID;
+    }
+    return nsd_train_masks_launch(seed, base_stream, p_lstm, p_head, n_lstm, drop_lstm, n_head, rrelu_slope, drop_head,
+                                  (hipStream_t)stream);
+}
+
 int nsd_debug_profile_buffer(void *p) { g_dbg = (long long *)p; return NSD_OK; }
 
 int nsd_dropout_mask(uint64_t seed, uint32_t stream_id, float p, int64_t n, float *out, void *stream) {

@@ -40,6 +40,7 @@ struct HeadArgs {
     float *hslabs;
     long o_ln_w, o_ln_b, o_attn_w, o_attn_b, o_fc0_w, o_fc0_b, o_fc3_w, o_fc3_b;
     long Ph;
+    int stage_stride;                        // set by the launcher: LDS row stride of the staged sequence (0 = read from HBM)
     int B, T, H, F, K;
 };
 int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st);
@@ -53,6 +54,8 @@ int nsd_grad_reduce_launch(const float *slabs, long slab_stride, int n_slabs, lo
 int nsd_adam_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
                     float wd, float gscale, int step, hipStream_t st);
 int nsd_dropout_mask_launch(uint64_t seed, uint32_t stream_id, float p, long n, float *out, hipStream_t st);
+int nsd_train_masks_launch(uint64_t seed, uint32_t base, float p_lstm, float p_head, long n_lstm, float *drop_lstm,
+                           long n_head, float *rrelu, float *drop_head, hipStream_t st);
 int nsd_rrelu_noise_launch(uint64_t seed, uint32_t stream_id, long n, float *out, hipStream_t st);
 int nsd_loss_sum_launch(const float *loss, int B, float *out, hipStream_t st);
 

@@ -31,7 +31,7 @@ __device__ __forceinline__ float block_max(float v, float *red) {
 
 
 // dynamic LDS layout (floats): sc[T] | vecH[4][H] | vecF[2][F] | vecK[K] | part[max(H,256)... see below] | red[8]
-__device__ __forceinline__ void weighted_rowsum(const float *seq, const float *w_t, int T, int H, float *part,
+__device__ __forceinline__ void weighted_rowsum(const float *seq, int rs, const float *w_t, int T, int H, float *part,
                                                 float *out /*LDS [H]*/) {
     // out[j] = sum_t w_t[t] * seq[t][j].  Lanes run along j (coalesced rows), parts run along t.
     const int HL = H < HEAD_NT ? H : HEAD_NT;
@@ -41,7 +41,7 @@ __device__ __forceinline__ void weighted_rowsum(const float *seq, const float *w
         const int j = j0 + lane_j;
         float acc = 0.f;
         if (p < nparts && j < H)
-            for (int t = p; t < T; t += nparts) acc = fmaf(w_t[t], seq[(size_t)t * H + j], acc);
+            for (int t = p; t < T; t += nparts) acc = fmaf(w_t[t], seq[(size_t)t * rs + j], acc);
         __syncthreads();
         if (p < nparts) part[p * HL + lane_j] = acc;
         __syncthreads();
@@ -57,7 +57,8 @@ __device__ __forceinline__ void weighted_rowsum(const float *seq, const float *w
 __global__ __launch_bounds__(HEAD_NT) void head_fwd_kernel(HeadArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int T = a.T, H = a.H, F = a.F, K = a.K;
-    float *sc = lds;                  // [T]
+    float *sseq = lds;                // [T][stage_stride] staged sequence (16-byte aligned), empty when not staging
+    float *sc = lds + (size_t)T * a.stage_stride;   // [T]
     float *vaw = sc + T;              // [H] attn weights
     float *vp = vaw + H;              // [H] pooled
     float *vln = vp + H;              // [H] ln out
@@ -73,10 +74,24 @@ __global__ __launch_bounds__(HEAD_NT) void head_fwd_kernel(HeadArgs a) {
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const float *seq = a.top + (size_t)b * T * H;
+        int rs = H;
+        if (a.stage_stride) {
+            // the trial's [T,H] sequence is read twice: stage it in LDS once with 16-byte loads (rows padded so
+            // that a lane-per-row ds_read_b128 sweep is bank-conflict free)
+            __syncthreads();
+            const int h4 = H >> 2;
+            for (int e = tid; e < T * h4; e += HEAD_NT) {
+                const int t = e / h4, q = e - t * h4;
+                *reinterpret_cast<float4 *>(sseq + (size_t)t * a.stage_stride + 4 * q) =
+                    *reinterpret_cast<const float4 *>(seq + (size_t)t * H + 4 * q);
+            }
+            __syncthreads();
+            seq = sseq; rs = a.stage_stride;
+        }
         // scores over time (lstm_eeg_model.py:35)
         float lmax = -INFINITY;
         for (int t = tid; t < T; t += HEAD_NT) {
-            const float *row = seq + (size_t)t * H;
+            const float *row = seq + (size_t)t * rs;
             float s = ab;
             if ((H & 3) == 0) {
                 for (int j = 0; j < H; j += 4) {
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(HEAD_NT) void head_fwd_kernel(HeadArgs a) {
         }
         __syncthreads();
         // weighted sum over time (lstm_eeg_model.py:37)
-        weighted_rowsum(seq, sc, T, H, part, vp);
+        weighted_rowsum(seq, rs, sc, T, H, part, vp);
         // LayerNorm (lstm_eeg_model.py:38): biased variance, eps inside the sqrt
         float ls = 0.f;
         for (int j = tid; j < H; j += HEAD_NT) { ls += vp[j]; if (a.pooled) a.pooled[(size_t)b * H + j] = vp[j]; }
@@ -149,7 +164,8 @@ __global__ __launch_bounds__(HEAD_NT) void head_fwd_kernel(HeadArgs a) {
 __global__ __launch_bounds__(HEAD_NT) void head_bwd_kernel(HeadArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int T = a.T, H = a.H, F = a.F, K = a.K;
-    float *sc = lds;                  // [T]  alpha, later dscore
+    float *sseq = lds;                // [T][stage_stride] staged sequence (16-byte aligned), empty when not staging
+    float *sc = lds + (size_t)T * a.stage_stride;   // [T]  alpha, later dscore
     float *vaw = sc + T;              // [H]
     float *vx = vaw + H;              // [H] xhat
     float *vln = vx + H;              // [H] ln out
@@ -166,6 +182,20 @@ __global__ __launch_bounds__(HEAD_NT) void head_bwd_kernel(HeadArgs a) {
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const float *seq = a.top + (size_t)b * T * H;
+        int rs = H;
+        if (a.stage_stride) {
+            // the trial's [T,H] sequence is read twice: stage it in LDS once with 16-byte loads (rows padded so
+            // that a lane-per-row ds_read_b128 sweep is bank-conflict free)
+            __syncthreads();
+            const int h4 = H >> 2;
+            for (int e = tid; e < T * h4; e += HEAD_NT) {
+                const int t = e / h4, q = e - t * h4;
+                *reinterpret_cast<float4 *>(sseq + (size_t)t * a.stage_stride + 4 * q) =
+                    *reinterpret_cast<const float4 *>(seq + (size_t)t * H + 4 * q);
+            }
+            __syncthreads();
+            seq = sseq; rs = a.stage_stride;
+        }
         float *slab = a.hslabs + (size_t)b * a.Ph;
         // dlogits (given, or mean-CE from labels)
         if (tid == 0) {
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(HEAD_NT) void head_bwd_kernel(HeadArgs a) {
         // attention backward: dalpha_t = dp . out_t ; ds = alpha * (dalpha - sum alpha*dalpha)
         float lsd = 0.f;
         for (int t = tid; t < T; t += HEAD_NT) {
-            const float *row = seq + (size_t)t * H;
+            const float *row = seq + (size_t)t * rs;
             float d = 0.f;
             for (int j = 0; j < H; ++j) d = fmaf(row[j], vdp[j], d);
             const float al = a.alpha[(size_t)b * T + t];
@@ -261,7 +291,7 @@ __global__ __launch_bounds__(HEAD_NT) void head_bwd_kernel(HeadArgs a) {
         const float dab = block_sum(lb, red);
         if (tid == 0) slab[a.o_attn_b] = dab;
         // d attn.weight[j] = sum_t ds_t * out_t[j]
-        weighted_rowsum(seq, sc, T, H, part, vx);
+        weighted_rowsum(seq, rs, sc, T, H, part, vx);
         for (int j = tid; j < H; j += HEAD_NT) slab[a.o_attn_w + j] = vx[j];
         __syncthreads();
     }
@@ -272,9 +302,19 @@ static size_t head_lds_bytes(int T, int H, int F, int K, bool bwd) {
     return n * sizeof(float);
 }
 
-int nsd_head_launch(const HeadArgs &a, bool bwd, hipStream_t st) {
+int nsd_head_launch(const HeadArgs &a_in, bool bwd, hipStream_t st) {
+    HeadArgs a = a_in;
     if (a.B <= 0) return NSD_OK;
-    const size_t lds = head_lds_bytes(a.T, a.H, a.F, a.K, bwd);
+    size_t lds = head_lds_bytes(a.T, a.H, a.F, a.K, bwd);
+    // stage the sequence in LDS when it fits next to the small vectors (<= 144 KB): row stride = H rounded up
+    // to 4 (mod 8) floats
+    a.stage_stride = 0;
+    if ((a.H & 3) == 0) {
+        int stride = a.H + 4;
+        if (((stride >> 2) & 1) == 0) stride += 4;
+        const size_t need = lds + (size_t)a.T * stride * sizeof(float);
+        if (need <= 144 * 1024) { a.stage_stride = stride; lds = need; }
+    }
     if (lds > 160 * 1024 || a.H > HEAD_NT * 8) {
         nsd_set_error("head: T=%d H=%d needs %zu B of LDS (max 163840)", a.T, a.H, lds);
         return NSD_E_INVALID;

@@ -51,29 +51,41 @@ int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t
 // gradient reduction: grads[e] (+)= sum over the per-workgroup LSTM slabs (e < P_lstm) or over the
 // per-trial head slabs (e >= P_lstm).  Column sums: consecutive threads read consecutive floats.
 // ---------------------------------------------------------------------------------------------
-__global__ void grad_reduce_kernel(const float *slabs, long slab_stride, int n_slabs, long p_lstm,
-                                   const float *hslabs, long ph, int n_hslabs, float *grads, int accumulate) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p_lstm + ph) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const float *p; long stride; int n;
-    if (e < p_lstm) { p = slabs + e; stride = slab_stride; n = n_slabs; }
-    else { p = hslabs + (e - p_lstm); stride = ph; n = n_hslabs; }
-    int q = 0;
-    for (; q + 3 < n; q += 4) {
-        s0 += p[(size_t)q * stride]; s1 += p[(size_t)(q + 1) * stride];
-        s2 += p[(size_t)(q + 2) * stride]; s3 += p[(size_t)(q + 3) * stride];
+// One workgroup = 32 consecutive gradient entries x 8 slab groups: lane (c = tid&31, grp = tid>>5) sums its share
+// of the slabs for column c (consecutive lanes read 128 contiguous bytes of a slab row), the 8 partials meet
+// in LDS in a fixed order (deterministic).  ~1000 workgroups for the reference model instead of 124.
+#define GR_COLS 32
+#define GR_GROUPS 8
+__global__ __launch_bounds__(GR_COLS * GR_GROUPS) void grad_reduce_kernel(
+        const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs, long ph, int n_hslabs,
+        float *grads, int accumulate) {
+    __shared__ float part[GR_GROUPS][GR_COLS];
+    const int c = threadIdx.x & (GR_COLS - 1), grp = threadIdx.x / GR_COLS;
+    const long e = (long)blockIdx.x * GR_COLS + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < p_lstm + ph) {
+        const float *p; long stride; int n;
+        if (e < p_lstm) { p = slabs + e; stride = slab_stride; n = n_slabs; }
+        else { p = hslabs + (e - p_lstm); stride = ph; n = n_hslabs; }
+        int q = grp;
+        for (; q + GR_GROUPS < n; q += 2 * GR_GROUPS) { s0 += p[(size_t)q * stride]; s1 += p[(size_t)(q + GR_GROUPS) * stride]; }
+        if (q < n) s0 += p[(size_t)q * stride];
     }
-    for (; q < n; ++q) s0 += p[(size_t)q * stride];
-    const float s = (s0 + s1) + (s2 + s3);
-    grads[e] = accumulate ? grads[e] + s : s;
+    part[grp][c] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && e < p_lstm + ph) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < GR_GROUPS; ++g) s += part[g][c];
+        grads[e] = accumulate ? grads[e] + s : s;
+    }
 }
 
 int nsd_grad_reduce_launch(const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs,
                            long ph, int n_hslabs, float *grads, int accumulate, hipStream_t st) {
     const long n = p_lstm + ph;
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, slab_stride,
-                       n_slabs, p_lstm, hslabs, ph, n_hslabs, grads, accumulate);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((n + GR_COLS - 1) / GR_COLS)), dim3(GR_COLS * GR_GROUPS), 0, st,
+                       slabs, slab_stride, n_slabs, p_lstm, hslabs, ph, n_hslabs, grads, accumulate);
     NSD_CHECK_LAUNCH("grad_reduce");
     return NSD_OK;
 }
@@ -120,6 +132,42 @@ __global__ void rrelu_noise_kernel(uint64_t seed, uint32_t stream_id, long n, fl
         const float u = (float)(nsd_rand_u32(seed, stream_id, (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
         out[i] = lower + (upper - lower) * u;
     }
+}
+
+// all three train-mode streams of one step in ONE launch (stream ids base, base+1, base+2: bit-identical to
+// the separate calls): LSTM inter-layer dropout [n_lstm], RReLU slopes [n_head], head dropout [n_head]
+__global__ void train_masks_kernel(uint64_t seed, uint32_t base, uint32_t thr_lstm, float keep_lstm, uint32_t thr_head,
+                                   float keep_head, long n_lstm, float *drop_lstm, long n_head, float *rrelu, float *drop_head) {
+    const float lower = 0.125f, upper = (float)(1.0 / 3.0);
+    const long total = n_lstm + 2 * n_head;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (i < n_lstm) {
+            drop_lstm[i] = nsd_rand_u32(seed, base, (uint64_t)i) >= thr_lstm ? keep_lstm : 0.f;
+        } else if (i < n_lstm + n_head) {
+            const long k = i - n_lstm;
+            const float u = (float)(nsd_rand_u32(seed, base + 1u, (uint64_t)k) >> 8) * (1.0f / 16777216.0f);
+            rrelu[k] = lower + (upper - lower) * u;
+        } else {
+            const long k = i - n_lstm - n_head;
+            drop_head[k] = nsd_rand_u32(seed, base + 2u, (uint64_t)k) >= thr_head ? keep_head : 0.f;
+        }
+    }
+}
+static uint32_t drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+int nsd_train_masks_launch(uint64_t seed, uint32_t base, float p_lstm, float p_head, long n_lstm, float *drop_lstm,
+                           long n_head, float *rrelu, float *drop_head, hipStream_t st) {
+    if (!(p_lstm >= 0.f && p_lstm < 1.f) || !(p_head >= 0.f && p_head < 1.f)) { nsd_set_error("train_masks: p out of [0,1)"); return NSD_E_INVALID; }
+    const long total = n_lstm + 2 * n_head;
+    if (total <= 0) return NSD_OK;
+    long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(train_masks_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, base, drop_threshold(p_lstm),
+                       1.0f / (1.0f - p_lstm), drop_threshold(p_head), 1.0f / (1.0f - p_head), n_lstm, drop_lstm, n_head, rrelu, drop_head);
+    NSD_CHECK_LAUNCH("train_masks");
+    return NSD_OK;
 }
 
 int nsd_dropout_mask_launch(uint64_t seed, uint32_t stream_id, float p, long n, float *out, hipStream_t st) {

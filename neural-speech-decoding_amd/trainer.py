@@ -94,11 +94,17 @@ class Trainer:
         self.step_count += 1
         sid = (self.step_count & 0x3FFFFFFF) * 4
         dl = buf.get("drop_lstm"); sl = buf.get("rrelu"); dh = buf.get("drop_head")
-        if dl is not None:
+        if dl is not None and sl is not None and dh is not None:
+            _lib.check(L.nsd_train_masks(self.seed, sid, self.model.dropout_p, self.model.head_dropout_p, dl.numel(),
+                                         dl.data_ptr(), sl.numel(), sl.data_ptr(), dh.data_ptr(), st), "train_masks")
+            dl_done = True
+        else:
+            dl_done = False
+        if dl is not None and not dl_done:
             _lib.check(L.nsd_dropout_mask(self.seed, sid, self.model.dropout_p, dl.numel(), dl.data_ptr(), st), "dropout_mask")
-        if sl is not None:
+        if sl is not None and not dl_done:
             _lib.check(L.nsd_rrelu_noise(self.seed, sid + 1, sl.numel(), sl.data_ptr(), st), "rrelu_noise")
-        if dh is not None:
+        if dh is not None and not dl_done:
             _lib.check(L.nsd_dropout_mask(self.seed, sid + 2, self.model.head_dropout_p, dh.numel(), dh.data_ptr(), st), "dropout_mask")
         ws = buf["ws"]
         scale = 1.0 / (B * self.world)

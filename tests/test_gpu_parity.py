@@ -272,6 +272,40 @@ def test_counter_streams_bit_exact(nsd, dev):
         assert np.array_equal(b, orc.rrelu_noise(seed, stream, (777,)))
 
 
+def test_fused_train_masks_bit_exact(nsd, dev):
+    from nsd_amd import _lib
+    L = _lib.lib()
+    n_lstm, n_head = 3 * 17 * 48, 3 * 32
+    a = torch.empty(n_lstm, device=dev); b = torch.empty(n_head, device=dev); c = torch.empty(n_head, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.nsd_train_masks(99, 40, 0.6, 0.25, n_lstm, a.data_ptr(), n_head, b.data_ptr(), c.data_ptr(), st), "train_masks")
+    assert np.array_equal(a.cpu().numpy(), orc.dropout_mask(99, 40, 0.6, (n_lstm,)))
+    assert np.array_equal(b.cpu().numpy(), orc.rrelu_noise(99, 41, (n_head,)))
+    assert np.array_equal(c.cpu().numpy(), orc.dropout_mask(99, 42, 0.25, (n_head,)))
+
+
+def test_trainer_step_matches_oracle_with_its_own_streams(nsd, dev, ref_state):
+    """One fused Trainer.step == oracle forward/backward with the same counter-based masks + oracle Adam."""
+    from nsd_amd.trainer import Trainer
+    m = _model(nsd, dev, ref_state).train()
+    tr = Trainer(m, lr=1e-3, seed=7)
+    B, T = 12, 40
+    x, y = synth_x(B, T, seed=4), synth_labels(B, seed=4)
+    flat0 = orc.flatten_state(ref_state, D)
+    tr.step(_t(x, dev), _t(y, dev))
+    sid = 4
+    dl = orc.dropout_mask(tr.seed, sid, 0.6, (1, B, T, 48))
+    sl = orc.rrelu_noise(tr.seed, sid + 1, (B, 32))
+    dh = orc.dropout_mask(tr.seed, sid + 2, 0.6, (B, 32))
+    loss_ref, g_ref, _ = orc.loss_and_grads(flat0, x, y, D, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    assert abs(tr.last_loss() - loss_ref) < 5e-5
+    _grad_close(tr.grads.cpu().numpy(), g_ref, D, rtol=3e-4)
+    # Adam on the step's own gradient (entries with |g| ~ eps make the update ill-conditioned w.r.t. g itself)
+    p, mm, vv = flat0.copy(), np.zeros_like(flat0), np.zeros_like(flat0)
+    orc.adam(p, tr.grads.cpu().numpy(), mm, vv, lr=1e-3, step=1)
+    assert np.abs(m.flat_parameters().cpu().numpy() - p).max() < 2e-6
+
+
 def test_adam_matches_oracle_and_torch(nsd, dev):
     from nsd_amd import ops
     rs = np.random.RandomState(0)
