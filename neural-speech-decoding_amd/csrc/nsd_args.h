@@ -47,6 +47,7 @@ int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st);
 int nsd_lstm2_bwd_launch(const Lstm2BwdArgs &a, int H, hipStream_t st);
 int nsd_lstm2_bwd_grid(int B);
 int nsd_lstm2_bwd48_launch(const Lstm2BwdArgs &a, int nb, int grid, hipStream_t st);
+int nsd_lstm2_fwd48_launch(const Lstm2FwdArgs &a, int nb, int grid, hipStream_t st);
 int nsd_head_launch(const HeadArgs &a, bool bwd, hipStream_t st);
 int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t st);
 int nsd_grad_reduce_launch(const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs,

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(8 * H) void lstm2_fwd_kernel(Lstm2FwdArgs a) {
     static_assert(KS % 4 == 0, "H must be a multiple of 16");
 
     __shared__ __align__(16) float xs[2][NB][XCH][CP];
+    __shared__ __align__(16) float ms[2][NB][XCH][H];   // inter-layer dropout multipliers, staged like x
     __shared__ __align__(16) float h0s[2][NB][H];   // h of layer 0 (recurrent operand)
     __shared__ __align__(16) float h0m[2][NB][H];   // layer-0 output after dropout (layer-1 input)
     __shared__ __align__(16) float h1s[2][NB][H];
@@ -79,17 +80,29 @@ __global__ __launch_bounds__(8 * H) void lstm2_fwd_kernel(Lstm2FwdArgs a) {
             (&h0m[0][0][0])[e] = 0.f;
             (&h1s[0][0][0])[e] = 0.f;
         }
-        // x chunk 0 straight into LDS
+        // x chunk 0 (and the dropout multipliers of chunk 0) straight into LDS
         for (int e = tid; e < XE; e += NT) {
             const int n = e / (XCH * CP), tl = (e / CP) % XCH, ch = e % CP;
             const int b = b0 + n;
             xs[0][n][tl][ch] = (b < B && tl < T && ch < C) ? a.x[((size_t)b * T + tl) * C + ch] : 0.f;
         }
+        // the mask chunk [XCH][H] of a trial is XCH*H/4 = NT float4: one per thread and trial
+        auto mask_f4 = [&](int t0, int n) -> float4 {
+            const int tl = tid / (H / 4), q = tid - tl * (H / 4);
+            const int b = b0 + n, t = t0 + tl;
+            if (a.mask && b < B && t < T) return *reinterpret_cast<const float4 *>(a.mask + ((size_t)b * T + t) * H + 4 * q);
+            return make_float4(1.f, 1.f, 1.f, 1.f);
+        };
+#pragma unroll
+        for (int n = 0; n < NB; ++n) *reinterpret_cast<float4 *>(&ms[0][n][0][0] + 4 * tid) = mask_f4(0, n);
         __syncthreads();
 
         for (int m0 = 0; m0 <= T; m0 += XCH) {
-            // prefetch the next x chunk into registers; written to LDS at the end of this chunk
+            // prefetch the next x / mask chunk into registers; written to LDS at the end of this chunk.  The
+            // recurrence itself never waits for HBM: a dependent global load per step would cost a full
+            // memory latency (~1 us) per step.
             float xr[XPT];
+            float4 mr[NB];
 #pragma unroll
             for (int q = 0; q < XPT; ++q) {
                 const int e = tid + q * NT;
@@ -97,6 +110,8 @@ __global__ __launch_bounds__(8 * H) void lstm2_fwd_kernel(Lstm2FwdArgs a) {
                 const int b = b0 + n, t = m0 + XCH + tl;
                 xr[q] = (e < XE && b < B && t < T && ch < C) ? a.x[((size_t)b * T + t) * C + ch] : 0.f;
             }
+#pragma unroll
+            for (int n = 0; n < NB; ++n) mr[n] = mask_f4(m0 + XCH, n);
             const int cb = (m0 / XCH) & 1;
             for (int k = 0; k < XCH; ++k) {
                 const int m = m0 + k;
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(8 * H) void lstm2_fwd_kernel(Lstm2FwdArgs a) {
                             const int b = b0 + n;
                             const bool valid = b < B;
                             const size_t idx = ((size_t)(valid ? b : 0) * T + t) * H + j;
-                            const float mk = (a.mask && valid) ? a.mask[idx] : 1.f;
+                            const float mk = ms[cb][n][k][j];
                             const float2 xv = *reinterpret_cast<const float2 *>(&xs[cb][n][k][s * CS]);
                             float hv[KS];
 #pragma unroll
@@ -192,6 +207,8 @@ __global__ __launch_bounds__(8 * H) void lstm2_fwd_kernel(Lstm2FwdArgs a) {
                         const int e = tid + q * NT;
                         if (e < XE) (&xs[cb ^ 1][0][0][0])[e] = xr[q];
                     }
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) *reinterpret_cast<float4 *>(&ms[cb ^ 1][n][0][0] + 4 * tid) = mr[n];
                 }
                 __syncthreads();
             }
@@ -519,7 +536,10 @@ int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st) {
     if (grid <= 0) return NSD_OK;
     switch (H) {
     case 32: launch_fwd_h<32>(a, nb, grid, st); break;
-    case 48: launch_fwd_h<48>(a, nb, grid, st); break;
+    case 48: {   // role-split kernel (nsd_lstm2_fwd48.hip): one trial per workgroup, one workgroup per CU, batches loop
+        const int cus = nsd_num_cus();
+        return nsd_lstm2_fwd48_launch(a, 1, a.B < cus ? a.B : cus, st);
+    }
     case 64: launch_fwd_h<64>(a, nb, grid, st); break;
     default: nsd_set_error("lstm2 fwd: unsupported H=%d", H); return NSD_E_INVALID;
     }
