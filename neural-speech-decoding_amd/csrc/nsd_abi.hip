@@ -154,6 +154,7 @@ static int build_lstm_fwd(const nsd_dims *d, const float *params, const float *x
     a.w_ih0 = params + pl.w_ih[0]; a.w_hh0 = params + pl.w_hh[0]; a.b_ih0 = params + pl.b_ih[0]; a.b_hh0 = params + pl.b_hh[0];
     a.w_ih1 = params + pl.w_ih[1]; a.w_hh1 = params + pl.w_hh[1]; a.b_ih1 = params + pl.b_ih[1]; a.b_hh1 = params + pl.b_hh[1];
     a.mask = drop_lstm;
+    a.dbg = g_dbg;
     a.B = d->B; a.T = d->T; a.C = d->C;
     a.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
     { const char *ab_ = getenv("NSD_ABLATE"); a.ablate = ab_ ? atoi(ab_) : 0; }

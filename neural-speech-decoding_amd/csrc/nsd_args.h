@@ -7,6 +7,7 @@ struct Lstm2FwdArgs {
     const float *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1;
     const float *mask;
     float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
+    long long *dbg;                          // diagnostic build only (see nsd_prof.h)
     int B, T, C, residual;
     int ablate;                              // timing experiments only (env NSD_ABLATE); 0 in production
 };

@@ -323,11 +323,11 @@ int nsd_head_launch(const HeadArgs &a_in, bool bwd, hipStream_t st) {
     const int grid = a.B < cap ? a.B : cap;
     if (bwd) {
         if (lds > 64 * 1024)
-            hipFuncSetAttribute((const void *)head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(HEAD_NT), lds, st, a);
     } else {
         if (lds > 64 * 1024)
-            hipFuncSetAttribute((const void *)head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(head_fwd_kernel, dim3(grid), dim3(HEAD_NT), lds, st, a);
     }
     NSD_CHECK_LAUNCH(bwd ? "head_bwd" : "head_fwd");

@@ -19,6 +19,7 @@
 // LDS: da ring [2 layers][8 steps][NB][192] + d_in1 double buffer.  HBM traffic = saved activations read
 // once (gates, c, h, in1, x) + one slab of partial gradients per workgroup at the end.
 #include "nsd_args.h"
+#include "nsd_prof.h"
 
 namespace {
 
@@ -45,36 +46,6 @@ struct Smem {
     float xst[2][NB][CHUNK][8];            // x[T+2-m] rows for the x1 waves (dW_ih0), same chunking
 };
 
-// step barrier with optional cycle stamps: only in the diagnostic build (-DNSD_PROFILE=1, libnsd_hip_prof.so);
-// the shipped kernel contains no stamp
-#ifndef NSD_PROFILE
-#define NSD_PROFILE 0
-#endif
-constexpr bool kProfile = NSD_PROFILE != 0;
-struct Prof {
-    long long work, wait, last;
-    bool on;
-};
-__device__ __forceinline__ Prof prof_init(const Lstm2BwdArgs &a) {
-    Prof p; p.work = 0; p.wait = 0; p.on = kProfile && (a.dbg != nullptr) && blockIdx.x == 0; p.last = p.on ? clock64() : 0; return p;
-}
-template <bool RAW>
-__device__ __forceinline__ void step_barrier(Prof &p) {
-    if (kProfile && p.on) {
-        const long long t = clock64();
-        p.work += t - p.last;
-        if (RAW) __builtin_amdgcn_s_barrier(); else __syncthreads();
-        const long long t2 = clock64();
-        p.wait += t2 - t;
-        p.last = t2;
-    } else {
-        if (RAW) __builtin_amdgcn_s_barrier(); else __syncthreads();
-    }
-}
-__device__ __forceinline__ void prof_store(const Lstm2BwdArgs &a, const Prof &p) {
-    if (kProfile && p.on && (threadIdx.x & 63) == 0) { a.dbg[2 * (threadIdx.x >> 6)] = p.work; a.dbg[2 * (threadIdx.x >> 6) + 1] = p.wait; }
-}
-
 // ------------------------------------------------------------------------------------------------
 // chain waves: layer = 1 (t = T-1-m) or 0 (t = T+1-m)
 // ------------------------------------------------------------------------------------------------
@@ -90,7 +61,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
     for (int q = 0; q < H; ++q) whT[q] = whh[(size_t)(s * H + q) * H + j];
     const float awj = a.attn_w[j];
     float db = 0.f;
-    Prof prof = prof_init(a);
+    Prof prof = prof_init(a.dbg);
 
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
@@ -157,7 +128,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
         }
     }
     float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
-    prof_store(a, prof);
+    prof_store(a.dbg, prof);
     if (layer == 0) { slab[a.o_b_ih0 + s * H + j] = db; slab[a.o_b_hh0 + s * H + j] = db; }
     else            { slab[a.o_b_ih1 + s * H + j] = db; slab[a.o_b_hh1 + s * H + j] = db; }
 }
@@ -177,7 +148,7 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
     for (int g = 0; g < 4; ++g) { dWih0[g][0] = 0.f; dWih0[g][1] = 0.f; }
     const float awj = a.attn_w[j];
     const int c0 = 2 * s, c1 = 2 * s + 1;
-    Prof prof = prof_init(a);
+    Prof prof = prof_init(a.dbg);
 
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
@@ -223,7 +194,7 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
             step_barrier<false>(prof);
         }
     }
-    prof_store(a, prof);
+    prof_store(a.dbg, prof);
     float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -292,7 +263,7 @@ template <int NB>
 __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int dwid, const int lane,
                                         const int n_groups) {
     DwState<NB> st;
-    Prof prof = prof_init(a);
+    Prof prof = prof_init(a.dbg);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -318,7 +289,7 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
             step_barrier<false>(prof);
         }
     }
-    prof_store(a, prof);
+    prof_store(a.dbg, prof);
     // accumulator tile -> slab: lane holds rows 4*(lane>>4)+r, column lane&15 of each 16x16 tile
     float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
     const long base[3] = {a.o_w_hh1, a.o_w_ih1, a.o_w_hh0};
@@ -420,7 +391,7 @@ template <int NB>
 __device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int lane, const int n_steps) {
     LdDesc d[NQ];
     loader_decode<NB>(a, lane, d);
-    Prof prof = prof_init(a);
+    Prof prof = prof_init(a.dbg);
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
@@ -449,7 +420,7 @@ __device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm,
             step_barrier<true>(prof);
         }
     }
-    prof_store(a, prof);
+    prof_store(a.dbg, prof);
 }
 
 template <int NB>
@@ -461,11 +432,12 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     // plus one more group so that the dW waves can drain the last one
     const int n_groups = (((a.T + 2) / 4 + 2) + 1) & ~1;    // even: the loader walks whole 8-step chunks
     const int n_steps = 4 * n_groups;
-    if (wave < 3)       chain_role<NB>(a, sm, 1, tid, n_steps);
-    else if (wave < 6)  chain_role<NB>(a, sm, 0, tid - 192, n_steps);
-    else if (wave < 9)  x1_role<NB>(a, sm, tid - 384, n_steps);
+    // issue priority follows the critical path: the two recurrences first, then the hand-off to layer 0
+    if (wave < 3)       { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 1, tid, n_steps); }
+    else if (wave < 6)  { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 0, tid - 192, n_steps); }
+    else if (wave < 9)  { __builtin_amdgcn_s_setprio(2); x1_role<NB>(a, sm, tid - 384, n_steps); }
     else if (wave < 15) dw_role<NB>(a, sm, wave - 9, tid & 63, n_groups);
-    else                loader_role<NB>(a, sm, tid & 63, n_steps);
+    else                { __builtin_amdgcn_s_setprio(1); loader_role<NB>(a, sm, tid & 63, n_steps); }
 }
 
 }  // namespace

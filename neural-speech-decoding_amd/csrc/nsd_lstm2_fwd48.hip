@@ -20,14 +20,22 @@
 // LDS, DPP quad reduction, lane s of the quad evaluates gate s.  One barrier per step.  x and the dropout
 // multipliers are staged through LDS in 32-step chunks, prefetched one chunk ahead.
 #include "nsd_args.h"
+#include "nsd_prof.h"
 
 namespace {
 
 constexpr int H = 48;
 constexpr int KS = 12;
-constexpr int NT = 576;
+constexpr int NT = 640;
 constexpr int XCH = 32;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// ---- activations for the backward pass leave through LDS: a per-step record written by the chain lanes
+// (cheap ds_write_b32) and streamed to HBM by a dedicated wave with 16-byte stores, 8 steps at a time.
+// Per-step dword stores from the 6 chain waves (~22 VMEM instructions per step) would sit on the recurrence.
+constexpr int SREC = 336;                 // floats per (layer, step): gates[192] | h[48] | c[48] | in1 or top[48]
+constexpr int SREC4 = SREC / 4;           // 84
+constexpr int SRING = 16;                 // steps kept in LDS (two 8-step chunks)
+constexpr int SCH = 8;
 
 template <int NB>
 struct FSmem {
@@ -38,6 +46,7 @@ struct FSmem {
     float h1s[2][NB][H];
     float pb[2][NB][4 * H];      // layer-1 input projection, [gate*48 + unit]
     float pin[2][NB][H];         // layer-1 input itself (residual top only)
+    float sv[SRING][NB][2][SREC];   // save ring, indexed by macro step % SRING
 };
 
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -52,13 +61,17 @@ __device__ __forceinline__ void load_slice(const float *p, f32x2 (&v)[6]) {
     }
 }
 
-// gate pre-activations of unit j, reduced over the 4 k-slices of the quad; returns the one of gate s
+// gate pre-activations of unit j, reduced over the 4 k-slices of the quad; lane s returns the sum of gate s.
+// Reduce-scatter (3 DPP adds, depth 4) instead of 4 full quad sums (8 DPP adds) + a 3-deep select.
 __device__ __forceinline__ float reduce_pick(const f32x2 (&acc)[4], const int s) {
-    float r[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) r[g] = quad_sum(acc[g].x + acc[g].y);
-    return s == 0 ? r[0] : s == 1 ? r[1] : s == 2 ? r[2] : r[3];
+    const float r0 = acc[0].x + acc[0].y, r1 = acc[1].x + acc[1].y;
+    const float r2 = acc[2].x + acc[2].y, r3 = acc[3].x + acc[3].y;
+    const bool odd = (s & 1) != 0, hi = (s & 2) != 0;
+    const float ra = (odd ? r1 : r0) + quad_xor1(odd ? r0 : r1);   // gate (odd ? 1 : 0) over lanes {s, s^1}
+    const float rb = (odd ? r3 : r2) + quad_xor1(odd ? r2 : r3);   // gate (odd ? 3 : 2) over lanes {s, s^1}
+    return (hi ? rb : ra) + quad_xor2(hi ? ra : rb);
 }
+
 
 struct GateConst { float a, b, c; };
 __device__ __forceinline__ GateConst gate_const(const int s) {
@@ -94,6 +107,7 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
     constexpr int XPT = (XE + 191) / 192;
     constexpr int MPT = NB * 2;                      // mask float4 per thread: XCH*H/4 = 384 per trial / 192 threads
 
+    Prof prof = prof_init(a.dbg);
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
@@ -120,7 +134,7 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
         for (int q = 0; q < XPT; ++q) { const int e = r + 192 * q; if (e < XE) (&sm.xs[0][0][0][0])[e] = x_at(e, 0); }
 #pragma unroll
         for (int q = 0; q < MPT; ++q) *reinterpret_cast<float4 *>(&sm.ms[0][0][0][0] + 4 * (r + 192 * q)) = mask_at(r + 192 * q, 0);
-        __syncthreads();
+        step_barrier<false>(prof);
 
         for (int m0 = 0; m0 < n_steps; m0 += XCH) {
             float xr[XPT]; float4 mr[MPT];
@@ -134,12 +148,8 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                 if (m >= n_steps) break;
                 const int cur = m & 1, prv = cur ^ 1;
                 if (m < T) {
-                    const int t = m;
 #pragma unroll
                     for (int n = 0; n < NB; ++n) {
-                        const int b = b0 + n;
-                        const bool valid = b < B;
-                        const size_t idx = ((size_t)(valid ? b : 0) * T + t) * H + j;
                         const float mk = sm.ms[cb][n][k][j];
                         const float2 xq = *reinterpret_cast<const float2 *>(&sm.xs[cb][n][k][2 * s]);
                         const f32x2 xv = {xq.x, xq.y};
@@ -161,12 +171,11 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                         const float hm = h * mk;
                         if (s == 0) sm.h0s[cur][n][j] = h;
                         if (s == 1) sm.h0m[cur][n][j] = hm;
-                        if (valid) {
-                            if (a.gact0) a.gact0[idx * 4 + s] = act;
-                            if (s == 0 && a.hseq0) a.hseq0[idx] = h;
-                            if (s == 1 && a.cseq0) a.cseq0[idx] = c[n];
-                            if (s == 2 && a.inseq) a.inseq[idx] = hm;
-                        }
+                        float *sr = &sm.sv[m & (SRING - 1)][n][0][0];
+                        sr[4 * j + s] = act;
+                        if (s == 0) sr[192 + j] = h;
+                        if (s == 1) sr[240 + j] = c[n];
+                        if (s == 2) sr[288 + j] = hm;
                     }
                 }
                 if (k == XCH - 1) {
@@ -175,10 +184,12 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
 #pragma unroll
                     for (int q = 0; q < MPT; ++q) *reinterpret_cast<float4 *>(&sm.ms[cb ^ 1][0][0][0] + 4 * (r + 192 * q)) = mr[q];
                 }
-                __syncthreads();
+                step_barrier<false>(prof);
             }
         }
+        step_barrier<false>(prof);      // the saver wave has drained the save ring of this trial group
     }
+    prof_store(a.dbg, prof);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -196,9 +207,10 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
             wi[g][q].x = a.w_ih1[(size_t)(g * H + j) * H + s * KS + 2 * q];
             wi[g][q].y = a.w_ih1[(size_t)(g * H + j) * H + s * KS + 2 * q + 1];
         }
+    Prof prof = prof_init(a.dbg);
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
-        __syncthreads();
+        step_barrier<false>(prof);
         for (int m = 0; m < n_steps; ++m) {
             if (m >= 1 && m <= T) {
 #pragma unroll
@@ -216,9 +228,11 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
                     if (a.residual && s == 0) sm.pin[m & 1][n][j] = sm.h0m[(m - 1) & 1][n][j];
                 }
             }
-            __syncthreads();
+            step_barrier<false>(prof);
         }
+        step_barrier<false>(prof);      // save ring drained
     }
+    prof_store(a.dbg, prof);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,50 +252,138 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
         }
     const float bias = a.b_ih1[s * H + j] + a.b_hh1[s * H + j];
     const GateConst gk = gate_const(s);
+    Prof prof = prof_init(a.dbg);
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
         float c[NB];
 #pragma unroll
         for (int n = 0; n < NB; ++n) c[n] = 0.f;
-        __syncthreads();
+        step_barrier<false>(prof);
         for (int m = 0; m < n_steps; ++m) {
             const int t = m - 2;
+            prof_mark<-1, false>(prof);
             if (t >= 0 && t < T) {
                 const int cur = m & 1, prv = cur ^ 1;
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
-                    const int b = b0 + n;
-                    const bool valid = b < B;
-                    const size_t idx = ((size_t)(valid ? b : 0) * T + t) * H + j;
                     const float pj = sm.pb[prv][n][s * H + j];          // input projection of this step (gate s)
                     f32x2 hv[6];
                     load_slice(&sm.h1s[prv][n][s * KS], hv);
+                    prof_mark<0, true>(prof);        // seg0: LDS operands arrived
                     f32x2 acc[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         acc[g] = wh[g][0] * hv[0];
+                        if (!(a.ablate & 4)) {
 #pragma unroll
-                        for (int q = 1; q < 6; ++q) acc[g] = pk_fma(wh[g][q], hv[q], acc[g]);
+                            for (int q = 1; q < 6; ++q) acc[g] = pk_fma(wh[g][q], hv[q], acc[g]);
+                        }
                     }
-                    const float pre = reduce_pick(acc, s) + (pj + bias);
-                    const float act = gate_act(pre, gk.a, gk.b, gk.c);
-                    const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act);
-                    const float gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
+                    prof_mark<1, false>(prof);       // seg1: 24 pk_fma issued (not necessarily retired)
+                    const float pre = ((a.ablate & 16) ? acc[0].x + acc[1].y + acc[2].x + acc[3].y : reduce_pick(acc, s)) + (pj + bias);
+                    prof_mark<2, false>(prof);       // seg2: quad reduction + select
+                    const float act = (a.ablate & 1) ? pre * 0.01f : gate_act(pre, gk.a, gk.b, gk.c);
+                    float ig, fg, gg, og;
+                    if (a.ablate & 32) { ig = act; fg = act * 0.5f; gg = act * 0.25f; og = act * 0.125f; }
+                    else { ig = quad_bcast<0>(act); fg = quad_bcast<1>(act); gg = quad_bcast<2>(act); og = quad_bcast<3>(act); }
+                    prof_mark<3, false>(prof);       // seg3: gate activation + quad broadcast
                     c[n] = fmaf(fg, c[n], ig * gg);
-                    const float h = og * fast_tanh(c[n]);
+                    const float h = og * ((a.ablate & 2) ? c[n] : fast_tanh(c[n]));
                     if (s == 0) sm.h1s[cur][n][j] = h;
-                    if (valid) {
-                        if (a.gact1) a.gact1[idx * 4 + s] = act;
-                        if (s == 0 && a.hseq1) a.hseq1[idx] = h;
-                        if (s == 1 && a.cseq1) a.cseq1[idx] = c[n];
-                        if (s == 2 && a.top) a.top[idx] = a.residual ? h + sm.pin[prv][n][j] : h;
+                    prof_mark<4, true>(prof);        // seg4: cell update, tanh, h to LDS
+                    if (!(a.ablate & 8)) {
+                        float *sr = &sm.sv[m & (SRING - 1)][n][1][0];
+                        sr[4 * j + s] = act;
+                        if (s == 0) sr[192 + j] = h;
+                        if (s == 1) sr[240 + j] = c[n];
+                        if (s == 2) sr[288 + j] = a.residual ? h + sm.pin[prv][n][j] : h;
+                    }
+                    prof_mark<5, false>(prof);       // seg5: record for the saver wave
+                }
+            }
+            step_barrier<false>(prof);
+        }
+        step_barrier<false>(prof);      // save ring drained
+    }
+    prof_store(a.dbg, prof);
+}
+
+// ------------------------------------------------------------------------------------------------
+// saver wave: LDS save ring -> HBM with 16-byte stores, one 8-step chunk behind the chain
+// ------------------------------------------------------------------------------------------------
+constexpr int SPIECES = 2 * SCH * SREC4 / 64;     // 21 wave-wide pieces (1 KB) per trial and chunk
+
+struct SvDesc {
+    char *base;          // destination of (trial 0, t = 0) for this lane's 16 bytes; null = not saved
+    int row_bytes;       // bytes per time step in the destination array
+    int t0;              // time index of this lane's record in chunk 0
+    int lds_off;         // float offset inside sv[0][0] (ring slot 0, trial 0)
+};
+
+template <int NB>
+__device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int lane, const int n_steps) {
+    const int T = a.T;
+    SvDesc d[SPIECES];
+#pragma unroll
+    for (int q = 0; q < SPIECES; ++q) {
+        const int e = q * 64 + lane;                       // float4 index in the chunk image [k][layer][84]
+        const int k = e / (2 * SREC4), rem = e - k * (2 * SREC4);
+        const int layer = rem / SREC4, w = rem - layer * SREC4;
+        d[q].t0 = k - (layer == 1 ? 2 : 0);
+        d[q].lds_off = (k * NB * 2 + layer) * SREC + 4 * w;
+        float *dst = nullptr; int rb = 0;
+        if (w < 48)      { dst = layer == 0 ? a.gact0 : a.gact1; rb = H * 16; if (dst) dst += 4 * w; }
+        else if (w < 60) { dst = layer == 0 ? a.hseq0 : a.hseq1; rb = H * 4;  if (dst) dst += 4 * (w - 48); }
+        else if (w < 72) { dst = layer == 0 ? a.cseq0 : a.cseq1; rb = H * 4;  if (dst) dst += 4 * (w - 60); }
+        else             { dst = layer == 0 ? a.inseq : a.top;   rb = H * 4;  if (dst) dst += 4 * (w - 72); }
+        d[q].base = (char *)dst; d[q].row_bytes = rb;
+    }
+    Prof prof = prof_init(a.dbg);
+    auto flush = [&](const int chunk, const int b0, const int q0, const int q1) {
+#pragma unroll
+        for (int q = 0; q < SPIECES; ++q) {
+            if (q < q0 || q >= q1) continue;
+            const int t = d[q].t0 + SCH * chunk;
+            if (d[q].base && (unsigned)t < (unsigned)T) {
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const int b = b0 + n;
+                    if (b < a.B) {
+                        const float4 v = *reinterpret_cast<const float4 *>(&sm.sv[(chunk & 1) * SCH][0][0][0] + d[q].lds_off + n * 2 * SREC);
+                        *reinterpret_cast<float4 *>(d[q].base + (size_t)((unsigned)(b * T + t)) * (unsigned)d[q].row_bytes) = v;
                     }
                 }
             }
-            __syncthreads();
         }
+    };
+    const int ngrp = (a.B + NB - 1) / NB;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b0 = grp * NB;
+        step_barrier<false>(prof);
+        for (int m0 = 0; m0 < n_steps; m0 += SCH) {
+            const int done = m0 / SCH - 1;                 // chunk completed before this one started
+            // 21 pieces over the first 7 steps of the chunk, nothing in the 8th
+            if (done >= 0) flush(done, b0, 0, 3);
+            step_barrier<false>(prof);
+            if (done >= 0) flush(done, b0, 3, 6);
+            step_barrier<false>(prof);
+            if (done >= 0) flush(done, b0, 6, 9);
+            step_barrier<false>(prof);
+            if (done >= 0) flush(done, b0, 9, 12);
+            step_barrier<false>(prof);
+            if (done >= 0) flush(done, b0, 12, 15);
+            step_barrier<false>(prof);
+            if (done >= 0) flush(done, b0, 15, 18);
+            step_barrier<false>(prof);
+            if (done >= 0) flush(done, b0, 18, 21);
+            step_barrier<false>(prof);
+            step_barrier<false>(prof);
+        }
+        flush(n_steps / SCH - 1, b0, 0, SPIECES);          // last chunk (its LDS image is complete: barrier above)
+        step_barrier<false>(prof);                          // keep the ring intact until it has been read
     }
+    prof_store(a.dbg, prof);
 }
 
 template <int NB>
@@ -291,19 +393,20 @@ __global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // macro steps 0..T+1, padded to whole x chunks so that every role runs the same number of barriers
     const int n_steps = ((a.T + 2 + XCH - 1) / XCH) * XCH;
-    if (wave < 3)      l0_role<NB>(a, sm, tid, n_steps);
-    else if (wave < 6) p_role<NB>(a, sm, tid - 192, n_steps);
-    else               l1_role<NB>(a, sm, tid - 384, n_steps);
+    // wave order = issue priority among equals (older waves win arbitration): the layer-1 chain is the longest
+    // dependent sequence of a step, so it gets the lowest wave ids and the highest s_setprio
+    if (wave < 3)      { __builtin_amdgcn_s_setprio(3); l1_role<NB>(a, sm, tid, n_steps); }
+    else if (wave < 6) { __builtin_amdgcn_s_setprio(2); l0_role<NB>(a, sm, tid - 192, n_steps); }
+    else if (wave < 9) { __builtin_amdgcn_s_setprio(1); p_role<NB>(a, sm, tid - 384, n_steps); }
+    else               saver_role<NB>(a, sm, tid & 63, n_steps);
 }
 
 }  // namespace
 
 int nsd_lstm2_fwd48_launch(const Lstm2FwdArgs &a, int nb, int grid, hipStream_t st) {
-    switch (nb) {
-    case 1: hipLaunchKernelGGL((lstm2_fwd48_kernel<1>), dim3(grid), dim3(NT), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((lstm2_fwd48_kernel<2>), dim3(grid), dim3(NT), 0, st, a); break;
-    default: hipLaunchKernelGGL((lstm2_fwd48_kernel<4>), dim3(grid), dim3(NT), 0, st, a); break;
-    }
+    // one trial per workgroup: the save ring and the register budget are sized for NB = 1; larger batches loop
+    if (nb != 1) { nsd_set_error("lstm2_fwd48: NB=%d not built", nb); return NSD_E_INVALID; }
+    hipLaunchKernelGGL((lstm2_fwd48_kernel<1>), dim3(grid), dim3(NT), 0, st, a);
     NSD_CHECK_LAUNCH("lstm2_fwd48");
     return NSD_OK;
 }

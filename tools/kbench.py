@@ -67,16 +67,24 @@ def main():
         b_med, b_min = timed(lambda: L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st), args.iters)
         print(f"ablate={ab:3d}  B={B} T={T}  lstm_fwd {f_med:8.1f} us (min {f_min:.1f})   lstm_bwd {b_med:8.1f} us (min {b_min:.1f})", flush=True)
         if args.prof:
-            dbg = torch.zeros(64, dtype=torch.int64, device=dev)
-            L.nsd_debug_profile_buffer(dbg.data_ptr())
-            L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st)
-            torch.cuda.synchronize()
-            L.nsd_debug_profile_buffer(None)
-            v = dbg.cpu().numpy().reshape(32, 2)
-            roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1"] * 3 + ["dW"] * 6 + ["loader"]
-            nst = 4 * ((((T + 2) // 4 + 2) + 1) & ~1)
-            for wv, role in enumerate(roles):
-                print(f"    wave {wv:2d} {role:7s} work {v[wv,0]/nst:7.0f} cyc/step   wait {v[wv,1]/nst:7.0f} cyc/step")
+            for which in ("fwd", "bwd"):
+                dbg = torch.zeros(256, dtype=torch.int64, device=dev)
+                L.nsd_debug_profile_buffer(dbg.data_ptr())
+                if which == "fwd":
+                    L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, st)
+                    roles = ["L1"] * 3 + ["L0"] * 3 + ["P"] * 3 + ["saver"]
+                    nst = ((T + 2 + 31) // 32) * 32
+                else:
+                    L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st)
+                    roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1"] * 3 + ["dW"] * 6 + ["loader"]
+                    nst = 4 * ((((T + 2) // 4 + 2) + 1) & ~1)
+                torch.cuda.synchronize()
+                L.nsd_debug_profile_buffer(None)
+                v = dbg.cpu().numpy().reshape(32, 8)
+                print(f"  {which}: cycles per step (workgroup 0)")
+                for wv, role in enumerate(roles):
+                    seg = "  ".join(f"{v[wv, 2 + q] / nst:5.0f}" for q in range(6))
+                    print(f"    wave {wv:2d} {role:7s} work {v[wv,0]/nst:6.0f}  wait {v[wv,1]/nst:6.0f}   segments {seg}")
     os.environ["NSD_ABLATE"] = "0"
 
 
