@@ -1,0 +1,114 @@
+"""Command-line trainer standing in for the reference's missing notebook (DeepLearning/lstm_trainer.ipynb,
+.MISSING_LARGE_BLOBS:1).  Trains EEG_LSTM on recorded trials (or synthetic windows) on 1..8 MI355X and writes a
+checkpoint the reference's SimplePredictor loads unchanged (lstm_eeg_model.py:77-81).
+
+    python -m nsd_amd.train --data /path/to/EEG_data_collection --classes 3 --epochs 60 --out model.pth
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m nsd_amd.train --synthetic 8192 ...
+
+Every rank holds the whole data set in HBM (6.5 MB); each global batch is split contiguously over the ranks
+(shard_range) and the flat gradient is summed with one RCCL all-reduce per step (trainer.py).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import data as D
+from .lstm_eeg_model import EEG_LSTM
+from .trainer import Trainer, init_distributed, save_reference_checkpoint, shard_range
+
+
+def evaluate(model: EEG_LSTM, x: torch.Tensor, y: torch.Tensor, batch: int = 512) -> float:
+    was_training = model.training
+    model.eval()
+    correct = 0
+    with torch.no_grad():
+        for lo in range(0, x.shape[0], batch):
+            pred = model(x[lo:lo + batch]).argmax(-1)
+            correct += int((pred == y[lo:lo + batch].long()).sum().item())
+    model.train(was_training)
+    return correct / max(int(x.shape[0]), 1)
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--data", help="directory with <prefix>_*.csv trials (reference: EEG_data_collection/)")
+    ap.add_argument("--synthetic", type=int, default=0, help="use N synthetic windows x = 2.7*N(0,1) instead of --data")
+    ap.add_argument("--classes", type=int, default=3, choices=(3, 5))
+    ap.add_argument("--label-order", default="checkpoint", choices=("checkpoint", "code"))
+    ap.add_argument("--T", type=int, default=625)
+    ap.add_argument("--epochs", type=int, default=40)
+    ap.add_argument("--batch", type=int, default=64, help="GLOBAL batch size")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--weight-decay", type=float, default=0.0)
+    ap.add_argument("--hidden", type=int, default=48)
+    ap.add_argument("--dropout", type=float, default=0.60)
+    ap.add_argument("--val-fraction", type=float, default=0.2)
+    ap.add_argument("--normalize", action="store_true", help="per-channel z-score of each window (app.py:166-170)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default="eeg_lstm.pth")
+    ap.add_argument("--log-every", type=int, default=1)
+    args = ap.parse_args(argv)
+
+    rank, local, world = init_distributed()
+    if not torch.cuda.is_available():
+        print("train: needs an MI355X (no CPU training path)", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    if args.synthetic:
+        rs = np.random.RandomState(args.seed)
+        y_np = rs.randint(0, args.classes, args.synthetic).astype(np.int32)
+        # class-dependent mean shift on one channel so that there is something to learn
+        x_np = (2.7 * rs.standard_normal((args.synthetic, args.T, 8))).astype(np.float32)
+        x_np[np.arange(args.synthetic), :, y_np % 8] += 1.5
+        tr_idx, va_idx = D.stratified_split(y_np, args.val_fraction, args.seed)
+    else:
+        if not args.data:
+            ap.error("give --data or --synthetic")
+        lm = D.LABELS_5CLASS if args.classes == 5 else (D.LABELS_3CLASS_CHECKPOINT if args.label_order == "checkpoint" else D.LABELS_3CLASS_CODE)
+        ts = D.load_trials(args.data, lm, samples=args.T)
+        x_np, y_np = ts.x, ts.y
+        tr_idx, va_idx = D.stratified_split(y_np, args.val_fraction, args.seed)
+    x_all = torch.from_numpy(x_np).to(dev)
+    y_all = torch.from_numpy(y_np).to(dev)
+
+    torch.manual_seed(args.seed)          # same initial weights on every rank
+    model = EEG_LSTM(8, args.hidden, 2, args.classes, args.dropout, normalize=args.normalize).to(dev).train()
+    trainer = Trainer(model, lr=args.lr, weight_decay=args.weight_decay, seed=args.seed + 1)
+    tr_dev = torch.from_numpy(tr_idx).to(dev)
+    best = (-1.0, -1)
+    t0 = time.time()
+    for epoch in range(args.epochs):
+        n_seen, loss_sum = 0, 0.0
+        for idx in D.epoch_batches(len(tr_idx), args.batch, args.seed, epoch, drop_last=len(tr_idx) >= args.batch):
+            lo, hi = shard_range(len(idx), rank, world)
+            if hi <= lo:
+                continue
+            sel = tr_dev[torch.from_numpy(idx[lo:hi]).to(dev)]
+            trainer.step(x_all[sel].contiguous(), y_all[sel].contiguous())
+            n_seen += hi - lo
+        if rank == 0 and (epoch % args.log_every == 0 or epoch == args.epochs - 1):
+            acc_tr = evaluate(model, x_all[tr_dev], y_all[tr_dev])
+            acc_va = evaluate(model, x_all[va_idx], y_all[va_idx]) if len(va_idx) else float("nan")
+            if acc_va > best[0]:
+                best = (acc_va, epoch)
+                save_reference_checkpoint(model, args.out)
+            print(json.dumps({"epoch": epoch, "loss_last_batch": round(trainer.last_loss(), 5), "acc_train": round(acc_tr, 4),
+                              "acc_val": round(acc_va, 4), "elapsed_s": round(time.time() - t0, 2)}), flush=True)
+    if rank == 0:
+        if best[1] < 0:
+            save_reference_checkpoint(model, args.out)
+        print(json.dumps({"done": True, "best_val_acc": best[0], "best_epoch": best[1], "checkpoint": args.out,
+                          "world": world}), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,82 @@
+"""Data-parallel host logic on CPU with the gloo backend, world_size 2 (no GPU needed).
+
+What is exercised is the part of the N>1 path that does not depend on the kernels: contiguous
+sharding of the global batch, the 1/B_global scaling convention, ONE all-reduce(SUM) of the flat
+gradient vector, and identical Adam updates on every rank.  The per-shard gradients come from the CPU
+oracle (test infrastructure) so that "2 ranks x half batch == 1 rank x full batch" can be checked
+numerically; on the GPU box the same reducer object sums the gradients the HIP kernels produce.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nsd_amd.trainer import FlatGradAllReducer, shard_range
+from oracle import nsd_oracle as orc
+from tests.golden.make_goldens import synth_labels, synth_x
+
+D = orc.Dims()
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 256, 8192, 8193):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, golden_dir, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = np.load(os.path.join(golden_dir, "weights_3class.npz"))
+        flat = orc.flatten_state({k: w[k] for k in w.files}, D)
+        B, T = 10, 24                                   # uneven split is impossible with 2 ranks; 10 -> 5 + 5
+        x, y = synth_x(B, T, seed=11), synth_labels(B, seed=11)
+        lo, hi = shard_range(B, rank, world)
+        # every rank scales its CE gradient by 1/B_global, then ONE all-reduce(SUM) of the flat vector
+        _, g_local, _ = orc.loss_and_grads(flat, x[lo:hi], y[lo:hi], D, scale=1.0 / B)
+        g = torch.from_numpy(g_local.copy())
+        reducer = FlatGradAllReducer()
+        assert reducer.world == world
+        reducer(g)
+        # identical Adam step on every rank
+        p, m, v = flat.copy(), np.zeros_like(flat), np.zeros_like(flat)
+        orc.adam(p, g.numpy(), m, v, lr=1e-3, step=1)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), g=g.numpy(), p=p)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_allreduce_equals_single_rank_full_batch(tmp_path):
+    golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, golden_dir, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["g"], r1["g"]) and np.array_equal(r0["p"], r1["p"])     # ranks stay in lock step
+    w = np.load(os.path.join(golden_dir, "weights_3class.npz"))
+    flat = orc.flatten_state({k: w[k] for k in w.files}, D)
+    x, y = synth_x(10, 24, seed=11), synth_labels(10, seed=11)
+    _, g_full, _ = orc.loss_and_grads(flat, x, y, D)                                   # mean CE over the full batch
+    scale = np.abs(g_full).max()
+    assert np.abs(r0["g"] - g_full).max() <= 1e-5 * scale                               # 1e-5 relative
+
+
+def test_reducer_is_identity_without_a_process_group():
+    g = torch.arange(8, dtype=torch.float32)
+    r = FlatGradAllReducer()
+    assert r.world == 1 and torch.equal(r(g.clone()), g)

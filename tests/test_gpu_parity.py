@@ -400,3 +400,21 @@ def test_run_trials_replay(nsd, dev, golden, ref_state, tmp_path):
     assert np.abs(res.avg_chunk - g["x"][:4].mean(0)).max() < 1e-5
     with pytest.raises(RuntimeError, match="Producer exited unexpectedly"):
         nsd.run_trials(trials=1, serial_port="/dev/does-not-exist", model_path="unused", verbose=False, queue_timeout=0.5)
+
+
+def test_train_cli_learns_and_writes_reference_loadable_checkpoint(nsd, dev, tmp_path):
+    from nsd_amd import train as cli
+    out = str(tmp_path / "trained.pth")
+    rc = cli.main(["--synthetic", "384", "--T", "40", "--classes", "3", "--epochs", "12", "--batch", "64", "--lr", "0.01",
+                   "--dropout", "0.2", "--out", out, "--seed", "3", "--log-every", "4"])
+    assert rc == 0 and os.path.exists(out)
+    sd = torch.load(out, map_location="cpu", weights_only=True)
+    assert list(sd.keys()) == orc.param_names(D) and all(v.device.type == "cpu" for v in sd.values())
+    pred = nsd.SimplePredictor(out, sr=125)                       # loads with strict=True like the reference
+    rs = np.random.RandomState(3)
+    y = rs.randint(0, 3, 384).astype(np.int32)
+    x = (2.7 * rs.standard_normal((384, 40, 8))).astype(np.float32)
+    x[np.arange(384), :, y % 8] += 1.5
+    with torch.no_grad():
+        acc = (pred.model(_t(x, dev)).argmax(-1).cpu().numpy() == y).mean()
+    assert acc > 0.8, acc                                          # chance is 1/3
