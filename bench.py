@@ -176,7 +176,7 @@ def main():
             tf = flop[dom] * B / t_s / 1e12
             gbs = byts[dom] * B / t_s / 1e9
             out["roofline"] = {
-                "kernel": {"nsd_lstm_fwd": "lstm2_fwd_kernel<48,NB>", "nsd_lstm_bwd": "lstm2_bwd_kernel<48,NB>"}[dom],
+                "kernel": {"nsd_lstm_fwd": "lstm2_fwd48_kernel<1>", "nsd_lstm_bwd": "lstm2_bwd48_kernel<NB>"}[dom],
                 "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_us": round(us[dom], 2), "algorithmic_flop_per_launch": flop[dom] * B,
@@ -185,6 +185,16 @@ def main():
                 "note": "fp32 path: arithmetic intensity ~110 FLOP/B >> ridge (~20), so the compute roof binds; "
                         "peak = 157.3 TFLOP/s fp32 (vector == f32 MFMA rate)",
             }
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+            # gfx950, + WRITE_SIZE), collected in separate rocprofv3 passes by tools/pmc_run.sh on this workload and
+            # committed under profiles/ (bench.py cannot run the profiler on itself)
+            tpath = os.path.join(ROOT, "profiles", "r01_v5_hbm_traffic.json")
+            if os.path.exists(tpath) and B == 256 and T == 250:
+                kname = {"nsd_lstm_fwd": "lstm2_fwd48_kernel", "nsd_lstm_bwd": "lstm2_bwd48_kernel"}[dom]
+                tj = json.load(open(tpath))["kernels"].get(kname)
+                if tj:
+                    out["roofline"]["traffic"] = tj["hbm_bytes_per_launch_corrected"]
+                    out["roofline"]["traffic_source"] = "profiles/r01_v5_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
             out["kernels_us"] = {k: (round(v, 2) if v is not None else None) for k, v in us.items()}
             step_alg = alg["flop_train"] * B / (ms_per_step * 1e-3) / 1e12
             out["step_frac_of_fp32_peak"] = round(step_alg / FP32_PEAK_TFLOPS, 4)
