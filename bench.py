@@ -121,7 +121,7 @@ def main():
 
     timer = None
     if not args.no_kernel_timing:
-        timer = KernelTimer(["nsd_lstm_fwd", "nsd_lstm_bwd", "nsd_head_fwd", "nsd_head_bwd", "nsd_grad_reduce", "nsd_adam_step"])
+        timer = KernelTimer(["nsd_lstm_fwd", "nsd_lstm_bwd", "nsd_head_train", "nsd_grad_reduce", "nsd_adam_step"])
 
     def note(msg):
         if rank == 0:

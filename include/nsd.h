@@ -131,6 +131,13 @@ int nsd_head_bwd(const nsd_dims *d, const float *params, const float *rrelu_slop
                  float *workspace, void *stream);
 
 /*
+ * Train-step head: nsd_head_fwd + mean cross-entropy + nsd_head_bwd of every trial in ONE launch (sequence and head
+ * parameters staged in LDS once).  Same workspace outputs as the two separate calls; logits[B,K] is written too.
+ */
+int nsd_head_train(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
+                   const int32_t *labels, float scale, float *workspace, float *logits, void *stream);
+
+/*
  * Stacked LSTM backward (BPTT) through lstm_eeg_model.py:34 with the activations kept by nsd_lstm_fwd.
  * Partial gradients go to the slabs.  dx: NULL or [B,T,C].
  */

@@ -46,6 +46,7 @@ SYMBOLS = {
     "nsd_lstm_fwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, _vp]),
     "nsd_head_fwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     "nsd_head_bwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, _fp, _vp]),
+    "nsd_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _ip, C.c_float, _fp, _fp, _vp]),
     "nsd_lstm_bwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, _fp, _vp]),
     "nsd_grad_reduce": (C.c_int, [_dp, _fp, _fp, C.c_int32, _vp]),
     "nsd_loss_sum": (C.c_int, [_dp, _fp, _fp, _vp]),

@@ -268,6 +268,27 @@ int nsd_head_bwd(const nsd_dims *d, const float *params, const float *rrelu_slop
     return nsd_head_launch(h, true, (hipStream_t)stream);
 }
 
+int nsd_head_train(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
+                   const int32_t *labels, float scale, float *workspace, float *logits, void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!params || !workspace || !logits || !labels) { nsd_set_error("head_train: null pointer"); return NSD_E_INVALID; }
+    if (d->B == 0) return NSD_OK;
+    const nsd_ws_layout w = make_ws(d, true);
+    HeadArgs h = build_head(d, params);
+    h.top = workspace + w.top;
+    h.rrelu_slope = rrelu_slope; h.drop_head = drop_head;
+    h.alpha = workspace + w.alpha; h.pooled = workspace + w.pooled; h.fc0_pre = workspace + w.fc0_pre;
+    h.logits = logits; h.logits_in = logits; h.labels = labels; h.scale = scale;
+    h.loss = workspace + w.loss; h.dscore = workspace + w.dscore; h.dpooled = workspace + w.dpooled;
+    h.hslabs = workspace + w.hslabs; h.adpack = workspace + w.adpack;
+    const int rc = nsd_head_train_launch(h, (hipStream_t)stream);
+    if (rc != 0) return rc < 0 ? rc : NSD_OK;
+    // shape does not fit the fused kernel's LDS budget: two passes
+    const int rc2 = nsd_head_launch(h, false, (hipStream_t)stream);
+    if (rc2 != NSD_OK) return rc2;
+    return nsd_head_launch(h, true, (hipStream_t)stream);
+}
+
 int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, uint32_t flags,
                  float *workspace, float *dx, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;

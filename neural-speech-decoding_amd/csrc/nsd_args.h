@@ -50,6 +50,7 @@ int nsd_lstm2_bwd_grid(int B);
 int nsd_lstm2_bwd48_launch(const Lstm2BwdArgs &a, int nb, int grid, hipStream_t st);
 int nsd_lstm2_fwd48_launch(const Lstm2FwdArgs &a, int nb, int grid, hipStream_t st);
 int nsd_head_launch(const HeadArgs &a, bool bwd, hipStream_t st);
+int nsd_head_train_launch(const HeadArgs &a, hipStream_t st);   // 1 launched, 0 shape does not fit, <0 error
 int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t st);
 int nsd_grad_reduce_launch(const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs,
                            long ph, int n_hslabs, float *grads, int accumulate, hipStream_t st);

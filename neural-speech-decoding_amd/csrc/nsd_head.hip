@@ -297,6 +297,195 @@ __global__ __launch_bounds__(HEAD_NT) void head_bwd_kernel(HeadArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused train-step head: forward, mean-CE and backward of one trial in ONE pass of one workgroup.
+// Everything lives in LDS: the trial's [T,H] sequence (read from HBM exactly once), the head's
+// parameters (staged once per workgroup), and every intermediate.  The only HBM latencies left on
+// the kernel's critical path are those two staging loads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HEAD_NT) void head_train_kernel(HeadArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int T = a.T, H = a.H, F = a.F, K = a.K, rs = a.stage_stride;
+    float *sseq = lds;                                   // [T][rs]
+    float *hp = sseq + (size_t)T * rs;                   // [Ph] parameters, same offsets as a head slab
+    float *sc = hp + ((a.Ph + 3) & ~3L);                 // [T]
+    float *vp = sc + T;                                  // [H] pooled
+    float *vx = vp + H;                                  // [H] xhat
+    float *vln = vx + H;                                 // [H] LayerNorm output
+    float *vdp = vln + H;                                // [H] d pooled
+    float *vpre = vdp + H;                               // [F] fc.0 pre-activation
+    float *vz = vpre + F;                                // [F] activated
+    float *vdz = vz + F;                                 // [F]
+    float *vlg = vdz + F;                                // [K]
+    float *vdl = vlg + K;                                // [K]
+    float *part = vdl + K;                               // [256]
+    float *red = part + HEAD_NT;                         // [8]
+    const int tid = threadIdx.x;
+    const float *p_lnw = hp + a.o_ln_w, *p_lnb = hp + a.o_ln_b, *p_aw = hp + a.o_attn_w;
+    const float *p_w0 = hp + a.o_fc0_w, *p_b0 = hp + a.o_fc0_b, *p_w3 = hp + a.o_fc3_w, *p_b3 = hp + a.o_fc3_b;
+
+    for (long e = tid; e < a.Ph; e += HEAD_NT) hp[e] = a.ln_w[e];     // head parameters are contiguous from ln.weight on
+    __syncthreads();
+    const float ab = hp[a.o_attn_b];
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float *gseq = a.top + (size_t)b * T * H;
+        float *slab = a.hslabs + (size_t)b * a.Ph;
+        const int h4 = H >> 2;
+        for (int e = tid; e < T * h4; e += HEAD_NT) {
+            const int t = e / h4, q = e - t * h4;
+            *reinterpret_cast<float4 *>(sseq + (size_t)t * rs + 4 * q) = *reinterpret_cast<const float4 *>(gseq + (size_t)t * H + 4 * q);
+        }
+        // per-trial small inputs, fetched while the sequence lands
+        float sl_f = a.eval_slope, mk_f = 1.f;
+        if (tid < F) {
+            if (a.rrelu_slope) sl_f = a.rrelu_slope[(size_t)b * F + tid];
+            if (a.drop_head) mk_f = a.drop_head[(size_t)b * F + tid];
+        }
+        const int label = a.labels[b];
+        __syncthreads();
+        // ---- forward ----
+        float lmax = -INFINITY;
+        for (int t = tid; t < T; t += HEAD_NT) {
+            const float *row = sseq + (size_t)t * rs;
+            float s = ab;
+            for (int j = 0; j < H; j += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + j);
+                s = fmaf(v.x, p_aw[j], s); s = fmaf(v.y, p_aw[j + 1], s); s = fmaf(v.z, p_aw[j + 2], s); s = fmaf(v.w, p_aw[j + 3], s);
+            }
+            sc[t] = s;
+            lmax = fmaxf(lmax, s);
+        }
+        const float mx = block_max(lmax, red);
+        float lsum = 0.f;
+        for (int t = tid; t < T; t += HEAD_NT) { const float e = __expf(sc[t] - mx); sc[t] = e; lsum += e; }
+        const float rden = 1.0f / block_sum(lsum, red);
+        for (int t = tid; t < T; t += HEAD_NT) { const float al = sc[t] * rden; sc[t] = al; a.alpha[(size_t)b * T + t] = al; }
+        __syncthreads();
+        weighted_rowsum(sseq, rs, sc, T, H, part, vp);
+        float ls = 0.f;
+        for (int j = tid; j < H; j += HEAD_NT) { ls += vp[j]; a.pooled[(size_t)b * H + j] = vp[j]; }
+        const float mu = block_sum(ls, red) / (float)H;
+        float lv = 0.f;
+        for (int j = tid; j < H; j += HEAD_NT) { const float d = vp[j] - mu; lv += d * d; }
+        const float rstd = 1.0f / sqrtf(block_sum(lv, red) / (float)H + 1e-5f);
+        for (int j = tid; j < H; j += HEAD_NT) { const float xh = (vp[j] - mu) * rstd; vx[j] = xh; vln[j] = xh * p_lnw[j] + p_lnb[j]; }
+        __syncthreads();
+        if (tid < F) {
+            float acc = p_b0[tid];
+            const float *w = p_w0 + (size_t)tid * H;
+            for (int j = 0; j < H; ++j) acc = fmaf(w[j], vln[j], acc);
+            vpre[tid] = acc;
+            a.fc0_pre[(size_t)b * F + tid] = acc;
+            vz[tid] = (acc >= 0.f ? acc : acc * sl_f) * mk_f;
+        }
+        __syncthreads();
+        if (tid < K) {
+            float acc = p_b3[tid];
+            for (int f = 0; f < F; ++f) acc = fmaf(p_w3[(size_t)tid * F + f], vz[f], acc);
+            vlg[tid] = acc;
+            a.logits[(size_t)b * K + tid] = acc;
+        }
+        __syncthreads();
+        // ---- mean cross-entropy: dlogits = (softmax - onehot) * scale, without cancellation for the label ----
+        if (tid == 0) {
+            float m2 = vlg[0];
+            for (int k = 1; k < K; ++k) m2 = fmaxf(m2, vlg[k]);
+            float d = 0.f, rest = 0.f;
+            for (int k = 0; k < K; ++k) { const float e = expf(vlg[k] - m2); d += e; if (k != label) rest += e; }
+            for (int k = 0; k < K; ++k) vdl[k] = (k == label ? -rest / d : expf(vlg[k] - m2) / d) * a.scale;
+            a.loss[b] = -((vlg[label] - m2) - logf(d));
+        }
+        __syncthreads();
+        // ---- backward ----
+        if (tid < F) {
+            float d = 0.f;
+            for (int k = 0; k < K; ++k) d = fmaf(p_w3[(size_t)k * F + tid], vdl[k], d);
+            d *= mk_f;
+            d = vpre[tid] >= 0.f ? d : d * sl_f;
+            vdz[tid] = d;
+            slab[a.o_fc0_b + tid] = d;
+        }
+        for (int e = tid; e < K * F; e += HEAD_NT) slab[a.o_fc3_w + e] = vdl[e / F] * vz[e % F];
+        if (tid < K) slab[a.o_fc3_b + tid] = vdl[tid];
+        __syncthreads();
+        for (int e = tid; e < F * H; e += HEAD_NT) slab[a.o_fc0_w + e] = vdz[e / H] * vln[e % H];
+        float l1 = 0.f, l2 = 0.f;
+        for (int j = tid; j < H; j += HEAD_NT) {
+            float d = 0.f;
+            for (int f = 0; f < F; ++f) d = fmaf(p_w0[(size_t)f * H + j], vdz[f], d);
+            slab[a.o_ln_w + j] = d * vx[j];
+            slab[a.o_ln_b + j] = d;
+            const float dxh = d * p_lnw[j];
+            vdp[j] = dxh;
+            l1 += dxh; l2 += dxh * vx[j];
+        }
+        const float m1 = block_sum(l1, red) / (float)H;
+        const float m2 = block_sum(l2, red) / (float)H;
+        for (int j = tid; j < H; j += HEAD_NT) {
+            const float d = rstd * (vdp[j] - m1 - vx[j] * m2);
+            vdp[j] = d;
+            a.dpooled[(size_t)b * H + j] = d;
+        }
+        __syncthreads();
+        float lsd = 0.f;
+        float dal[4];                                        // up to 4 time steps per thread (T <= 1024 staged)
+        int nt = 0;
+        for (int t = tid; t < T; t += HEAD_NT, ++nt) {
+            const float *row = sseq + (size_t)t * rs;
+            float d = 0.f;
+            for (int j = 0; j < H; j += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + j);
+                d = fmaf(v.x, vdp[j], d); d = fmaf(v.y, vdp[j + 1], d); d = fmaf(v.z, vdp[j + 2], d); d = fmaf(v.w, vdp[j + 3], d);
+            }
+            if (nt < 4) dal[nt] = d;
+            lsd = fmaf(sc[t], d, lsd);
+        }
+        const float sdot = block_sum(lsd, red);
+        float lb = 0.f;
+        nt = 0;
+        for (int t = tid; t < T; t += HEAD_NT, ++nt) {
+            const float al = sc[t];
+            const float ds = al * (dal[nt < 4 ? nt : 3] - sdot);
+            a.dscore[(size_t)b * T + t] = ds;
+            *reinterpret_cast<float4 *>(a.adpack + ((size_t)b * T + t) * 4) = make_float4(al, ds, 0.f, 0.f);
+            lb += ds;
+            sc[t] = ds;                                      // alpha is no longer needed: reuse for d attn.weight
+        }
+        const float dab = block_sum(lb, red);
+        if (tid == 0) slab[a.o_attn_b] = dab;
+        weighted_rowsum(sseq, rs, sc, T, H, part, vx);
+        for (int j = tid; j < H; j += HEAD_NT) slab[a.o_attn_w + j] = vx[j];
+        __syncthreads();
+    }
+}
+
+// fused head is used when everything fits in LDS and T <= 4*256 (per-thread d-alpha registers)
+static bool head_train_fits(const HeadArgs &a, int *stride_out, size_t *lds_out) {
+    if ((a.H & 3) != 0 || a.T > 4 * HEAD_NT || a.F > HEAD_NT || a.K > HEAD_NT) return false;
+    int stride = a.H + 4;
+    if (((stride >> 2) & 1) == 0) stride += 4;
+    const size_t n = (size_t)a.T * stride + ((a.Ph + 3) & ~3L) + a.T + 4 * (size_t)a.H + 3 * (size_t)a.F + 2 * (size_t)a.K + HEAD_NT + 8;
+    if (n * sizeof(float) > 150 * 1024) return false;
+    *stride_out = stride; *lds_out = n * sizeof(float);
+    return true;
+}
+
+// returns 1 if launched, 0 if the shape does not fit (caller falls back to head_fwd + head_bwd), <0 on error
+int nsd_head_train_launch(const HeadArgs &a_in, hipStream_t st) {
+    HeadArgs a = a_in;
+    int stride; size_t lds;
+    if (!head_train_fits(a, &stride, &lds)) return 0;
+    if (a.B <= 0) return 1;
+    a.stage_stride = stride;
+    const int cap = 8 * nsd_num_cus();
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)head_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(head_train_kernel, dim3(a.B < cap ? a.B : cap), dim3(HEAD_NT), lds, st, a);
+    NSD_CHECK_LAUNCH("head_train");
+    return 1;
+}
+
 static size_t head_lds_bytes(int T, int H, int F, int K, bool bwd) {
     size_t n = (size_t)T + (bwd ? 4 : 3) * (size_t)H + (bwd ? 2 : 1) * (size_t)F + K + HEAD_NT + 8;
     return n * sizeof(float);

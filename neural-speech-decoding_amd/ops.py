@@ -221,6 +221,26 @@ def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: tor
     return grads
 
 
+def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: torch.Tensor, labels: torch.Tensor,
+                     logits: torch.Tensor, grads: torch.Tensor, *, scale: Optional[float] = None, drop_lstm=None,
+                     rrelu_slope=None, drop_head=None, residual: bool = False) -> None:
+    """The four launches of one training evaluation: lstm fwd, fused head (fwd + mean CE + bwd), lstm bwd, slab
+    reduce -> `grads` (flat, overwritten).  `logits` [B,K] is an output buffer."""
+    B, T, _ = x.shape
+    d = spec.dims(B, T)
+    flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0)
+    pp = _dev_f32(flat, "params", (spec.param_count,))
+    if labels.dtype != torch.int32 or not labels.is_cuda or not labels.is_contiguous():
+        raise NsdError("labels must be a contiguous int32 tensor on the device")
+    scale = (1.0 / max(B, 1)) if scale is None else float(scale)
+    xp, wsp, st = _dev_f32(x, "x", (B, T, spec.C)), _dev_f32(ws, "workspace"), _stream()
+    dl, sl, dh = _dev_f32(drop_lstm, "drop_lstm"), _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head")
+    _call("nsd_lstm_fwd", C.byref(d), pp, xp, dl, flags, wsp, st)
+    _call("nsd_head_train", C.byref(d), pp, sl, dh, labels.data_ptr(), scale, wsp, _dev_f32(logits, "logits", (B, spec.K)), st)
+    _call("nsd_lstm_bwd", C.byref(d), pp, xp, dl, flags, wsp, None, st)
+    _call("nsd_grad_reduce", C.byref(d), wsp, _dev_f32(grads, "grads", (spec.param_count,)), 0, st)
+
+
 def loss_sum(spec: ModelSpec, ws: torch.Tensor, B: int, T: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Sum of the per-trial CE losses written by the labels form of train_backward (device scalar)."""
     d = spec.dims(B, T)

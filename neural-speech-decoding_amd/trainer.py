@@ -73,7 +73,8 @@ class Trainer:
         key = (B, T)
         if key not in self._bufs:
             sp, dev = self.spec, self.flat.device
-            buf = {"ws": ops.new_workspace(sp, B, T, dev)}
+            buf = {"ws": ops.new_workspace(sp, B, T, dev),
+                   "logits": torch.empty((B, sp.K), dtype=torch.float32, device=dev)}
             if self.stochastic:
                 if self.model.dropout_p > 0 and sp.L > 1:
                     buf["drop_lstm"] = torch.empty((sp.L - 1, B, T, sp.H), dtype=torch.float32, device=dev)
@@ -108,10 +109,8 @@ class Trainer:
             _lib.check(L.nsd_dropout_mask(self.seed, sid + 2, self.model.head_dropout_p, dh.numel(), dh.data_ptr(), st), "dropout_mask")
         ws = buf["ws"]
         scale = 1.0 / (B * self.world)
-        logits, _ = ops.train_forward(sp, self.flat, x, ws, drop_lstm=dl, rrelu_slope=sl, drop_head=dh,
-                                      residual=self.model.residual)
-        ops.train_backward(sp, self.flat, x, ws, logits, labels=y, scale=scale, drop_lstm=dl, rrelu_slope=sl,
-                           drop_head=dh, residual=self.model.residual, grads=self.grads)
+        ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
+                             rrelu_slope=sl, drop_head=dh, residual=self.model.residual)
         self.reducer(self.grads)
         ops.adam_step(self.flat, self.grads, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay)
