@@ -69,6 +69,8 @@ typedef struct nsd_ws_layout {
     int64_t slabs;     /* [n_slabs,P_lstm] per-workgroup partial gradients of the LSTM stack */
     int64_t n_slabs;
     int64_t hslabs;    /* [B,P_head]  per-trial gradients of ln/attn/fc                  */
+    int64_t da_seq;    /* [B,T,4H]    generic path only: pre-activation gradients of the layer in flight */
+    int64_t din;       /* [2,B,T,H]   generic path only: gradient w.r.t. a layer's input (ping-pong)      */
     int64_t total;     /* floats */
 } nsd_ws_layout;
 
@@ -83,7 +85,8 @@ int     nsd_param_layout(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, 
 /* workspace needed by the train-mode calls for these dims, in BYTES; layout optional */
 int64_t nsd_workspace_bytes(const nsd_dims *d, nsd_ws_layout *layout_out);
 
-/* 1 if the fused register-resident kernels cover these dims (H in {32,48,64}, L==2, C<=8), else 0 (generic path) */
+/* 1 if the fused register-resident kernels cover these dims (H in {32,48,64}, L==2, C<=8), else 0: the shape-generic
+ * per-layer kernels (nsd_lstm_generic.hip) are used -- same results, not tuned */
 int     nsd_fast_path(const nsd_dims *d);
 
 /*

@@ -27,7 +27,7 @@ class Dims(C.Structure):
 
 class WsLayout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("hseq", "cseq", "gact", "inseq", "top", "alpha", "pooled", "fc0_pre",
-                                          "dscore", "dpooled", "loss", "adpack", "slabs", "n_slabs", "hslabs", "total")]
+                                          "dscore", "dpooled", "loss", "adpack", "slabs", "n_slabs", "hslabs", "da_seq", "din", "total")]
 
 
 # every symbol include/nsd.h declares: name -> (restype, argtypes)

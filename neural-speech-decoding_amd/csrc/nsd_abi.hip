@@ -82,12 +82,15 @@ static nsd_ws_layout make_ws(const nsd_dims *d, bool have_device) {
     w.adpack = p;  p = align4(p + B * T * 4);
     // LSTM slabs: one per backward workgroup (<= #CUs); head slabs: one per trial, stored behind them.
     // Without a device (symbol / layout checks on CPU) assume the MI355X's 256 CUs.
+    const bool fast = d->L == 2 && (d->H == 32 || d->H == 48 || d->H == 64) && d->C <= 8;
     int64_t nsl = B < 256 ? B : 256;
     if (have_device) nsl = nsd_lstm2_bwd_grid((int)B);
-    if (nsl < 1) nsl = 1;
+    if (nsl < 1 || !fast) nsl = 1;       // generic path: the weight-gradient GEMMs write one slab
     w.n_slabs = nsl;
     w.slabs = p;   p = align4(p + nsl * align4(pl.lstm_total));
     w.hslabs = p;  p = align4(p + B * (pl.total - pl.lstm_total));
+    w.da_seq = p;  if (!fast) p = align4(p + B * T * 4 * H);
+    w.din = p;     if (!fast) p = align4(p + 2 * B * T * H);
     w.total = p;
     return w;
 }
@@ -199,20 +202,27 @@ static HeadArgs build_head(const nsd_dims *d, const float *params) {
 
 int64_t nsd_infer_scratch_bytes(const nsd_dims *d) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
-    return align4((int64_t)d->B * d->T * d->H) * (int64_t)sizeof(float);
+    return (fast_path_ok(d) ? 1 : 2) * align4((int64_t)d->B * d->T * d->H) * (int64_t)sizeof(float);
 }
 
 int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t flags, float *logits, float *probs,
               void *scratch, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !x || !logits || !scratch) { nsd_set_error("infer: null pointer"); return NSD_E_INVALID; }
-    REQUIRE_FAST(d, "nsd_infer");
     if (d->B == 0) return NSD_OK;
-    nsd_ws_layout w;
-    memset(&w, 0, sizeof(w));
-    Lstm2FwdArgs a;
-    build_lstm_fwd(d, params, x, nullptr, flags, nullptr, w, false, (float *)scratch, &a);
-    int rc = nsd_lstm2_fwd_launch(a, d->H, (hipStream_t)stream);
+    int rc;
+    if (fast_path_ok(d)) {
+        nsd_ws_layout w;
+        memset(&w, 0, sizeof(w));
+        Lstm2FwdArgs a;
+        build_lstm_fwd(d, params, x, nullptr, flags, nullptr, w, false, (float *)scratch, &a);
+        rc = nsd_lstm2_fwd_launch(a, d->H, (hipStream_t)stream);
+    } else {
+        const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+        float *top = (float *)scratch;
+        rc = nsd_lstm_generic_fwd(d, pl, params, x, nullptr, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, nullptr, nullptr, nullptr, nullptr,
+                                  top, top + align4((int64_t)d->B * d->T * d->H), (hipStream_t)stream);
+    }
     if (rc != NSD_OK) return rc;
     HeadArgs h = build_head(d, params);
     h.top = (const float *)scratch;
@@ -224,9 +234,14 @@ int nsd_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const f
                  float *workspace, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !x || !workspace) { nsd_set_error("lstm_fwd: null pointer"); return NSD_E_INVALID; }
-    REQUIRE_FAST(d, "nsd_lstm_fwd");
     if (d->B == 0) return NSD_OK;
     const nsd_ws_layout w = make_ws(d, true);
+    if (!fast_path_ok(d)) {
+        const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+        return nsd_lstm_generic_fwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
+                                    workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.top, nullptr,
+                                    (hipStream_t)stream);
+    }
     Lstm2FwdArgs a;
     build_lstm_fwd(d, params, x, drop_lstm, flags, workspace, w, true, nullptr, &a);
     return nsd_lstm2_fwd_launch(a, d->H, (hipStream_t)stream);
@@ -293,12 +308,16 @@ int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const f
                  float *workspace, float *dx, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !x || !workspace) { nsd_set_error("lstm_bwd: null pointer"); return NSD_E_INVALID; }
-    REQUIRE_FAST(d, "nsd_lstm_bwd");
     if (dx) { nsd_set_error("lstm_bwd: dx (gradient w.r.t. the EEG window) is not implemented"); return NSD_E_INVALID; }
     if (d->B == 0) return NSD_OK;
     const nsd_ws_layout w = make_ws(d, true);
     const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
     const int64_t BTH = (int64_t)d->B * d->T * d->H;
+    if (!fast_path_ok(d))
+        return nsd_lstm_generic_bwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
+                                    workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.alpha,
+                                    workspace + w.dscore, workspace + w.dpooled, workspace + w.da_seq, workspace + w.din,
+                                    workspace + w.din + BTH, workspace + w.slabs, (hipStream_t)stream);
     Lstm2BwdArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x;

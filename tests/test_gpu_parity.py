@@ -206,12 +206,63 @@ def test_other_fast_path_shapes_vs_oracle(nsd, dev, H, C, K):
     _grad_close(grads, g_ref, d, rtol=3e-4)
 
 
-def test_unsupported_shape_fails_loudly(nsd, dev):
+def test_generic_path_cfg3_shape_vs_reference_goldens(nsd, dev, golden):
+    """BASELINE cfg3 shape (H=256, K=5): not covered by the fused kernels -> shape-generic per-layer kernels.
+    Goldens come from the reference class itself (tests/golden/make_goldens.py)."""
     from nsd_amd import ops
-    spec = ops.ModelSpec(H=256, K=5)       # cfg3 shape: not covered by the fused kernels yet
-    flat = torch.zeros(spec.param_count, device=dev)
-    with pytest.raises(nsd.NsdError, match="not covered"):
-        ops.infer(spec, flat, torch.zeros(2, 10, 8, device=dev))
+    from tests.golden.make_goldens import CFG3_STRIDE
+    e = golden("extensions")
+    d3 = orc.Dims(C=8, H=256, L=2, K=5)
+    spec = ops.ModelSpec(C=8, H=256, L=2, K=5)
+    assert not spec.fast_path() and spec.param_count == 807878
+    st3 = synth_params(8, 256, 2, 5, seed=11)
+    flat_np = orc.flatten_state(st3, d3)
+    x, y = synth_x(4, 250, seed=3), synth_labels(4, K=5, seed=3)
+    loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, x, y, spec=spec)
+    assert np.abs(logits - e["cfg3.logits"]).max() < LOGIT_TOL
+    got = orc.unflatten(grads, d3)
+    for k in orc.param_names(d3):
+        if "cfg3.grad." + k in e.files:
+            r = e["cfg3.grad." + k]
+            tol = 2e-6 if k == "attn.bias" else 3e-4 * max(np.abs(r).max(), 1e-6) + 1e-7
+            assert np.abs(got[k] - r).max() <= tol, k
+        else:
+            r = e["cfg3.gradsample." + k]
+            assert np.abs(got[k].ravel()[::CFG3_STRIDE] - r).max() <= 3e-4 * np.abs(r).max() + 1e-7, k
+    m = _model(nsd, dev, st3).eval()                       # module surface on the generic path
+    with torch.no_grad():
+        assert np.abs(m(_t(x, dev)).cpu().numpy() - e["cfg3.logits"]).max() < LOGIT_TOL
+
+
+@pytest.mark.parametrize("L", [1, 3])
+def test_generic_path_layer_counts_vs_reference_goldens(nsd, dev, golden, L):
+    e = golden("extensions")
+    st = synth_params(8, 48, L, 3, seed=20 + L)
+    m = _model(nsd, dev, st).eval()
+    with torch.no_grad():
+        lg = m(_t(synth_x(3, 50, seed=30 + L), dev)).cpu().numpy()
+    assert np.abs(lg - e[f"L{L}.logits"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("C,H,L,K,residual", [(8, 48, 3, 3, False), (8, 48, 3, 4, True), (64, 128, 2, 5, False),
+                                               (3, 40, 1, 2, False), (8, 96, 2, 3, True)])
+def test_generic_path_gradients_vs_oracle(nsd, dev, C, H, L, K, residual):
+    from nsd_amd import ops
+    d = orc.Dims(C=C, H=H, L=L, K=K)
+    spec = ops.ModelSpec(C=C, H=H, L=L, K=K)
+    assert not spec.fast_path()
+    flat_np = orc.flatten_state(synth_params(C, H, L, K, seed=C + H + L), d)
+    B, T = 5, 37
+    x, y = synth_x(B, T, C=C, seed=H), synth_labels(B, K=K, seed=H)
+    dl, sl, dh = counter_masks(B, T, H, 32, L=L, seed=H + L)
+    dl = dl if L > 1 else None
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, d, drop_lstm=dl, rrelu_slope=sl, drop_head=dh, residual=residual)
+    kw = dict(rrelu_slope=sl, drop_head=dh, residual=residual)
+    if dl is not None:
+        kw["drop_lstm"] = dl
+    loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, x, y, spec=spec, **kw)
+    assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
+    _grad_close(grads, g_ref, d, rtol=3e-4)
 
 
 # ---------------------------------------------------------------------------------------------------
