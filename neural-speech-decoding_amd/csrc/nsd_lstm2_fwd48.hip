@@ -32,8 +32,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ---- activations for the backward pass leave through LDS: a per-step record written by the chain lanes
 // (cheap ds_write_b32) and streamed to HBM by a dedicated wave with 16-byte stores, 8 steps at a time.
 // Per-step dword stores from the 6 chain waves (~22 VMEM instructions per step) would sit on the recurrence.
-constexpr int SREC = 336;                 // floats per (layer, step): gates[192] | h[48] | c[48] | in1 or top[48]
-constexpr int SREC4 = SREC / 4;           // 84
+constexpr int SREC = 384;                 // floats per (layer, step): gates[192] | h[48] | c[48] | in1 or top[48] | spare[48]
+constexpr int SREC4 = SREC / 4;           // 96
 constexpr int SRING = 16;                 // steps kept in LDS (two 8-step chunks)
 constexpr int SCH = 8;
 
@@ -41,12 +41,11 @@ template <int NB>
 struct FSmem {
     float xs[2][NB][XCH][8];
     float ms[2][NB][XCH][H];
-    float h0s[2][NB][H];
-    float h0m[2][NB][H];
-    float h1s[2][NB][H];
     float pb[2][NB][4 * H];      // layer-1 input projection, [gate*48 + unit]
-    float pin[2][NB][H];         // layer-1 input itself (residual top only)
-    float sv[SRING][NB][2][SREC];   // save ring, indexed by macro step % SRING
+    // save ring, indexed by macro step % SRING.  It is also the STATE of the recurrence: the next step reads h (and the
+    // masked h that feeds layer 1) straight from the previous step's record, so a chain lane issues exactly two
+    // unconditional ds_write_b32 per step (its gate, and slot s of {h, c, in1/top, spare})
+    float sv[SRING][NB][2][SREC];
 };
 
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -126,9 +125,7 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
             return make_float4(1.f, 1.f, 1.f, 1.f);
         };
         // state buffers and chunk 0
-        for (int e = r; e < 2 * NB * H; e += 192) {
-            (&sm.h0s[0][0][0])[e] = 0.f; (&sm.h0m[0][0][0])[e] = 0.f; (&sm.h1s[0][0][0])[e] = 0.f; (&sm.pin[0][0][0])[e] = 0.f;
-        }
+        for (int e = r; e < SRING * NB * 2 * SREC; e += 192) (&sm.sv[0][0][0][0])[e] = 0.f;    // h(-1) = 0 lives in slot 15
         for (int e = r; e < 2 * NB * 4 * H; e += 192) (&sm.pb[0][0][0])[e] = 0.f;
 #pragma unroll
         for (int q = 0; q < XPT; ++q) { const int e = r + 192 * q; if (e < XE) (&sm.xs[0][0][0][0])[e] = x_at(e, 0); }
@@ -154,7 +151,7 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                         const float2 xq = *reinterpret_cast<const float2 *>(&sm.xs[cb][n][k][2 * s]);
                         const f32x2 xv = {xq.x, xq.y};
                         f32x2 hv[6];
-                        load_slice(&sm.h0s[prv][n][s * KS], hv);
+                        load_slice(&sm.sv[(m - 1) & (SRING - 1)][n][0][192 + s * KS], hv);
                         f32x2 acc[4];
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -169,13 +166,9 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                         c[n] = fmaf(fg, c[n], ig * gg);
                         const float h = og * fast_tanh(c[n]);
                         const float hm = h * mk;
-                        if (s == 0) sm.h0s[cur][n][j] = h;
-                        if (s == 1) sm.h0m[cur][n][j] = hm;
                         float *sr = &sm.sv[m & (SRING - 1)][n][0][0];
                         sr[4 * j + s] = act;
-                        if (s == 0) sr[192 + j] = h;
-                        if (s == 1) sr[240 + j] = c[n];
-                        if (s == 2) sr[288 + j] = hm;
+                        sr[192 + 48 * s + j] = s == 1 ? c[n] : s == 2 ? hm : h;       // slots: h | c | masked h | spare
                     }
                 }
                 if (k == XCH - 1) {
@@ -216,7 +209,7 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     f32x2 iv[6];
-                    load_slice(&sm.h0m[(m - 1) & 1][n][s * KS], iv);
+                    load_slice(&sm.sv[(m - 1) & (SRING - 1)][n][0][288 + s * KS], iv);
                     f32x2 acc[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -225,7 +218,6 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
                         for (int q = 1; q < 6; ++q) acc[g] = pk_fma(wi[g][q], iv[q], acc[g]);
                     }
                     sm.pb[m & 1][n][s * H + j] = reduce_pick(acc, s);
-                    if (a.residual && s == 0) sm.pin[m & 1][n][j] = sm.h0m[(m - 1) & 1][n][j];
                 }
             }
             step_barrier<false>(prof);
@@ -269,7 +261,7 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                 for (int n = 0; n < NB; ++n) {
                     const float pj = sm.pb[prv][n][s * H + j];          // input projection of this step (gate s)
                     f32x2 hv[6];
-                    load_slice(&sm.h1s[prv][n][s * KS], hv);
+                    load_slice(&sm.sv[(m - 1) & (SRING - 1)][n][1][192 + s * KS], hv);
                     prof_mark<0, true>(prof);        // seg0: LDS operands arrived
                     f32x2 acc[4];
 #pragma unroll
@@ -290,14 +282,13 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                     prof_mark<3, false>(prof);       // seg3: gate activation + quad broadcast
                     c[n] = fmaf(fg, c[n], ig * gg);
                     const float h = og * ((a.ablate & 2) ? c[n] : fast_tanh(c[n]));
-                    if (s == 0) sm.h1s[cur][n][j] = h;
                     prof_mark<4, true>(prof);        // seg4: cell update, tanh, h to LDS
                     if (!(a.ablate & 8)) {
                         float *sr = &sm.sv[m & (SRING - 1)][n][1][0];
                         sr[4 * j + s] = act;
-                        if (s == 0) sr[192 + j] = h;
-                        if (s == 1) sr[240 + j] = c[n];
-                        if (s == 2) sr[288 + j] = a.residual ? h + sm.pin[prv][n][j] : h;
+                        float top = h;                                // layer-1 input of step t was written two macro steps ago
+                        if (a.residual) top += sm.sv[(m - 2) & (SRING - 1)][n][0][288 + j];
+                        sr[192 + 48 * s + j] = s == 1 ? c[n] : s == 2 ? top : h;      // slots: h | c | top | spare
                     }
                     prof_mark<5, false>(prof);       // seg5: record for the saver wave
                 }
@@ -312,7 +303,7 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
 // ------------------------------------------------------------------------------------------------
 // saver wave: LDS save ring -> HBM with 16-byte stores, one 8-step chunk behind the chain
 // ------------------------------------------------------------------------------------------------
-constexpr int SPIECES = 2 * SCH * SREC4 / 64;     // 21 wave-wide pieces (1 KB) per trial and chunk
+constexpr int SPIECES = 2 * SCH * SREC4 / 64;     // 24 wave-wide pieces (1 KB) per trial and chunk
 
 struct SvDesc {
     char *base;          // destination of (trial 0, t = 0) for this lane's 16 bytes; null = not saved
@@ -336,7 +327,7 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
         if (w < 48)      { dst = layer == 0 ? a.gact0 : a.gact1; rb = H * 16; if (dst) dst += 4 * w; }
         else if (w < 60) { dst = layer == 0 ? a.hseq0 : a.hseq1; rb = H * 4;  if (dst) dst += 4 * (w - 48); }
         else if (w < 72) { dst = layer == 0 ? a.cseq0 : a.cseq1; rb = H * 4;  if (dst) dst += 4 * (w - 60); }
-        else             { dst = layer == 0 ? a.inseq : a.top;   rb = H * 4;  if (dst) dst += 4 * (w - 72); }
+        else if (w < 84) { dst = layer == 0 ? a.inseq : a.top;   rb = H * 4;  if (dst) dst += 4 * (w - 72); }
         d[q].base = (char *)dst; d[q].row_bytes = rb;
     }
     Prof prof = prof_init(a.dbg);
@@ -363,7 +354,7 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
         step_barrier<false>(prof);
         for (int m0 = 0; m0 < n_steps; m0 += SCH) {
             const int done = m0 / SCH - 1;                 // chunk completed before this one started
-            // 21 pieces over the first 7 steps of the chunk, nothing in the 8th
+            // 24 pieces, 3 per step
             if (done >= 0) flush(done, b0, 0, 3);
             step_barrier<false>(prof);
             if (done >= 0) flush(done, b0, 3, 6);
@@ -378,6 +369,7 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
             step_barrier<false>(prof);
             if (done >= 0) flush(done, b0, 18, 21);
             step_barrier<false>(prof);
+            if (done >= 0) flush(done, b0, 21, 24);
             step_barrier<false>(prof);
         }
         flush(n_steps / SCH - 1, b0, 0, SPIECES);          // last chunk (its LDS image is complete: barrier above)
