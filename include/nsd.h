@@ -170,6 +170,19 @@ int nsd_train_masks(uint64_t seed, uint32_t base_stream, float p_lstm, float p_h
 int nsd_rrelu_noise(uint64_t seed, uint32_t stream_id, int64_t n, float *out, void *stream);
 
 /*
+ * hipGraph-friendly variants: whatever changes from step to step (the Adam step number, the random-stream ids) is read
+ * from a device-side counter instead of being a kernel argument, so that one captured graph can be replayed.
+ *   nsd_step_counter_inc  step_dev[0] += 1 (int64, device); call it first in the captured step
+ *   nsd_train_masks_dev   like nsd_train_masks with base_stream = 4 * (step_dev[0] & 0x3fffffff)
+ *   nsd_adam_step_dev     like nsd_adam_step with step = step_dev[0]
+ */
+int nsd_step_counter_inc(int64_t *step_dev, void *stream);
+int nsd_train_masks_dev(uint64_t seed, const int64_t *step_dev, float p_lstm, float p_head, int64_t n_lstm, float *drop_lstm,
+                        int64_t n_head, float *rrelu_slope, float *drop_head, void *stream);
+int nsd_adam_step_dev(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float grad_scale, const int64_t *step_dev, void *stream);
+
+/*
  * Diagnostics: when set to a device buffer of >= 64 int64, the LSTM backward kernel's workgroup 0 stores per wave
  * {cycles working, cycles waiting at the step barrier}.  NULL (default) switches the stamps off.
  */

@@ -370,8 +370,30 @@ int nsd_train_masks(uint64_t seed, uint32_t base_stream, float p_lstm, float p_h
         nsd_set_error("train_masks: null pointer or negative size");
         return NSD_E_INVALID;
     }
-    return nsd_train_masks_launch(seed, base_stream, p_lstm, p_head, n_lstm, drop_lstm, n_head, rrelu_slope, drop_head,
+    return nsd_train_masks_launch(seed, base_stream, nullptr, p_lstm, p_head, n_lstm, drop_lstm, n_head, rrelu_slope, drop_head,
                                   (hipStream_t)stream);
+}
+
+int nsd_train_masks_dev(uint64_t seed, const int64_t *step_dev, float p_lstm, float p_head, int64_t n_lstm, float *drop_lstm,
+                        int64_t n_head, float *rrelu_slope, float *drop_head, void *stream) {
+    if (!step_dev || n_lstm < 0 || n_head < 0 || (n_lstm > 0 && !drop_lstm) || (n_head > 0 && (!rrelu_slope || !drop_head))) {
+        nsd_set_error("train_masks_dev: null pointer or negative size");
+        return NSD_E_INVALID;
+    }
+    return nsd_train_masks_launch(seed, 0, (const long long *)step_dev, p_lstm, p_head, n_lstm, drop_lstm, n_head, rrelu_slope,
+                                  drop_head, (hipStream_t)stream);
+}
+
+int nsd_adam_step_dev(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float grad_scale, const int64_t *step_dev, void *stream) {
+    if (n < 0 || !p || !g || !m || !v || !step_dev) { nsd_set_error("adam_dev: null pointer or n<0"); return NSD_E_INVALID; }
+    return nsd_adam_dev_launch(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, (const long long *)step_dev,
+                               (hipStream_t)stream);
+}
+
+int nsd_step_counter_inc(int64_t *step_dev, void *stream) {
+    if (!step_dev) { nsd_set_error("step_counter_inc: null pointer"); return NSD_E_INVALID; }
+    return nsd_step_inc_launch((long long *)step_dev, (hipStream_t)stream);
 }
 
 int nsd_debug_profile_buffer(void *p) { g_dbg = (long long *)p; return NSD_OK; }

@@ -64,8 +64,11 @@ int nsd_grad_reduce_launch(const float *slabs, long slab_stride, int n_slabs, lo
 int nsd_adam_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
                     float wd, float gscale, int step, hipStream_t st);
 int nsd_dropout_mask_launch(uint64_t seed, uint32_t stream_id, float p, long n, float *out, hipStream_t st);
-int nsd_train_masks_launch(uint64_t seed, uint32_t base, float p_lstm, float p_head, long n_lstm, float *drop_lstm,
-                           long n_head, float *rrelu, float *drop_head, hipStream_t st);
+int nsd_train_masks_launch(uint64_t seed, uint32_t base, const long long *step_dev, float p_lstm, float p_head, long n_lstm,
+                           float *drop_lstm, long n_head, float *rrelu, float *drop_head, hipStream_t st);
+int nsd_adam_dev_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
+                        float wd, float gscale, const long long *step_dev, hipStream_t st);
+int nsd_step_inc_launch(long long *step_dev, hipStream_t st);
 int nsd_rrelu_noise_launch(uint64_t seed, uint32_t stream_id, long n, float *out, hipStream_t st);
 int nsd_loss_sum_launch(const float *loss, int B, float *out, hipStream_t st);
 

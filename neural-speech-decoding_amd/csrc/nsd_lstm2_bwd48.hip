@@ -430,7 +430,9 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // every role runs the same number of barriers: 4 per 4-step group, groups cover macro steps 0..T+2
     // plus one more group so that the dW waves can drain the last one
-    const int n_groups = (((a.T + 2) / 4 + 2) + 1) & ~1;    // even: the loader walks whole 8-step chunks
+    // groups of 4 macro steps: the last chain step is T+1 and the x1 waves need T+2 (group (T+2)/4); one more group lets the
+    // dW waves drain the last one; rounded up to even because the loader walks whole 8-step chunks
+    const int n_groups = (((a.T + 2) / 4 + 1) + 1 + 1) & ~1;
     const int n_steps = 4 * n_groups;
     // issue priority follows the critical path: the two recurrences first, then the hand-off to layer 0
     if (wave < 3)       { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 1, tid, n_steps); }

@@ -107,6 +107,38 @@ __global__ void adam_kernel(long n, float *p, const float *g, float *m, float *v
     }
 }
 
+// Device-side step counter variants (hipGraph replay: nothing that changes from step to step may be a kernel
+// argument).  step_dev[0] is the 1-based step number; bias corrections are formed in double like on the host.
+__global__ void adam_dev_kernel(long n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
+                                float eps, float wd, float gscale, const long long *step_dev) {
+    const double st = (double)step_dev[0];
+    const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
+    const float lr_over_bc1 = (float)((double)lr / bc1), rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = fmaf(wd, pi, g[i] * gscale);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        p[i] = pi - lr_over_bc1 * (mi / denom);
+    }
+}
+int nsd_adam_dev_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
+                        float wd, float gscale, const long long *step_dev, hipStream_t st) {
+    if (n <= 0) return NSD_OK;
+    long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, p, g, m, v, lr, b1, b2, eps, wd, gscale, step_dev);
+    NSD_CHECK_LAUNCH("adam_dev");
+    return NSD_OK;
+}
+__global__ void step_inc_kernel(long long *step_dev) { if (threadIdx.x == 0 && blockIdx.x == 0) step_dev[0] += 1; }
+int nsd_step_inc_launch(long long *step_dev, hipStream_t st) {
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, st, step_dev);
+    NSD_CHECK_LAUNCH("step_inc");
+    return NSD_OK;
+}
+
 int nsd_adam_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
                     float wd, float gscale, int step, hipStream_t st) {
     if (n <= 0) return NSD_OK;
@@ -136,9 +168,11 @@ __global__ void rrelu_noise_kernel(uint64_t seed, uint32_t stream_id, long n, fl
 
 // all three train-mode streams of one step in ONE launch (stream ids base, base+1, base+2: bit-identical to
 // the separate calls): LSTM inter-layer dropout [n_lstm], RReLU slopes [n_head], head dropout [n_head]
-__global__ void train_masks_kernel(uint64_t seed, uint32_t base, uint32_t thr_lstm, float keep_lstm, uint32_t thr_head,
+__global__ void train_masks_kernel(uint64_t seed, uint32_t base_arg, const long long *step_dev, uint32_t thr_lstm, float keep_lstm, uint32_t thr_head,
                                    float keep_head, long n_lstm, float *drop_lstm, long n_head, float *rrelu, float *drop_head) {
     const float lower = 0.125f, upper = (float)(1.0 / 3.0);
+    // stream ids of this step: explicit, or 4 * (device step counter) as nsd_amd.trainer numbers them
+    const uint32_t base = step_dev ? (uint32_t)(step_dev[0] & 0x3FFFFFFF) * 4u : base_arg;
     const long total = n_lstm + 2 * n_head;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         if (i < n_lstm) {
@@ -158,13 +192,13 @@ static uint32_t drop_threshold(float p) {
     if (t > 4294967295.0) t = 4294967295.0;
     return (uint32_t)t;
 }
-int nsd_train_masks_launch(uint64_t seed, uint32_t base, float p_lstm, float p_head, long n_lstm, float *drop_lstm,
-                           long n_head, float *rrelu, float *drop_head, hipStream_t st) {
+int nsd_train_masks_launch(uint64_t seed, uint32_t base, const long long *step_dev, float p_lstm, float p_head, long n_lstm,
+                           float *drop_lstm, long n_head, float *rrelu, float *drop_head, hipStream_t st) {
     if (!(p_lstm >= 0.f && p_lstm < 1.f) || !(p_head >= 0.f && p_head < 1.f)) { nsd_set_error("train_masks: p out of [0,1)"); return NSD_E_INVALID; }
     const long total = n_lstm + 2 * n_head;
     if (total <= 0) return NSD_OK;
     long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(train_masks_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, base, drop_threshold(p_lstm),
+    hipLaunchKernelGGL(train_masks_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, base, step_dev, drop_threshold(p_lstm),
                        1.0f / (1.0f - p_lstm), drop_threshold(p_head), 1.0f / (1.0f - p_head), n_lstm, drop_lstm, n_head, rrelu, drop_head);
     NSD_CHECK_LAUNCH("train_masks");
     return NSD_OK;

@@ -67,6 +67,9 @@ class Trainer:
         self._bufs = {}
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
         self._last_B = 0
+        # hipGraph replay of the step (static-input path): everything that varies per step lives on the device
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.flat.device)
+        self._graphs = {}
 
     # buffers that depend on the batch shape are created once and reused every step
     def _buffers(self, B: int, T: int):
@@ -114,6 +117,78 @@ class Trainer:
         self.reducer(self.grads)
         ops.adam_step(self.flat, self.grads, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay)
+        self._last_B, self._last_T = B, T
+
+    # ---- hipGraph path ------------------------------------------------------------------------------------
+    def static_inputs(self, B: int, T: int):
+        """(x [B,T,C] fp32, y [B] int32) device buffers owned by the trainer.  Fill them in place (copy_, index_select
+        with out=...) and call step_static(B, T): the whole step is then ONE hipGraph replay per segment instead of
+        seven launches, with no host-side argument that changes from step to step."""
+        buf = self._buffers(B, T)
+        if "x" not in buf:
+            dev = self.flat.device
+            buf["x"] = torch.zeros((B, T, self.spec.C), dtype=torch.float32, device=dev)
+            buf["y"] = torch.zeros((B,), dtype=torch.int32, device=dev)
+        return buf["x"], buf["y"]
+
+    def _issue_segment_a(self, B: int, T: int) -> None:
+        """step counter, random streams, lstm fwd, fused head, lstm bwd, slab reduce -> self.grads"""
+        from . import _lib
+        L = _lib.lib()
+        buf = self._buffers(B, T)
+        st = torch.cuda.current_stream().cuda_stream
+        dl = buf.get("drop_lstm"); sl = buf.get("rrelu"); dh = buf.get("drop_head")
+        _lib.check(L.nsd_step_counter_inc(self._step_dev.data_ptr(), st), "step_counter_inc")
+        if dl is not None and sl is not None and dh is not None:
+            _lib.check(L.nsd_train_masks_dev(self.seed, self._step_dev.data_ptr(), self.model.dropout_p, self.model.head_dropout_p,
+                                             dl.numel(), dl.data_ptr(), sl.numel(), sl.data_ptr(), dh.data_ptr(), st), "train_masks_dev")
+        elif self.stochastic:
+            raise ops.NsdError("graph step needs all three random streams (dropout > 0, num_layers > 1) or stochastic=False")
+        ops.train_step_grads(self.spec, self.flat, buf["x"], buf["ws"], buf["y"], buf["logits"], self.grads,
+                             scale=1.0 / (B * self.world), drop_lstm=dl, rrelu_slope=sl, drop_head=dh, residual=self.model.residual)
+
+    def _issue_segment_b(self) -> None:
+        from . import _lib
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().nsd_adam_step_dev(self.flat.numel(), self.flat.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
+                                                self.v.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                                self.weight_decay, 1.0, self._step_dev.data_ptr(), st), "adam_step_dev")
+
+    def step_static(self, B: int, T: int) -> None:
+        """One optimisation step on the trainer's static input buffers, replayed from captured hipGraphs.
+        world == 1: one graph.  world > 1: graph A, the eager RCCL all-reduce of the flat gradient, graph B (Adam)."""
+        key = (B, T)
+        if key not in self._graphs:
+            self.static_inputs(B, T)
+            self._step_dev.fill_(self.step_count)
+            # warm up eagerly on a side stream (lazy module loading, hipFuncSetAttribute), then capture
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                snap = (self.flat.clone(), self.m.clone(), self.v.clone())
+                self._issue_segment_a(B, T)
+                self._issue_segment_b()
+                self.flat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2])     # the warm-up step does not count
+                self._step_dev.fill_(self.step_count)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._issue_segment_a(B, T)
+                if self.world == 1:
+                    self._issue_segment_b()
+            gb = None
+            if self.world > 1:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb):
+                    self._issue_segment_b()
+            self._graphs = {key: (ga, gb)}
+        ga, gb = self._graphs[key]
+        self.step_count += 1
+        ga.replay()
+        if gb is not None:
+            self.reducer(self.grads)
+            gb.replay()
         self._last_B, self._last_T = B, T
 
     def last_loss(self) -> float:

@@ -357,6 +357,24 @@ def test_trainer_step_matches_oracle_with_its_own_streams(nsd, dev, ref_state):
     assert np.abs(m.flat_parameters().cpu().numpy() - p).max() < 2e-6
 
 
+def test_graph_replay_step_equals_eager_step(nsd, dev, ref_state):
+    """Trainer.step_static (captured hipGraphs, device-side step counter) == Trainer.step (eager launches)."""
+    from nsd_amd.trainer import Trainer
+    B, T = 16, 30
+    x, y = _t(synth_x(B, T, seed=8), dev), _t(synth_labels(B, seed=8), dev)
+    ma, mb = _model(nsd, dev, ref_state).train(), _model(nsd, dev, ref_state).train()
+    ta, tb = Trainer(ma, lr=1e-3, seed=5), Trainer(mb, lr=1e-3, seed=5)
+    xs, ys = tb.static_inputs(B, T)
+    xs.copy_(x); ys.copy_(y)
+    for _ in range(3):
+        ta.step(x, y)
+        tb.step_static(B, T)
+    assert tb.step_count == 3 and int(tb._step_dev.item()) == 3
+    assert torch.equal(ta.grads, tb.grads)                                   # same streams, same kernels: bit-identical gradients
+    assert (ma.flat_parameters() - mb.flat_parameters()).abs().max().item() < 1e-6   # device pow() vs host pow() in Adam
+    assert abs(ta.last_loss() - tb.last_loss()) < 1e-6
+
+
 def test_adam_matches_oracle_and_torch(nsd, dev):
     from nsd_amd import ops
     rs = np.random.RandomState(0)
