@@ -216,6 +216,17 @@ int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t f
         memset(&w, 0, sizeof(w));
         Lstm2FwdArgs a;
         build_lstm_fwd(d, params, x, nullptr, flags, nullptr, w, false, (float *)scratch, &a);
+        if (d->H == 48 && d->F <= 64 && d->K <= 64) {
+            // single launch: attention pooling (online softmax), LayerNorm, dense head and class softmax run in the
+            // LSTM kernel's tail wave; nothing but x, the parameters and the [B,K] outputs touches HBM
+            const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+            a.top = nullptr;
+            a.attn_w = params + pl.attn_w; a.attn_b = params + pl.attn_b; a.ln_w = params + pl.ln_w; a.ln_b = params + pl.ln_b;
+            a.fc0_w = params + pl.fc0_w; a.fc0_b = params + pl.fc0_b; a.fc3_w = params + pl.fc3_w; a.fc3_b = params + pl.fc3_b;
+            a.eval_slope = (float)((0.125 + 1.0 / 3.0) / 2.0);
+            a.logits_out = logits; a.probs_out = probs; a.K = d->K; a.F = d->F;
+            return nsd_lstm2_fwd_launch(a, d->H, (hipStream_t)stream);
+        }
         rc = nsd_lstm2_fwd_launch(a, d->H, (hipStream_t)stream);
     } else {
         const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);

@@ -8,6 +8,12 @@ struct Lstm2FwdArgs {
     const float *mask;
     float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
     long long *dbg;                          // diagnostic build only (see nsd_prof.h)
+    // fused inference tail (lstm2_fwd48 only; logits_out != null): attention pooling over time as an online softmax,
+    // LayerNorm, dense head and class softmax inside the LSTM kernel -- the [B,T,H] sequence never leaves the chip
+    const float *attn_w, *attn_b, *ln_w, *ln_b, *fc0_w, *fc0_b, *fc3_w, *fc3_b;
+    float *logits_out, *probs_out;
+    float eval_slope;
+    int K, F;
     int B, T, C, residual;
     int ablate;                              // timing experiments only (env NSD_ABLATE); 0 in production
 };

@@ -46,6 +46,8 @@ struct FSmem {
     // masked h that feeds layer 1) straight from the previous step's record, so a chain lane issues exactly two
     // unconditional ds_write_b32 per step (its gate, and slot s of {h, c, in1/top, spare})
     float sv[SRING][NB][2][SREC];
+    float pk[NB][8];             // inference tail: softmax numerators of the chunk being pooled
+    float vec[NB][64];           // inference tail: LayerNorm output / activated fc.0 output
 };
 
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -378,6 +380,95 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
     prof_store(a.dbg, prof);
 }
 
+// ------------------------------------------------------------------------------------------------
+// inference tail (wave 9 when logits_out != null): lstm_eeg_model.py:35-39 and the class softmax of :97 fused into
+// the LSTM kernel.  Attention pooling over time runs as an ONLINE softmax over the layer-1 records of the save ring,
+// one 8-step chunk behind the chain (running max m, denominator, weighted sum in lane j); the [T,H] sequence is
+// never written to HBM, so the kernel's traffic is the algorithmic 8 000 B in + K*4 B out per trial.
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void pool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int lane, const int n_steps) {
+    static_assert(NB == 1, "inference tail is built for one trial per workgroup");
+    const int T = a.T, K = a.K, F = a.F;
+    const int kq = lane >> 3, part = lane & 7;            // scores: 8 steps x 8 parts of 6 units
+    float awp[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) awp[u] = a.attn_w[6 * part + u];
+    const float ab = a.attn_b[0];
+    Prof prof = prof_init(a.dbg);
+    const int ngrp = (a.B + NB - 1) / NB;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b = grp;
+        float mrun = -INFINITY, den = 0.f, pooled = 0.f;     // pooled: lane j < 48
+        auto pool_chunk = [&](const int chunk) {
+            const int t = SCH * chunk + kq - 2;               // layer-1 time index of ring slot kq of this chunk
+            const float *rec = &sm.sv[(chunk & 1) * SCH + kq][0][1][288];
+            float sc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) sc = fmaf(awp[u], rec[6 * part + u], sc);
+            sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 4, 64);
+            const bool ok = (unsigned)t < (unsigned)T;
+            sc = ok ? sc + ab : -INFINITY;
+            float cm = sc;
+            cm = fmaxf(cm, __shfl_xor(cm, 8, 64)); cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            const float mnew = fmaxf(mrun, cm);
+            if (mnew == -INFINITY) return;                    // nothing valid yet (wave-uniform)
+            const float pkv = ok ? __expf(sc - mnew) : 0.f;
+            const float scale = __expf(mrun - mnew);          // exp(-inf) = 0 on the first valid chunk
+            float ps = pkv;
+            ps += __shfl_xor(ps, 8, 64); ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
+            den = fmaf(den, scale, ps);
+            mrun = mnew;
+            if (part == 0) sm.pk[0][kq] = pkv;
+            float acc = pooled * scale;                       // same wave: the LDS queue is in order, the reads see pk
+            if (lane < H) {
+#pragma unroll
+                for (int k = 0; k < SCH; ++k) acc = fmaf(sm.pk[0][k], sm.sv[(chunk & 1) * SCH + k][0][1][288 + lane], acc);
+            }
+            pooled = acc;
+        };
+        step_barrier<false>(prof);
+        for (int m0 = 0; m0 < n_steps; m0 += SCH) {
+            const int done = m0 / SCH - 1;
+            if (done >= 0) pool_chunk(done);
+#pragma unroll
+            for (int k = 0; k < SCH; ++k) step_barrier<false>(prof);
+        }
+        pool_chunk(n_steps / SCH - 1);
+        // ---- LayerNorm (biased variance, eps in the sqrt), fc.0 -> RReLU(eval) -> fc.3, softmax over classes ----
+        const float p = lane < H ? pooled / den : 0.f;
+        const float mu = wave_sum(p) * (1.0f / H);
+        const float dlt = lane < H ? p - mu : 0.f;
+        const float rstd = 1.0f / sqrtf(wave_sum(dlt * dlt) * (1.0f / H) + 1e-5f);
+        if (lane < H) sm.vec[0][lane] = dlt * rstd * a.ln_w[lane] + a.ln_b[lane];
+        float z = 0.f;
+        if (lane < F) {
+            float acc = a.fc0_b[lane];
+            const float *w = a.fc0_w + (size_t)lane * H;
+#pragma unroll 8
+            for (int j = 0; j < H; ++j) acc = fmaf(w[j], sm.vec[0][j], acc);
+            z = acc >= 0.f ? acc : acc * a.eval_slope;
+        }
+        if (lane < F) sm.vec[0][lane] = z;                    // all reads of the LayerNorm vector are done (same wave, in order)
+        float lg = -INFINITY;
+        if (lane < K) {
+            float acc = a.fc3_b[lane];
+            const float *w = a.fc3_w + (size_t)lane * F;
+            for (int f = 0; f < F; ++f) acc = fmaf(w[f], sm.vec[0][f], acc);
+            lg = acc;
+            if (b < a.B) a.logits_out[(size_t)b * K + lane] = acc;
+        }
+        if (a.probs_out) {
+            const float mx = wave_max(lg);
+            const float e = lane < K ? __expf(lg - mx) : 0.f;
+            const float d = wave_sum(e);
+            if (lane < K && b < a.B) a.probs_out[(size_t)b * K + lane] = e / d;
+        }
+        step_barrier<false>(prof);
+    }
+    prof_store(a.dbg, prof);
+}
+
 template <int NB>
 __global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
     __shared__ __align__(16) FSmem<NB> sm;
@@ -390,6 +481,7 @@ __global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
     if (wave < 3)      { __builtin_amdgcn_s_setprio(3); l1_role<NB>(a, sm, tid, n_steps); }
     else if (wave < 6) { __builtin_amdgcn_s_setprio(2); l0_role<NB>(a, sm, tid - 192, n_steps); }
     else if (wave < 9) { __builtin_amdgcn_s_setprio(1); p_role<NB>(a, sm, tid - 384, n_steps); }
+    else if (a.logits_out) pool_role<NB>(a, sm, tid & 63, n_steps);
     else               saver_role<NB>(a, sm, tid & 63, n_steps);
 }
 
