@@ -125,7 +125,7 @@ def main():
 
     timer = None
     if not args.no_kernel_timing:
-        timer = KernelTimer(["nsd_lstm_fwd", "nsd_lstm_bwd", "nsd_head_train", "nsd_grad_reduce", "nsd_adam_step"])
+        timer = KernelTimer(["nsd_lstm_fwd", "nsd_lstm_bwd", "nsd_head_train", "nsd_grad_reduce", "nsd_grad_reduce_adam", "nsd_adam_step", "nsd_train_masks"])
 
     def note(msg):
         if rank == 0:

@@ -150,6 +150,12 @@ int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const f
 /* grads[P] (=|+=) sum over slabs.  accumulate: 0 overwrite, 1 add to existing. */
 int nsd_grad_reduce(const nsd_dims *d, const float *workspace, float *grads, int32_t accumulate, void *stream);
 
+/* Single-rank train step tail: nsd_grad_reduce (grads[] is still written) followed, in the same launch, by
+ * nsd_adam_step on the reduced gradient -- same arithmetic in the same order as the two separate calls.  With more
+ * than one rank the all-reduce sits between the two and the separate entry points are used. */
+int nsd_grad_reduce_adam(const nsd_dims *d, const float *workspace, float *grads, float *p, float *m, float *v, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t step, void *stream);
+
 /* sum of the per-trial losses written by nsd_head_bwd -> out[0] (device) */
 int nsd_loss_sum(const nsd_dims *d, const float *workspace, float *out, void *stream);
 

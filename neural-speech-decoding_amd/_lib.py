@@ -49,6 +49,7 @@ SYMBOLS = {
     "nsd_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _ip, C.c_float, _fp, _fp, _vp]),
     "nsd_lstm_bwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, _fp, _vp]),
     "nsd_grad_reduce": (C.c_int, [_dp, _fp, _fp, C.c_int32, _vp]),
+    "nsd_grad_reduce_adam": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [C.c_int32, _vp]),
     "nsd_loss_sum": (C.c_int, [_dp, _fp, _fp, _vp]),
     "nsd_adam_step": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [C.c_int32, _vp]),
     "nsd_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint32, C.c_float, C.c_int64, _fp, _vp]),
@@ -82,7 +83,10 @@ def lib() -> C.CDLL:
             raise NsdError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
         L = C.CDLL(LIB_PATH)
+        diag = os.path.basename(LIB_PATH) != "libnsd_hip.so"     # NSD_LIB: profiling / A-B builds, possibly of an older ABI
         for name, (res, args) in SYMBOLS.items():
+            if diag and not hasattr(L, name):
+                continue
             fn = getattr(L, name)        # AttributeError if the ABI and the header ever diverge
             fn.restype, fn.argtypes = res, args
         _lib = L

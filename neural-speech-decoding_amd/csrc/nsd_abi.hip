@@ -362,6 +362,17 @@ int nsd_grad_reduce(const nsd_dims *d, const float *workspace, float *grads, int
                                   (hipStream_t)stream);
 }
 
+int nsd_grad_reduce_adam(const nsd_dims *d, const float *workspace, float *grads, float *p, float *m, float *v, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t step, void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!workspace || !grads || !p || !m || !v) { nsd_set_error("grad_reduce_adam: null pointer"); return NSD_E_INVALID; }
+    const nsd_ws_layout w = make_ws(d, true);
+    const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+    return nsd_grad_reduce_adam_launch(workspace + w.slabs, align4(pl.lstm_total), d->B > 0 ? (int)w.n_slabs : 0, pl.lstm_total,
+                                       workspace + w.hslabs, pl.total - pl.lstm_total, d->B, grads, p, m, v, lr, beta1, beta2,
+                                       eps, weight_decay, grad_scale, step, (hipStream_t)stream);
+}
+
 int nsd_loss_sum(const nsd_dims *d, const float *workspace, float *out, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!workspace || !out) { nsd_set_error("loss_sum: null pointer"); return NSD_E_INVALID; }

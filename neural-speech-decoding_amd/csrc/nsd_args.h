@@ -67,6 +67,9 @@ int nsd_head_train_launch(const HeadArgs &a, hipStream_t st);   // 1 launched, 0
 int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t st);
 int nsd_grad_reduce_launch(const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs,
                            long ph, int n_hslabs, float *grads, int accumulate, hipStream_t st);
+int nsd_grad_reduce_adam_launch(const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs,
+                                long ph, int n_hslabs, float *grads, float *p, float *m, float *v, float lr, float b1,
+                                float b2, float eps, float wd, float gscale, int step, hipStream_t st);
 int nsd_adam_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
                     float wd, float gscale, int step, hipStream_t st);
 int nsd_dropout_mask_launch(uint64_t seed, uint32_t stream_id, float p, long n, float *out, hipStream_t st);

@@ -1,7 +1,7 @@
 // nsd_lstm2_bwd48.hip -- BPTT of the two-layer H=48 LSTM, role-split workgroup (gfx950).
 //
 // Replaces autograd through self.lstm(x) (Neuro-Alpha-App/Utilities/lstm_eeg_model.py:34) for the reference
-// model shape (H=48, L=2, C<=8).  One 960-thread workgroup (15 waves) owns NB trials and walks time
+// model shape (H=48, L=2, C<=8).  One 1024-thread workgroup (16 waves) owns NB trials and walks time
 // backwards with ONE barrier per step; the waves have different jobs so that only the true recurrence
 // is on the critical path and every register array stays small:
 //
@@ -10,6 +10,7 @@
 //                          backward for step t -> da1[t] into an LDS ring.
 //   waves 3-5   "chain 0"  the same for layer 0, two steps behind layer 1.
 //   waves 6-8   "x1"       d_in1[t] = W_ih1^T da1[t] (the gradient handed to layer 0) and dW_ih0 (K=8, VALU).
+//   wave  15    "loader" LDS-DMA stream of the saved activations, one 8-step chunk ahead (see below).
 //   waves 9-14  "dW"       weight gradients dW_hh1, dW_ih1, dW_hh0 = sum_t da[t] (x) operand[t] as
 //                          v_mfma_f32_16x16x4_f32 with K = 4 time steps per instruction: A = da tiles from
 //                          the LDS ring, B = h / input rows straight from the activations saved in HBM
@@ -49,6 +50,25 @@ struct Smem {
 // ------------------------------------------------------------------------------------------------
 // chain waves: layer = 1 (t = T-1-m) or 0 (t = T+1-m)
 // ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// W^T-slice mat-vec of a chain / x1 lane: 48 operands from LDS (12 x 16 B) against 24 weight pairs, FOUR independent
+// accumulator pairs (a single chain of 24 dependent v_pk_fma_f32 costs ~2x their issue time), then the quad sum.
+__device__ __forceinline__ float slice_dot(const float *dv, const f32x2 (&wp)[24]) {
+    f32x2 acc[4];
+#pragma unroll
+    for (int q = 0; q < H / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(dv + 4 * q);
+        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+        const int a0 = (2 * q) & 3, a1 = (2 * q + 1) & 3;
+        acc[a0] = q < 2 ? wp[2 * q] * lo : pk_fma(wp[2 * q], lo, acc[a0]);
+        acc[a1] = q < 2 ? wp[2 * q + 1] * hi : pk_fma(wp[2 * q + 1], hi, acc[a1]);
+    }
+    const f32x2 r = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    return quad_sum(r.x + r.y);
+}
+
 template <int NB>
 __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int layer, const int r,
                                            const int n_steps) {
@@ -56,9 +76,12 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
     const int T = a.T, B = a.B;
     const float *cseq = layer == 0 ? a.cseq0 : a.cseq1;
     const float *whh = layer == 0 ? a.w_hh0 : a.w_hh1;
-    float whT[H];
+    f32x2 wp[H / 2];
 #pragma unroll
-    for (int q = 0; q < H; ++q) whT[q] = whh[(size_t)(s * H + q) * H + j];
+    for (int q = 0; q < H / 2; ++q) {
+        wp[q].x = whh[(size_t)(s * H + 2 * q) * H + j];
+        wp[q].y = whh[(size_t)(s * H + 2 * q + 1) * H + j];
+    }
     const float awj = a.attn_w[j];
     float db = 0.f;
     Prof prof = prof_init(a.dbg);
@@ -74,57 +97,53 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
             dpj[n] = (layer == 1 && b < B) ? a.dpooled[(size_t)b * H + j] : 0.f;
             ct[n] = (b < B) ? cseq[((size_t)b * T + (T - 1)) * H + j] : 0.f;   // c[T-1] of the first step
         }
-        step_barrier<false>(prof);      // chunk 0 of the stage has been written by the x1 waves
+        step_barrier<false>(prof);      // chunk 0 of the stage has been written by the loader wave
 
-        for (int m = 0; m < n_steps; ++m) {
-            const int t = layer == 1 ? (T - 1 - m) : (T + 1 - m);
-            const bool active = (t >= 0 && t < T);
-            const bool prev_active = (t + 1 >= 0 && t + 1 < T);
-            // this step's record from the LDS stage (issued first, consumed after the mat-vec)
-            float4 gcur[NB]; float cprev[NB], aux0[NB], aux1[NB];
+        // unrolled by the ring length (== stage chunk): every LDS offset of a step is an immediate
+        for (int m0 = 0; m0 < n_steps; m0 += CHUNK) {
+            const int sb = (m0 / CHUNK) & 1;
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const float *rec = &sm.stage[(m / CHUNK) & 1][n][layer][m & (CHUNK - 1)][0];
-                gcur[n] = *reinterpret_cast<const float4 *>(rec + 4 * j);
-                cprev[n] = t > 0 ? rec[192 + j] : 0.f;
-                aux0[n] = layer == 1 ? rec[240] : (a.mask ? rec[240 + j] : 1.f);
-                aux1[n] = rec[241];
-            }
-
+            for (int k = 0; k < CHUNK; ++k) {
+                const int m = m0 + k;
+                const int t = layer == 1 ? (T - 1 - m) : (T + 1 - m);
+                const bool active = (t >= 0 && t < T);
+                const bool prev_active = (t + 1 >= 0 && t + 1 < T);
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                if (prev_active && !(a.ablate & 4)) {
-                    const float *dv = &sm.ring[layer][(m - 1) & (RING - 1)][n][s * H];
-                    float rec0 = 0.f, rec1 = 0.f;
-#pragma unroll
-                    for (int q = 0; q < H / 4; ++q) {
-                        const float4 v = *reinterpret_cast<const float4 *>(dv + 4 * q);
-                        rec0 = fmaf(whT[4 * q], v.x, rec0); rec1 = fmaf(whT[4 * q + 1], v.y, rec1);
-                        rec0 = fmaf(whT[4 * q + 2], v.z, rec0); rec1 = fmaf(whT[4 * q + 3], v.w, rec1);
-                    }
-                    dhrec[n] = quad_sum(rec0 + rec1);
-                }
-                if (active && b0 + n >= B) sm.ring[layer][m & (RING - 1)][n][s * H + j] = 0.f;
-                if (active && b0 + n < B) {
-                    const float ig = gcur[n].x, fg = gcur[n].y, gg = gcur[n].z, og = gcur[n].w;
+                for (int n = 0; n < NB; ++n) {
+                    // ---- everything that does not depend on the recurrence: the step's record from the LDS stage, the
+                    // derivative factors of this lane's gate, the gradient arriving from above
+                    const float *rec = &sm.stage[sb][n][layer][k][0];
+                    const float4 gc = *reinterpret_cast<const float4 *>(rec + 4 * j);
+                    const float own = rec[4 * j + s];
+                    const float cprev = t > 0 ? rec[192 + j] : 0.f;
+                    const float aux0 = layer == 1 ? rec[240] : (a.mask ? rec[240 + j] : 1.f);
+                    const float aux1 = rec[241];
+                    const float ig = gc.x, fg = gc.y, gg = gc.z, og = gc.w;
+                    const float tc = fast_tanh(ct[n]);
+                    const float wq = og * (1.f - tc * tc);                     // d c_t / d h_t path
+                    const float dact = s == 2 ? 1.f - own * own : own * (1.f - own);
+                    const float qsel = s == 0 ? gg : s == 1 ? cprev : s == 2 ? ig : tc;
+                    const float qr = qsel * dact;                               // da_s = (s == 3 ? dh : dc) * qr
                     float dout;
-                    if (layer == 1) dout = fmaf(aux0[n], dpj[n], aux1[n] * awj);
-                    else            dout = sm.din1[(m - 1) & 1][n][j] * aux0[n];
-                    const float dht = dout + dhrec[n];
-                    const float tc = (a.ablate & 8) ? ct[n] : fast_tanh(ct[n]);
-                    const float dct = fmaf(dht * og, 1.f - tc * tc, dc[n]);
-                    const float da_i = dct * gg * ig * (1.f - ig);
-                    const float da_f = dct * cprev[n] * fg * (1.f - fg);
-                    const float da_g = dct * ig * (1.f - gg * gg);
-                    const float da_o = dht * tc * og * (1.f - og);
-                    dc[n] = dct * fg;
-                    const float mine = s == 0 ? da_i : s == 1 ? da_f : s == 2 ? da_g : da_o;
-                    sm.ring[layer][m & (RING - 1)][n][s * H + j] = mine;
-                    db += mine;
-                    ct[n] = cprev[n];    // c[t-1] is the cell state of the next step handled
+                    if (layer == 1) dout = fmaf(aux0, dpj[n], aux1 * awj);
+                    else            dout = sm.din1[(k + 1) & 1][n][j] * aux0;
+                    // ---- the recurrence
+                    if (prev_active) dhrec[n] = slice_dot(&sm.ring[layer][(k + RING - 1) & (RING - 1)][n][s * H], wp);
+                    if (active) {
+                        float mine = 0.f;                                       // trials past B keep the ring clean
+                        if (b0 + n < B) {
+                            const float dht = dout + dhrec[n];
+                            const float dct = fmaf(dht, wq, dc[n]);
+                            mine = (s == 3 ? dht : dct) * qr;
+                            dc[n] = dct * fg;
+                            db += mine;
+                            ct[n] = cprev;   // c[t-1] is the cell state of the next step handled
+                        }
+                        sm.ring[layer][k][n][s * H + j] = mine;
+                    }
                 }
+                step_barrier<false>(prof);
             }
-            step_barrier<false>(prof);
         }
     }
     float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
@@ -140,9 +159,12 @@ template <int NB>
 __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int r, const int n_steps) {
     const int j = r >> 2, s = r & 3;
     const int T = a.T, B = a.B, C = a.C;
-    float wiT[H];
+    f32x2 wp[H / 2];
 #pragma unroll
-    for (int q = 0; q < H; ++q) wiT[q] = a.w_ih1[(size_t)(s * H + q) * H + j];
+    for (int q = 0; q < H / 2; ++q) {
+        wp[q].x = a.w_ih1[(size_t)(s * H + 2 * q) * H + j];
+        wp[q].y = a.w_ih1[(size_t)(s * H + 2 * q + 1) * H + j];
+    }
     float dWih0[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { dWih0[g][0] = 0.f; dWih0[g][1] = 0.f; }
@@ -158,40 +180,39 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
         for (int n = 0; n < NB; ++n) dpj[n] = (a.residual && b0 + n < B) ? a.dpooled[(size_t)(b0 + n) * H + j] : 0.f;
         step_barrier<false>(prof);
 
-        for (int m = 0; m < n_steps; ++m) {
-            const int t1p = T - m;          // layer-1 step whose da1 was written at macro step m-1
-            const int t0p = T + 2 - m;      // layer-0 step whose da0 was written at macro step m-1
-            const int e = (m - 1) & (RING - 1);
+        for (int m0 = 0; m0 < n_steps; m0 += CHUNK) {
+            const int sb = (m0 / CHUNK) & 1;
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const float2 xv = *reinterpret_cast<const float2 *>(&sm.xst[(m / CHUNK) & 1][n][m & (CHUNK - 1)][2 * s]);
-                if (t1p >= 0 && t1p < T && !(a.ablate & 2)) {
-                    const float *dv = &sm.ring[1][e][n][s * H];
-                    float i0 = 0.f, i1 = 0.f;
+            for (int k = 0; k < CHUNK; ++k) {
+                const int m = m0 + k;
+                const int t1p = T - m;          // layer-1 step whose da1 was written at macro step m-1
+                const int t0p = T + 2 - m;      // layer-0 step whose da0 was written at macro step m-1
+                constexpr int PREV = RING - 1;
+                const int e = (k + PREV) & (RING - 1);
 #pragma unroll
-                    for (int q = 0; q < H / 4; ++q) {
-                        const float4 v = *reinterpret_cast<const float4 *>(dv + 4 * q);
-                        i0 = fmaf(wiT[4 * q], v.x, i0); i1 = fmaf(wiT[4 * q + 1], v.y, i1);
-                        i0 = fmaf(wiT[4 * q + 2], v.z, i0); i1 = fmaf(wiT[4 * q + 3], v.w, i1);
+                for (int n = 0; n < NB; ++n) {
+                    const float2 xv = *reinterpret_cast<const float2 *>(&sm.xst[sb][n][k][2 * s]);
+                    if (t1p >= 0 && t1p < T) {
+                        float inp = slice_dot(&sm.ring[1][e][n][s * H], wp);
+                        if (a.residual && b0 + n < B) {
+                            // dout1[t1p] = alpha*dpooled + dscore*attn_w: the scalars sit in the record of macro step m-1
+                            // (for k == 0 that is step 7 of the other stage buffer)
+                            const float *recp = &sm.stage[k == 0 ? sb ^ 1 : sb][n][1][e][0];
+                            inp += fmaf(recp[240], dpj[n], recp[241] * awj);
+                        }
+                        if (s == 0) sm.din1[k & 1][n][j] = inp;
                     }
-                    float inp = quad_sum(i0 + i1);
-                    if (a.residual && b0 + n < B) {
-                        // dout1[t1p] = alpha*dpooled + dscore*attn_w: the scalars sit in the record of macro step m-1
-                        const float *recp = &sm.stage[((m - 1) / CHUNK) & 1][n][1][(m - 1) & (CHUNK - 1)][0];
-                        inp += fmaf(recp[240], dpj[n], recp[241] * awj);
+                    if (t0p >= 0 && t0p < T && b0 + n < B) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float d = sm.ring[0][e][n][g * H + j];
+                            dWih0[g][0] = fmaf(d, xv.x, dWih0[g][0]);
+                            dWih0[g][1] = fmaf(d, xv.y, dWih0[g][1]);
+                        }
                     }
-                    if (s == 0) sm.din1[m & 1][n][j] = inp;
                 }
-                if (t0p >= 0 && t0p < T && b0 + n < B) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float d = sm.ring[0][e][n][g * H + j];
-                        dWih0[g][0] = fmaf(d, xv.x, dWih0[g][0]);
-                        dWih0[g][1] = fmaf(d, xv.y, dWih0[g][1]);
-                    }
-                }
+                step_barrier<false>(prof);
             }
-            step_barrier<false>(prof);
         }
     }
     prof_store(a.dbg, prof);

@@ -142,18 +142,19 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
 #pragma unroll
             for (int q = 0; q < MPT; ++q) mr[q] = mask_at(r + 192 * q, m0 + XCH);
             const int cb = (m0 / XCH) & 1;
-            for (int k = 0; k < XCH; ++k) {
+            for (int kh = 0; kh < XCH; kh += SRING) {
+#pragma unroll
+              for (int kr = 0; kr < SRING; ++kr) {
+                const int k = kh + kr;
                 const int m = m0 + k;
-                if (m >= n_steps) break;
-                const int cur = m & 1, prv = cur ^ 1;
-                if (m < T) {
+                if (m < T && !(a.ablate & 64)) {
 #pragma unroll
                     for (int n = 0; n < NB; ++n) {
                         const float mk = sm.ms[cb][n][k][j];
                         const float2 xq = *reinterpret_cast<const float2 *>(&sm.xs[cb][n][k][2 * s]);
                         const f32x2 xv = {xq.x, xq.y};
                         f32x2 hv[6];
-                        load_slice(&sm.sv[(m - 1) & (SRING - 1)][n][0][192 + s * KS], hv);
+                        load_slice(&sm.sv[(kr + SRING - 1) & (SRING - 1)][n][0][192 + s * KS], hv);
                         f32x2 acc[4];
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -168,7 +169,7 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                         c[n] = fmaf(fg, c[n], ig * gg);
                         const float h = og * fast_tanh(c[n]);
                         const float hm = h * mk;
-                        float *sr = &sm.sv[m & (SRING - 1)][n][0][0];
+                        float *sr = &sm.sv[kr][n][0][0];
                         sr[4 * j + s] = act;
                         sr[192 + 48 * s + j] = s == 1 ? c[n] : s == 2 ? hm : h;       // slots: h | c | masked h | spare
                     }
@@ -180,6 +181,7 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                     for (int q = 0; q < MPT; ++q) *reinterpret_cast<float4 *>(&sm.ms[cb ^ 1][0][0][0] + 4 * (r + 192 * q)) = mr[q];
                 }
                 step_barrier<false>(prof);
+              }
             }
         }
         step_barrier<false>(prof);      // the saver wave has drained the save ring of this trial group
@@ -206,12 +208,15 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         step_barrier<false>(prof);
-        for (int m = 0; m < n_steps; ++m) {
-            if (m >= 1 && m <= T) {
+        for (int m0 = 0; m0 < n_steps; m0 += SRING) {
+#pragma unroll
+          for (int k = 0; k < SRING; ++k) {
+            const int m = m0 + k;
+            if (m >= 1 && m <= T && !(a.ablate & 128)) {
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     f32x2 iv[6];
-                    load_slice(&sm.sv[(m - 1) & (SRING - 1)][n][0][288 + s * KS], iv);
+                    load_slice(&sm.sv[(k + SRING - 1) & (SRING - 1)][n][0][288 + s * KS], iv);
                     f32x2 acc[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -219,10 +224,11 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
 #pragma unroll
                         for (int q = 1; q < 6; ++q) acc[g] = pk_fma(wi[g][q], iv[q], acc[g]);
                     }
-                    sm.pb[m & 1][n][s * H + j] = reduce_pick(acc, s);
+                    sm.pb[k & 1][n][s * H + j] = reduce_pick(acc, s);
                 }
             }
             step_barrier<false>(prof);
+          }
         }
         step_barrier<false>(prof);      // save ring drained
     }
@@ -254,48 +260,50 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
 #pragma unroll
         for (int n = 0; n < NB; ++n) c[n] = 0.f;
         step_barrier<false>(prof);
-        for (int m = 0; m < n_steps; ++m) {
+        // The time loop is unrolled by the ring length: ring slots, buffer parities and every LDS offset become
+        // immediates.  (A wave issues about one instruction per 5 cycles whatever its ILP -- tools/isa_loops.py --
+        // so scalar index arithmetic in the step body costs as much as the FMAs.)
+        for (int m0 = 0; m0 < n_steps; m0 += SRING) {
+#pragma unroll
+          for (int k = 0; k < SRING; ++k) {
+            const int m = m0 + k;
             const int t = m - 2;
             prof_mark<-1, false>(prof);
             if (t >= 0 && t < T) {
-                const int cur = m & 1, prv = cur ^ 1;
+                const int prv = (k & 1) ^ 1;
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     const float pj = sm.pb[prv][n][s * H + j];          // input projection of this step (gate s)
                     f32x2 hv[6];
-                    load_slice(&sm.sv[(m - 1) & (SRING - 1)][n][1][192 + s * KS], hv);
+                    load_slice(&sm.sv[(k + SRING - 1) & (SRING - 1)][n][1][192 + s * KS], hv);
                     prof_mark<0, true>(prof);        // seg0: LDS operands arrived
                     f32x2 acc[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         acc[g] = wh[g][0] * hv[0];
-                        if (!(a.ablate & 4)) {
 #pragma unroll
-                            for (int q = 1; q < 6; ++q) acc[g] = pk_fma(wh[g][q], hv[q], acc[g]);
-                        }
+                        for (int q = 1; q < 6; ++q) acc[g] = pk_fma(wh[g][q], hv[q], acc[g]);
                     }
                     prof_mark<1, false>(prof);       // seg1: 24 pk_fma issued (not necessarily retired)
-                    const float pre = ((a.ablate & 16) ? acc[0].x + acc[1].y + acc[2].x + acc[3].y : reduce_pick(acc, s)) + (pj + bias);
+                    const float pre = reduce_pick(acc, s) + (pj + bias);
                     prof_mark<2, false>(prof);       // seg2: quad reduction + select
-                    const float act = (a.ablate & 1) ? pre * 0.01f : gate_act(pre, gk.a, gk.b, gk.c);
-                    float ig, fg, gg, og;
-                    if (a.ablate & 32) { ig = act; fg = act * 0.5f; gg = act * 0.25f; og = act * 0.125f; }
-                    else { ig = quad_bcast<0>(act); fg = quad_bcast<1>(act); gg = quad_bcast<2>(act); og = quad_bcast<3>(act); }
+                    const float act = gate_act(pre, gk.a, gk.b, gk.c);
+                    const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act);
+                    const float gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
                     prof_mark<3, false>(prof);       // seg3: gate activation + quad broadcast
                     c[n] = fmaf(fg, c[n], ig * gg);
-                    const float h = og * ((a.ablate & 2) ? c[n] : fast_tanh(c[n]));
-                    prof_mark<4, true>(prof);        // seg4: cell update, tanh, h to LDS
-                    if (!(a.ablate & 8)) {
-                        float *sr = &sm.sv[m & (SRING - 1)][n][1][0];
-                        sr[4 * j + s] = act;
-                        float top = h;                                // layer-1 input of step t was written two macro steps ago
-                        if (a.residual) top += sm.sv[(m - 2) & (SRING - 1)][n][0][288 + j];
-                        sr[192 + 48 * s + j] = s == 1 ? c[n] : s == 2 ? top : h;      // slots: h | c | top | spare
-                    }
+                    const float h = og * fast_tanh(c[n]);
+                    prof_mark<4, true>(prof);        // seg4: cell update, tanh
+                    float *sr = &sm.sv[k][n][1][0];
+                    sr[4 * j + s] = act;
+                    float top = h;                                // layer-1 input of step t was written two macro steps ago
+                    if (a.residual) top += sm.sv[(k + SRING - 2) & (SRING - 1)][n][0][288 + j];
+                    sr[192 + 48 * s + j] = s == 1 ? c[n] : s == 2 ? top : h;      // slots: h | c | top | spare
                     prof_mark<5, false>(prof);       // seg5: record for the saver wave
                 }
             }
             step_barrier<false>(prof);
+          }
         }
         step_barrier<false>(prof);      // save ring drained
     }

@@ -56,9 +56,13 @@ int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t
 // in LDS in a fixed order (deterministic).  ~1000 workgroups for the reference model instead of 124.
 #define GR_COLS 32
 #define GR_GROUPS 8
+// optional optimizer tail of the reduction (single-rank training: no all-reduce sits between the two)
+struct AdamTail { float *p, *m, *v; float lr_over_bc1, rsqrt_bc2, beta1, beta2, eps, wd, gscale; };
+
+template <bool ADAM>
 __global__ __launch_bounds__(GR_COLS * GR_GROUPS) void grad_reduce_kernel(
         const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs, long ph, int n_hslabs,
-        float *grads, int accumulate) {
+        float *grads, int accumulate, AdamTail ad) {
     __shared__ float part[GR_GROUPS][GR_COLS];
     const int c = threadIdx.x & (GR_COLS - 1), grp = threadIdx.x / GR_COLS;
     const long e = (long)blockIdx.x * GR_COLS + c;
@@ -77,16 +81,39 @@ __global__ __launch_bounds__(GR_COLS * GR_GROUPS) void grad_reduce_kernel(
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < GR_GROUPS; ++g) s += part[g][c];
-        grads[e] = accumulate ? grads[e] + s : s;
+        if (accumulate) s += grads[e];
+        grads[e] = s;
+        if (ADAM) {                                   // same arithmetic, in the same order, as adam_kernel
+            const float pi = ad.p[e];
+            const float gi = fmaf(ad.wd, pi, s * ad.gscale);
+            const float mi = ad.beta1 * ad.m[e] + (1.f - ad.beta1) * gi;
+            const float vi = ad.beta2 * ad.v[e] + (1.f - ad.beta2) * gi * gi;
+            ad.m[e] = mi; ad.v[e] = vi;
+            const float denom = sqrtf(vi) * ad.rsqrt_bc2 + ad.eps;
+            ad.p[e] = pi - ad.lr_over_bc1 * (mi / denom);
+        }
     }
 }
 
 int nsd_grad_reduce_launch(const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs,
                            long ph, int n_hslabs, float *grads, int accumulate, hipStream_t st) {
     const long n = p_lstm + ph;
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((n + GR_COLS - 1) / GR_COLS)), dim3(GR_COLS * GR_GROUPS), 0, st,
-                       slabs, slab_stride, n_slabs, p_lstm, hslabs, ph, n_hslabs, grads, accumulate);
+    hipLaunchKernelGGL((grad_reduce_kernel<false>), dim3((unsigned)((n + GR_COLS - 1) / GR_COLS)), dim3(GR_COLS * GR_GROUPS), 0, st,
+                       slabs, slab_stride, n_slabs, p_lstm, hslabs, ph, n_hslabs, grads, accumulate, AdamTail{});
     NSD_CHECK_LAUNCH("grad_reduce");
+    return NSD_OK;
+}
+
+int nsd_grad_reduce_adam_launch(const float *slabs, long slab_stride, int n_slabs, long p_lstm, const float *hslabs,
+                                long ph, int n_hslabs, float *grads, float *p, float *m, float *v, float lr, float b1,
+                                float b2, float eps, float wd, float gscale, int step, hipStream_t st) {
+    const long n = p_lstm + ph;
+    if (step < 1) { nsd_set_error("grad_reduce_adam: step must be >= 1"); return NSD_E_INVALID; }
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    AdamTail ad{p, m, v, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, wd, gscale};
+    hipLaunchKernelGGL((grad_reduce_kernel<true>), dim3((unsigned)((n + GR_COLS - 1) / GR_COLS)), dim3(GR_COLS * GR_GROUPS), 0, st,
+                       slabs, slab_stride, n_slabs, p_lstm, hslabs, ph, n_hslabs, grads, 0, ad);
+    NSD_CHECK_LAUNCH("grad_reduce_adam");
     return NSD_OK;
 }
 

@@ -52,5 +52,6 @@ __device__ __forceinline__ void prof_store(long long *dbg, const Prof &p) {
         long long *o = dbg + 8 * (threadIdx.x >> 6);
         o[0] = p.work; o[1] = p.wait;
         for (int i = 0; i < 6; ++i) o[2 + i] = p.seg[i];
+        dbg[256 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID: wave slot, SIMD, CU ...
     }
 }

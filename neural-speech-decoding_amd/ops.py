@@ -223,9 +223,12 @@ def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: tor
 
 def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: torch.Tensor, labels: torch.Tensor,
                      logits: torch.Tensor, grads: torch.Tensor, *, scale: Optional[float] = None, drop_lstm=None,
-                     rrelu_slope=None, drop_head=None, residual: bool = False) -> None:
+                     rrelu_slope=None, drop_head=None, residual: bool = False, adam: Optional[dict] = None) -> None:
     """The four launches of one training evaluation: lstm fwd, fused head (fwd + mean CE + bwd), lstm bwd, slab
-    reduce -> `grads` (flat, overwritten).  `logits` [B,K] is an output buffer."""
+    reduce -> `grads` (flat, overwritten).  `logits` [B,K] is an output buffer.
+
+    adam=dict(m=, v=, step=, lr=, beta1=, beta2=, eps=, weight_decay=): single-rank training -- the optimizer update of
+    `flat` rides in the reduction launch (nsd_grad_reduce_adam); `grads` is still written."""
     B, T, _ = x.shape
     d = spec.dims(B, T)
     flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0)
@@ -238,7 +241,13 @@ def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: t
     _call("nsd_lstm_fwd", C.byref(d), pp, xp, dl, flags, wsp, st)
     _call("nsd_head_train", C.byref(d), pp, sl, dh, labels.data_ptr(), scale, wsp, _dev_f32(logits, "logits", (B, spec.K)), st)
     _call("nsd_lstm_bwd", C.byref(d), pp, xp, dl, flags, wsp, None, st)
-    _call("nsd_grad_reduce", C.byref(d), wsp, _dev_f32(grads, "grads", (spec.param_count,)), 0, st)
+    gp = _dev_f32(grads, "grads", (spec.param_count,))
+    if adam is None:
+        _call("nsd_grad_reduce", C.byref(d), wsp, gp, 0, st)
+    else:
+        _call("nsd_grad_reduce_adam", C.byref(d), wsp, gp, pp, _dev_f32(adam["m"], "m", flat.shape), _dev_f32(adam["v"], "v", flat.shape),
+              adam.get("lr", 1e-3), adam.get("beta1", 0.9), adam.get("beta2", 0.999), adam.get("eps", 1e-8),
+              adam.get("weight_decay", 0.0), 1.0, int(adam["step"]), st)
 
 
 def loss_sum(spec: ModelSpec, ws: torch.Tensor, B: int, T: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -112,11 +112,18 @@ class Trainer:
             _lib.check(L.nsd_dropout_mask(self.seed, sid + 2, self.model.head_dropout_p, dh.numel(), dh.data_ptr(), st), "dropout_mask")
         ws = buf["ws"]
         scale = 1.0 / (B * self.world)
-        ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
-                             rrelu_slope=sl, drop_head=dh, residual=self.model.residual)
-        self.reducer(self.grads)
-        ops.adam_step(self.flat, self.grads, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
-                      beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay)
+        hyper = dict(step=self.step_count, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                     weight_decay=self.weight_decay)
+        if self.world == 1:
+            # no exchange step between reduction and update: one launch does both
+            ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
+                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual,
+                                 adam=dict(m=self.m, v=self.v, **hyper))
+        else:
+            ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
+                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual)
+            self.reducer(self.grads)
+            ops.adam_step(self.flat, self.grads, self.m, self.v, **hyper)
         self._last_B, self._last_T = B, T
 
     # ---- hipGraph path ------------------------------------------------------------------------------------

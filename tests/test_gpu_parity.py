@@ -357,6 +357,34 @@ def test_trainer_step_matches_oracle_with_its_own_streams(nsd, dev, ref_state):
     assert np.abs(m.flat_parameters().cpu().numpy() - p).max() < 2e-6
 
 
+def test_fused_reduce_adam_is_bit_identical_to_separate_launches(nsd, dev, ref_state):
+    """nsd_grad_reduce_adam == nsd_grad_reduce followed by nsd_adam_step (same arithmetic, same order)."""
+    from nsd_amd import ops
+    spec = ops.ModelSpec()
+    B, T = 37, 50
+    x, y = _t(synth_x(B, T, seed=12), dev), _t(synth_labels(B, seed=12), dev)
+    flat0 = _t(orc.flatten_state(ref_state, D), dev)
+    out = {}
+    for fused in (False, True):
+        flat, g = flat0.clone(), torch.zeros_like(flat0)
+        m, v = torch.rand_like(flat0) * 1e-3, torch.rand_like(flat0) * 1e-6
+        m0 = torch.rand(flat0.shape, generator=torch.Generator().manual_seed(3)).to(dev) * 1e-3
+        v0 = torch.rand(flat0.shape, generator=torch.Generator().manual_seed(4)).to(dev) * 1e-6
+        m.copy_(m0); v.copy_(v0)
+        ws = ops.new_workspace(spec, B, T, dev)
+        logits = torch.empty(B, 3, device=dev)
+        hyper = dict(step=3, lr=2e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-4)
+        if fused:
+            ops.train_step_grads(spec, flat, x, ws, y, logits, g, adam=dict(m=m, v=v, **hyper))
+        else:
+            ops.train_step_grads(spec, flat, x, ws, y, logits, g)
+            ops.adam_step(flat, g, m, v, **hyper)
+        out[fused] = (flat.cpu(), g.cpu(), m.cpu(), v.cpu())
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+    assert not torch.equal(out[True][0], flat0.cpu())
+
+
 def test_graph_replay_step_equals_eager_step(nsd, dev, ref_state):
     """Trainer.step_static (captured hipGraphs, device-side step counter) == Trainer.step (eager launches)."""
     from nsd_amd.trainer import Trainer

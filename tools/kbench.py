@@ -41,7 +41,7 @@ def main():
     dl = ops.dropout_mask(1, 0, 0.6, (1, B, T, 48), dev) if args.mask else None
 
     def timed(fn, n):
-        for _ in range(3):
+        for _ in range(100):       # the GPU clock ramps over the first tens of launches
             fn()
         torch.cuda.synchronize()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -68,7 +68,7 @@ def main():
         print(f"ablate={ab:3d}  B={B} T={T}  lstm_fwd {f_med:8.1f} us (min {f_min:.1f})   lstm_bwd {b_med:8.1f} us (min {b_min:.1f})", flush=True)
         if args.prof:
             for which in ("fwd", "bwd"):
-                dbg = torch.zeros(256, dtype=torch.int64, device=dev)
+                dbg = torch.zeros(512, dtype=torch.int64, device=dev)
                 L.nsd_debug_profile_buffer(dbg.data_ptr())
                 if which == "fwd":
                     L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, st)
@@ -80,11 +80,12 @@ def main():
                     nst = 4 * ((((T + 2) // 4 + 2) + 1) & ~1)
                 torch.cuda.synchronize()
                 L.nsd_debug_profile_buffer(None)
-                v = dbg.cpu().numpy().reshape(32, 8)
+                hw = dbg.cpu().numpy()[256:]
+                v = dbg.cpu().numpy()[:256].reshape(32, 8)
                 print(f"  {which}: cycles per step (workgroup 0)")
                 for wv, role in enumerate(roles):
                     seg = "  ".join(f"{v[wv, 2 + q] / nst:5.0f}" for q in range(6))
-                    print(f"    wave {wv:2d} {role:7s} work {v[wv,0]/nst:6.0f}  wait {v[wv,1]/nst:6.0f}   segments {seg}")
+                    print(f"    wave {wv:2d} {role:7s} work {v[wv,0]/nst:6.0f}  wait {v[wv,1]/nst:6.0f}   segments {seg}   simd {(int(hw[wv]) >> 4) & 3} slot {int(hw[wv]) & 15} cu {(int(hw[wv]) >> 8) & 15}")
     os.environ["NSD_ABLATE"] = "0"
 
 
