@@ -49,6 +49,11 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
+// rotation inside a row of 16 lanes (DPP row_ror:N): lane i receives the value of lane (i + N) % 16 or (i - N) % 16 --
+// only used in sums over all rotations by a multiple of 4, where the direction does not matter
+template <int N>
+__device__ __forceinline__ float row_ror(float v) { return dpp_quad<0x120 + N>(v); }
+
 // sigma(x) = 1/(1+2^(-x*log2e)); tanh(x) = 2*sigma(2x) - 1.  v_exp_f32 / v_rcp_f32 (1 ulp each).
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E_F * x));

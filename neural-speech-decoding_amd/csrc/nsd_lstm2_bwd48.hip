@@ -5,9 +5,9 @@
 // backwards with ONE barrier per step; the waves have different jobs so that only the true recurrence
 // is on the critical path and every register array stays small:
 //
-//   waves 0-2   "chain 1"  layer-1 cell backward: dh_rec = W_hh1^T da1[t+1] (48 FMA/lane, weights in VGPRs,
-//                          operands broadcast from LDS, DPP quad reduction) then the element-wise cell
-//                          backward for step t -> da1[t] into an LDS ring.
+//   waves 0-2   "chain 1"  layer-1 cell backward: dh_rec = W_hh1^T da1[t+1] (48 FMA/lane as 24 v_pk_fma_f32, weights
+//                          in VGPRs, 12 operands per lane from LDS, DPP reduction over 16 lanes) then the
+//                          element-wise cell backward for step t -> da1[t] into an LDS ring.
 //   waves 3-5   "chain 0"  the same for layer 0, two steps behind layer 1.
 //   waves 6-8   "x1"       d_in1[t] = W_ih1^T da1[t] (the gradient handed to layer 0) and dW_ih0 (K=8, VALU).
 //   wave  15    "loader" LDS-DMA stream of the saved activations, one 8-step chunk ahead (see below).
@@ -53,35 +53,57 @@ struct Smem {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// W^T-slice mat-vec of a chain / x1 lane: 48 operands from LDS (12 x 16 B) against 24 weight pairs, FOUR independent
-// accumulator pairs (a single chain of 24 dependent v_pk_fma_f32 costs ~2x their issue time), then the quad sum.
-__device__ __forceinline__ float slice_dot(const float *dv, const f32x2 (&wp)[24]) {
+// Transposed mat-vec of a chain / x1 wave: out[j] = sum_{r<192} W[r][j] * v[r] for the wave's 16 units.
+// Lane (row of 16 lanes = output group og of 4 units, kk = lane & 15 = slice of 12 inputs): 12 operands from LDS
+// (3 x 16 B; the previous layout -- one unit x 48 inputs per lane -- needed 12 x 16 B and made the LDS pipe the
+// busiest unit of the step) against 4 x 6 weight pairs, four independent accumulator pairs (depth 6), a
+// reduce-scatter over the quad and two row rotations.  Returns out[4*og + (lane & 3)], replicated over the 4 quads
+// of the row -- which is where the 4 gates of that unit are evaluated.
+__device__ __forceinline__ float slice_dot_t(const float *dv, const f32x2 (&wp)[4][6]) {
     f32x2 acc[4];
 #pragma unroll
-    for (int q = 0; q < H / 4; ++q) {
+    for (int q = 0; q < 3; ++q) {
         const float4 v = *reinterpret_cast<const float4 *>(dv + 4 * q);
         const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-        const int a0 = (2 * q) & 3, a1 = (2 * q + 1) & 3;
-        acc[a0] = q < 2 ? wp[2 * q] * lo : pk_fma(wp[2 * q], lo, acc[a0]);
-        acc[a1] = q < 2 ? wp[2 * q + 1] * hi : pk_fma(wp[2 * q + 1], hi, acc[a1]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            acc[jj] = q == 0 ? wp[jj][0] * lo : pk_fma(wp[jj][2 * q], lo, acc[jj]);
+            acc[jj] = pk_fma(wp[jj][2 * q + 1], hi, acc[jj]);
+        }
     }
-    const f32x2 r = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    return quad_sum(r.x + r.y);
+    const int lane = threadIdx.x;
+    const bool odd = (lane & 1) != 0, hi2 = (lane & 2) != 0;
+    const float r0 = acc[0].x + acc[0].y, r1 = acc[1].x + acc[1].y;
+    const float r2 = acc[2].x + acc[2].y, r3 = acc[3].x + acc[3].y;
+    const float ra = (odd ? r1 : r0) + quad_xor1(odd ? r0 : r1);
+    const float rb = (odd ? r3 : r2) + quad_xor1(odd ? r2 : r3);
+    float v = (hi2 ? rb : ra) + quad_xor2(hi2 ? ra : rb);     // unit (lane & 3) over this quad's 4 slices
+    v += row_ror<4>(v);
+    v += row_ror<8>(v);                                        // ... over all 16 slices
+    return v;
+}
+
+// weights of slice_dot_t for W [192][48] row-major (nn.LSTM weight_hh / weight_ih layout)
+__device__ __forceinline__ void load_wT(const float *w, const int og, const int kk, f32x2 (&wp)[4][6]) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            wp[jj][p].x = w[(size_t)(12 * kk + 2 * p) * H + 4 * og + jj];
+            wp[jj][p].y = w[(size_t)(12 * kk + 2 * p + 1) * H + 4 * og + jj];
+        }
 }
 
 template <int NB>
 __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int layer, const int r,
                                            const int n_steps) {
-    const int j = r >> 2, s = r & 3;
+    // lane -> mat-vec coordinates (output group og, input slice kk) and cell coordinates (unit j, gate s)
+    const int og = r >> 4, kk = r & 15;
+    const int j = 4 * og + (r & 3), s = (r >> 2) & 3;
     const int T = a.T, B = a.B;
     const float *cseq = layer == 0 ? a.cseq0 : a.cseq1;
-    const float *whh = layer == 0 ? a.w_hh0 : a.w_hh1;
-    f32x2 wp[H / 2];
-#pragma unroll
-    for (int q = 0; q < H / 2; ++q) {
-        wp[q].x = whh[(size_t)(s * H + 2 * q) * H + j];
-        wp[q].y = whh[(size_t)(s * H + 2 * q + 1) * H + j];
-    }
+    f32x2 wp[4][6];
+    load_wT(layer == 0 ? a.w_hh0 : a.w_hh1, og, kk, wp);
     const float awj = a.attn_w[j];
     float db = 0.f;
     Prof prof = prof_init(a.dbg);
@@ -128,7 +150,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
                     if (layer == 1) dout = fmaf(aux0, dpj[n], aux1 * awj);
                     else            dout = sm.din1[(k + 1) & 1][n][j] * aux0;
                     // ---- the recurrence
-                    if (prev_active) dhrec[n] = slice_dot(&sm.ring[layer][(k + RING - 1) & (RING - 1)][n][s * H], wp);
+                    if (prev_active) dhrec[n] = slice_dot_t(&sm.ring[layer][(k + RING - 1) & (RING - 1)][n][12 * kk], wp);
                     if (active) {
                         float mine = 0.f;                                       // trials past B keep the ring clean
                         if (b0 + n < B) {
@@ -157,14 +179,11 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
 // ------------------------------------------------------------------------------------------------
 template <int NB>
 __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int r, const int n_steps) {
-    const int j = r >> 2, s = r & 3;
+    const int og = r >> 4, kk = r & 15;
+    const int j = 4 * og + (r & 3), s = (r >> 2) & 3;        // s: which copy of unit j this lane is (dW_ih0 channel pair)
     const int T = a.T, B = a.B, C = a.C;
-    f32x2 wp[H / 2];
-#pragma unroll
-    for (int q = 0; q < H / 2; ++q) {
-        wp[q].x = a.w_ih1[(size_t)(s * H + 2 * q) * H + j];
-        wp[q].y = a.w_ih1[(size_t)(s * H + 2 * q + 1) * H + j];
-    }
+    f32x2 wp[4][6];
+    load_wT(a.w_ih1, og, kk, wp);
     float dWih0[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { dWih0[g][0] = 0.f; dWih0[g][1] = 0.f; }
@@ -193,7 +212,7 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
                 for (int n = 0; n < NB; ++n) {
                     const float2 xv = *reinterpret_cast<const float2 *>(&sm.xst[sb][n][k][2 * s]);
                     if (t1p >= 0 && t1p < T) {
-                        float inp = slice_dot(&sm.ring[1][e][n][s * H], wp);
+                        float inp = slice_dot_t(&sm.ring[1][e][n][12 * kk], wp);
                         if (a.residual && b0 + n < B) {
                             // dout1[t1p] = alpha*dpooled + dscore*attn_w: the scalars sit in the record of macro step m-1
                             // (for k == 0 that is step 7 of the other stage buffer)

@@ -255,7 +255,6 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
     Prof prof = prof_init(a.dbg);
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
-        const int b0 = grp * NB;
         float c[NB];
 #pragma unroll
         for (int n = 0; n < NB; ++n) c[n] = 0.f;
