@@ -141,6 +141,15 @@ int nsd_head_train(const nsd_dims *d, const float *params, const float *rrelu_sl
                    const int32_t *labels, float scale, float *workspace, float *logits, void *stream);
 
 /*
+ * nsd_lstm_fwd + nsd_head_train in ONE launch where the shape allows (H = 48, L = 2, T <= 1024, F <= 64, K <= 8: the
+ * attention pooling rides along the recurrence and the dense head, loss and head backward run in the kernel's tail);
+ * other shapes run the two launches it replaces.  Same outputs, workspace contents and gradient slabs either way.
+ */
+int nsd_lstm_head_train(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
+                        const float *rrelu_slope, const float *drop_head, const int32_t *labels, float scale, uint32_t flags,
+                        float *workspace, float *logits, void *stream);
+
+/*
  * Stacked LSTM backward (BPTT) through lstm_eeg_model.py:34 with the activations kept by nsd_lstm_fwd.
  * Partial gradients go to the slabs.  dx: NULL or [B,T,C].
  */

@@ -47,6 +47,7 @@ SYMBOLS = {
     "nsd_head_fwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     "nsd_head_bwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, _fp, _vp]),
     "nsd_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _ip, C.c_float, _fp, _fp, _vp]),
+    "nsd_lstm_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, C.c_uint32, _fp, _fp, _vp]),
     "nsd_lstm_bwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, _fp, _vp]),
     "nsd_grad_reduce": (C.c_int, [_dp, _fp, _fp, C.c_int32, _vp]),
     "nsd_grad_reduce_adam": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [C.c_int32, _vp]),

@@ -315,6 +315,35 @@ int nsd_head_train(const nsd_dims *d, const float *params, const float *rrelu_sl
     return nsd_head_launch(h, true, (hipStream_t)stream);
 }
 
+int nsd_lstm_head_train(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
+                        const float *rrelu_slope, const float *drop_head, const int32_t *labels, float scale, uint32_t flags,
+                        float *workspace, float *logits, void *stream) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!params || !x || !workspace || !logits || !labels) { nsd_set_error("lstm_head_train: null pointer"); return NSD_E_INVALID; }
+    if (d->B == 0) return NSD_OK;
+    if (!(fast_path_ok(d) && d->H == 48 && nsd_lstm2_fwd48_head_train_fits(d->T, d->F, d->K))) {
+        // shapes outside the fused kernel: the two launches it replaces
+        const int rc = nsd_lstm_fwd(d, params, x, drop_lstm, flags, workspace, stream);
+        if (rc != NSD_OK) return rc;
+        return nsd_head_train(d, params, rrelu_slope, drop_head, labels, scale, workspace, logits, stream);
+    }
+    const nsd_ws_layout w = make_ws(d, true);
+    Lstm2FwdArgs a;
+    build_lstm_fwd(d, params, x, drop_lstm, flags, workspace, w, true, nullptr, &a);
+    const HeadArgs h = build_head(d, params);
+    a.attn_w = h.attn_w; a.attn_b = h.attn_b; a.ln_w = h.ln_w; a.ln_b = h.ln_b;
+    a.fc0_w = h.fc0_w; a.fc0_b = h.fc0_b; a.fc3_w = h.fc3_w; a.fc3_b = h.fc3_b;
+    a.eval_slope = h.eval_slope; a.K = d->K; a.F = d->F;
+    a.head_train = 1;
+    a.labels = labels; a.rrelu_slope = rrelu_slope; a.drop_head = drop_head; a.scale = scale;
+    a.logits = logits; a.loss = workspace + w.loss; a.alpha = workspace + w.alpha; a.pooled = workspace + w.pooled;
+    a.fc0_pre = workspace + w.fc0_pre; a.dscore = workspace + w.dscore; a.dpooled = workspace + w.dpooled;
+    a.adpack = workspace + w.adpack; a.hslabs = workspace + w.hslabs;
+    a.o_ln_w = h.o_ln_w; a.o_ln_b = h.o_ln_b; a.o_attn_w = h.o_attn_w; a.o_attn_b = h.o_attn_b;
+    a.o_fc0_w = h.o_fc0_w; a.o_fc0_b = h.o_fc0_b; a.o_fc3_w = h.o_fc3_w; a.o_fc3_b = h.o_fc3_b; a.Ph = h.Ph;
+    return nsd_lstm2_fwd_launch(a, d->H, (hipStream_t)stream);
+}
+
 int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, uint32_t flags,
                  float *workspace, float *dx, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;

@@ -16,6 +16,15 @@ struct Lstm2FwdArgs {
     int K, F;
     int B, T, C, residual;
     int ablate;                              // timing experiments only (env NSD_ABLATE); 0 in production
+    // fused TRAIN head (lstm2_fwd48 only; head_train != 0): attention pooling rides along the recurrence (wave 10), then
+    // LayerNorm, dense head, mean-CE and the head's backward run in the kernel's tail -- what nsd_head_train does in a
+    // second launch.  Outputs and per-trial gradient slabs are those of HeadArgs.
+    int head_train;
+    const int32_t *labels;
+    const float *rrelu_slope, *drop_head;
+    float scale;
+    float *logits, *loss, *alpha, *pooled, *fc0_pre, *dscore, *dpooled, *adpack, *hslabs;
+    long o_ln_w, o_ln_b, o_attn_w, o_attn_b, o_fc0_w, o_fc0_b, o_fc3_w, o_fc3_b, Ph;
 };
 struct Lstm2BwdArgs {
     const float *x;
@@ -55,6 +64,7 @@ int nsd_lstm2_bwd_launch(const Lstm2BwdArgs &a, int H, hipStream_t st);
 int nsd_lstm2_bwd_grid(int B);
 int nsd_lstm2_bwd48_launch(const Lstm2BwdArgs &a, int nb, int grid, hipStream_t st);
 int nsd_lstm2_fwd48_launch(const Lstm2FwdArgs &a, int nb, int grid, hipStream_t st);
+bool nsd_lstm2_fwd48_head_train_fits(int T, int F, int K);
 int nsd_lstm_generic_fwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,
                          int residual, float *hseq, float *cseq, float *gact, float *inseq, float *top_out, float *scratch2,
                          hipStream_t st);

@@ -11,12 +11,15 @@
 // mat-vec is issued as v_pk_fma_f32 (2 FMA per instruction, pairs along k), and nothing on the chain
 // touches HBM:
 //
-//   waves 0-2  "L0"   layer 0, step t = m        : W_ih0 x_t + W_hh0 h0_{t-1}  (28 pk_fma), cell update,
+//   waves 0-2  "L1"   layer 1, step t = m-2      : W_hh1 h1_{t-1} (24 pk_fma) + P_t, cell update
+//   waves 3-5  "L0"   layer 0, step t = m        : W_ih0 x_t + W_hh0 h0_{t-1}  (28 pk_fma), cell update,
 //                                                  dropout multiplier, h0 / masked h0 to LDS
-//   waves 3-5  "P"    layer-1 input projection of step t = m-1 : W_ih1 in1_t (24 pk_fma) -> LDS
-//   waves 6-8  "L1"   layer 1, step t = m-2      : W_hh1 h1_{t-1} (24 pk_fma) + P_t, cell update
+//   waves 6-8  "P"    layer-1 input projection of step t = m-1 : W_ih1 in1_t (24 pk_fma) -> LDS
+//   wave  9    "saver" (training) LDS save ring -> HBM, or "pool" (inference) attention pooling + head
+//   wave  10   "tpool" (training with the fused head only) attention pooling along the recurrence + the head's
+//                      forward / loss / backward in the kernel tail
 //
-// Thread (unit j, k-slice s) in every role: 4 gates x 12 (or 2) weights in VGPRs, operands broadcast from
+// Thread (unit j, k-slice s) in every chain role: 4 gates x 12 (or 2) weights in VGPRs, operands broadcast from
 // LDS, DPP quad reduction, lane s of the quad evaluates gate s.  One barrier per step.  x and the dropout
 // multipliers are staged through LDS in 32-step chunks, prefetched one chunk ahead.
 #include "nsd_args.h"
@@ -36,6 +39,10 @@ constexpr int SREC = 384;                 // floats per (layer, step): gates[192
 constexpr int SREC4 = SREC / 4;           // 96
 constexpr int SRING = 16;                 // steps kept in LDS (two 8-step chunks)
 constexpr int SCH = 8;
+// fused train head limits (larger shapes use the separate head kernel)
+constexpr int TT_TMAX = 1024, TT_KMAX = 8, TT_W0S = 49;
+constexpr int NT_TRAIN = 704;             // 11 waves
+constexpr int TT_PARTS = NT_TRAIN / 48;   // 14
 
 template <int NB>
 struct FSmem {
@@ -48,9 +55,20 @@ struct FSmem {
     float sv[SRING][NB][2][SREC];
     float pk[NB][8];             // inference tail: softmax numerators of the chunk being pooled
     float vec[NB][64];           // inference tail: LayerNorm output / activated fc.0 output
+    // fused train head (head_train): raw attention scores of the trial, staged head weights, small vectors
+    float sc[TT_TMAX];
+    float w0[64 * TT_W0S];       // fc.0 weight rows, stride 49 (odd: lane f reads row f without bank conflicts)
+    float w3[TT_KMAX * 64];
+    float vln[64], vx[64], vz[64], vdz[64], vdl[64], dp[64];
+    float md[4];                 // {running max, 1/denominator}
+    float red[16];
+    float part[TT_PARTS][H];
 };
 
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int NB>
+__device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b);
 
 // 12 operands of a k-slice from LDS as 6 pairs
 __device__ __forceinline__ void load_slice(const float *p, f32x2 (&v)[6]) {
@@ -185,6 +203,7 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
             }
         }
         step_barrier<false>(prof);      // the saver wave has drained the save ring of this trial group
+        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, b0);
     }
     prof_store(a.dbg, prof);
 }
@@ -231,6 +250,7 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
           }
         }
         step_barrier<false>(prof);      // save ring drained
+        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, grp * NB);
     }
     prof_store(a.dbg, prof);
 }
@@ -305,6 +325,7 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
           }
         }
         step_barrier<false>(prof);      // save ring drained
+        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, grp * NB);
     }
     prof_store(a.dbg, prof);
 }
@@ -382,7 +403,9 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
             step_barrier<false>(prof);
         }
         flush(n_steps / SCH - 1, b0, 0, SPIECES);          // last chunk (its LDS image is complete: barrier above)
+        if (a.head_train) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail reads the top rows back
         step_barrier<false>(prof);                          // keep the ring intact until it has been read
+        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, b0);
     }
     prof_store(a.dbg, prof);
 }
@@ -476,8 +499,226 @@ __device__ __forceinline__ void pool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, 
     prof_store(a.dbg, prof);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fused TRAIN head (head_train): what nsd_head.hip's head_train_kernel does in a second launch
+// (lstm_eeg_model.py:35-39 forward, mean cross-entropy, and the backward of both down to dL/dscore_t and dL/dpooled).
+//   * wave 10 ("tpool") pools along the recurrence like the inference tail (online softmax over 8-step chunks) and
+//     keeps the raw scores of the trial in LDS; after the last step it runs LayerNorm, fc.0 -> RReLU -> dropout ->
+//     fc.3, the loss and the dense backward by itself (vectors of <= 64: one wave, weights staged in LDS);
+//   * then ALL waves compute alpha_t, dL/dscore_t = alpha_t (dpooled . top_t - sum_s alpha_s dpooled . top_s) and
+//     d attn.weight = sum_t dscore_t top_t from the top rows the saver wave has just written (L2-resident).
+// Per-trial gradient slab and outputs: exactly those of HeadArgs (nsd_args.h).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tail_block_sum(float v, float *red, const int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT_TRAIN / 64; ++w) s += red[w];
+    __syncthreads();
+    return s;
+}
+
+// every wave of the workgroup calls this after the ring-drain barrier of trial b (the barrier also published the
+// tpool wave's LDS vectors and, with the saver's vmcnt(0), the top rows in memory)
 template <int NB>
-__global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
+__device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b) {
+    const int T = a.T;
+    const float *top = a.top + (size_t)b * T * H;
+    const float mx = sm.md[0], rden = sm.md[1];
+    float al[2], dd[2];
+    float lsd = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int t = tid + q * NT_TRAIN;
+        al[q] = 0.f; dd[q] = 0.f;
+        if (t < T) {
+            al[q] = __expf(sm.sc[t] - mx) * rden;
+            const float4 *row = reinterpret_cast<const float4 *>(top + (size_t)t * H);
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll 3                                               // (the role's weights stay live across the tail: keep it lean)
+            for (int j4 = 0; j4 < H / 4; ++j4) {
+                const float4 v = row[j4];
+                const float4 p = *reinterpret_cast<const float4 *>(&sm.dp[4 * j4]);
+                d0 = fmaf(v.x, p.x, d0); d1 = fmaf(v.y, p.y, d1); d0 = fmaf(v.z, p.z, d0); d1 = fmaf(v.w, p.w, d1);
+            }
+            dd[q] = d0 + d1;
+            lsd = fmaf(al[q], dd[q], lsd);
+        }
+    }
+    const float sdot = tail_block_sum(lsd, sm.red, tid);
+    float lb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int t = tid + q * NT_TRAIN;
+        if (t < T) {
+            const float ds = al[q] * (dd[q] - sdot);
+            a.alpha[(size_t)b * T + t] = al[q];
+            a.dscore[(size_t)b * T + t] = ds;
+            *reinterpret_cast<float4 *>(a.adpack + ((size_t)b * T + t) * 4) = make_float4(al[q], ds, 0.f, 0.f);
+            sm.sc[t] = ds;                                   // the raw score is no longer needed
+            lb += ds;
+        }
+    }
+    const float dab = tail_block_sum(lb, sm.red, tid);       // (its barriers also publish sc[] = dscore)
+    float *slab = a.hslabs + (size_t)b * a.Ph;
+    if (tid == 0) slab[a.o_attn_b] = dab;
+    // d attn.weight[j] = sum_t dscore_t top_t[j]: thread (j, part) sums the steps t == part (mod 14)
+    if (tid < TT_PARTS * H) {
+        const int part = tid / H, j = tid - part * H;
+        float s0 = 0.f, s1 = 0.f;
+        int t = part;
+        for (; t + TT_PARTS < T; t += 2 * TT_PARTS) {
+            s0 = fmaf(sm.sc[t], top[(size_t)t * H + j], s0);
+            s1 = fmaf(sm.sc[t + TT_PARTS], top[(size_t)(t + TT_PARTS) * H + j], s1);
+        }
+        if (t < T) s0 = fmaf(sm.sc[t], top[(size_t)t * H + j], s0);
+        sm.part[part][j] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < H) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < TT_PARTS; ++p) s += sm.part[p][tid];
+        slab[a.o_attn_w + tid] = s;
+    }
+    __syncthreads();                                          // sc / part / red are reused by the next trial
+}
+
+template <int NB>
+__device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int lane, const int n_steps) {
+    static_assert(NB == 1, "the fused head is built for one trial per workgroup");
+    const int T = a.T, K = a.K, F = a.F;
+    const int kq = lane >> 3, part = lane & 7;            // scores: 8 steps x 8 parts of 6 units
+    float awp[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) awp[u] = a.attn_w[6 * part + u];
+    const float ab = a.attn_b[0];
+    // head weights: staged once per workgroup (LDS), per-lane vectors in registers
+    for (int e = lane; e < F * H; e += 64) { const int f = e / H; sm.w0[f * TT_W0S + (e - f * H)] = a.fc0_w[e]; }
+    for (int e = lane; e < K * F; e += 64) sm.w3[e] = a.fc3_w[e];
+    const float lnw = lane < H ? a.ln_w[lane] : 0.f, lnb = lane < H ? a.ln_b[lane] : 0.f;
+    const float b0v = lane < F ? a.fc0_b[lane] : 0.f, b3v = lane < K ? a.fc3_b[lane] : 0.f;
+    Prof prof = prof_init(a.dbg);
+    const int ngrp = (a.B + NB - 1) / NB;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b = grp;
+        // per-trial scalars, fetched while the recurrence runs
+        const float sl_f = (lane < F && a.rrelu_slope) ? a.rrelu_slope[(size_t)b * F + lane] : a.eval_slope;
+        const float mk_f = (lane < F && a.drop_head) ? a.drop_head[(size_t)b * F + lane] : 1.f;
+        const int label = a.labels[b];
+        float mrun = -INFINITY, den = 0.f, pooled = 0.f;     // pooled: lane j < 48
+        auto pool_chunk = [&](const int chunk) {
+            const int t = SCH * chunk + kq - 2;               // layer-1 time index of ring slot kq of this chunk
+            const float *rec = &sm.sv[(chunk & 1) * SCH + kq][0][1][288];
+            float sc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) sc = fmaf(awp[u], rec[6 * part + u], sc);
+            sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 4, 64);
+            const bool ok = (unsigned)t < (unsigned)T;
+            sc = ok ? sc + ab : -INFINITY;
+            if (ok && part == 0) sm.sc[t] = sc;
+            float cm = sc;
+            cm = fmaxf(cm, __shfl_xor(cm, 8, 64)); cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            const float mnew = fmaxf(mrun, cm);
+            if (mnew == -INFINITY) return;                    // nothing valid yet (wave-uniform)
+            const float pkv = ok ? __expf(sc - mnew) : 0.f;
+            const float scale = __expf(mrun - mnew);          // exp(-inf) = 0 on the first valid chunk
+            float ps = pkv;
+            ps += __shfl_xor(ps, 8, 64); ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
+            den = fmaf(den, scale, ps);
+            mrun = mnew;
+            if (part == 0) sm.pk[0][kq] = pkv;
+            float acc = pooled * scale;                       // same wave: the LDS queue is in order, the reads see pk
+            if (lane < H) {
+#pragma unroll
+                for (int k = 0; k < SCH; ++k) acc = fmaf(sm.pk[0][k], sm.sv[(chunk & 1) * SCH + k][0][1][288 + lane], acc);
+            }
+            pooled = acc;
+        };
+        step_barrier<false>(prof);
+        for (int m0 = 0; m0 < n_steps; m0 += SCH) {
+            const int done = m0 / SCH - 1;
+            if (done >= 0) pool_chunk(done);
+#pragma unroll
+            for (int k = 0; k < SCH; ++k) step_barrier<false>(prof);
+        }
+        pool_chunk(n_steps / SCH - 1);
+        // ---- forward of the dense head (same formulas as head_train_kernel) ----
+        const bool vb = b < a.B;
+        const float rden = 1.0f / den;
+        const float p = lane < H ? pooled * rden : 0.f;
+        if (lane < H && vb) a.pooled[(size_t)b * H + lane] = p;
+        const float mu = wave_sum(p) * (1.0f / H);
+        const float dlt = lane < H ? p - mu : 0.f;
+        const float rstd = 1.0f / sqrtf(wave_sum(dlt * dlt) * (1.0f / H) + 1e-5f);
+        const float xh = dlt * rstd;
+        const float ln = fmaf(xh, lnw, lnb);
+        if (lane < H) { sm.vx[lane] = xh; sm.vln[lane] = ln; }
+        float pre = 0.f, z = 0.f;                             // (same wave: LDS queue in order, no barrier needed)
+        if (lane < F) {
+            float acc = b0v;
+            const float *w = &sm.w0[lane * TT_W0S];
+#pragma unroll 8
+            for (int j = 0; j < H; ++j) acc = fmaf(w[j], sm.vln[j], acc);
+            pre = acc;
+            if (vb) a.fc0_pre[(size_t)b * F + lane] = acc;
+            z = (acc >= 0.f ? acc : acc * sl_f) * mk_f;
+            sm.vz[lane] = z;
+        }
+        float lg = -INFINITY;
+        if (lane < K) {
+            float acc = b3v;
+            for (int f = 0; f < F; ++f) acc = fmaf(sm.w3[lane * F + f], sm.vz[f], acc);
+            lg = acc;
+            if (vb) a.logits[(size_t)b * K + lane] = acc;
+        }
+        // ---- mean cross-entropy: dlogits = (softmax - onehot) * scale, without cancellation for the label ----
+        const float m2 = wave_max(lg);
+        const float e = lane < K ? expf(lg - m2) : 0.f;
+        const float d = wave_sum(e);
+        const float rest = wave_sum(lane == label ? 0.f : e);
+        const float dl = (lane == label ? -rest / d : e / d) * a.scale;
+        if (lane < K) sm.vdl[lane] = dl;
+        if (lane == label && vb) a.loss[b] = -((lg - m2) - logf(d));
+        // ---- backward of the dense head ----
+        float *slab = a.hslabs + (size_t)b * a.Ph;
+        float dz = 0.f;
+        if (lane < F) {
+            for (int k = 0; k < K; ++k) dz = fmaf(sm.w3[k * F + lane], sm.vdl[k], dz);
+            dz *= mk_f;
+            dz = pre >= 0.f ? dz : dz * sl_f;
+            sm.vdz[lane] = dz;
+            if (vb) slab[a.o_fc0_b + lane] = dz;
+        }
+        if (vb) {
+            for (int e2 = lane; e2 < K * F; e2 += 64) slab[a.o_fc3_w + e2] = sm.vdl[e2 / F] * sm.vz[e2 % F];
+            if (lane < K) slab[a.o_fc3_b + lane] = dl;
+            for (int e2 = lane; e2 < F * H; e2 += 64) { const int f = e2 / H; slab[a.o_fc0_w + e2] = sm.vdz[f] * sm.vln[e2 - f * H]; }
+        }
+        float dxh = 0.f;
+        if (lane < H) {
+            float dv = 0.f;
+            for (int f = 0; f < F; ++f) dv = fmaf(sm.w0[f * TT_W0S + lane], sm.vdz[f], dv);
+            if (vb) { slab[a.o_ln_w + lane] = dv * xh; slab[a.o_ln_b + lane] = dv; }
+            dxh = dv * lnw;
+        }
+        const float m1 = wave_sum(dxh) * (1.0f / H);
+        const float m2b = wave_sum(dxh * xh) * (1.0f / H);
+        const float dpl = lane < H ? rstd * (dxh - m1 - xh * m2b) : 0.f;
+        sm.dp[lane] = dpl;
+        if (lane < H && vb) a.dpooled[(size_t)b * H + lane] = dpl;
+        if (lane == 0) { sm.md[0] = mrun; sm.md[1] = rden; }
+        step_barrier<false>(prof);                             // ring drained; publishes dp / md / sc
+        train_tail<NB>(a, sm, threadIdx.x, b);
+    }
+    prof_store(a.dbg, prof);
+}
+
+template <int NB, int NTH>
+__global__ __launch_bounds__(NTH) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
     __shared__ __align__(16) FSmem<NB> sm;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -488,8 +729,12 @@ __global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
     if (wave < 3)      { __builtin_amdgcn_s_setprio(3); l1_role<NB>(a, sm, tid, n_steps); }
     else if (wave < 6) { __builtin_amdgcn_s_setprio(2); l0_role<NB>(a, sm, tid - 192, n_steps); }
     else if (wave < 9) { __builtin_amdgcn_s_setprio(1); p_role<NB>(a, sm, tid - 384, n_steps); }
-    else if (a.logits_out) pool_role<NB>(a, sm, tid & 63, n_steps);
-    else               saver_role<NB>(a, sm, tid & 63, n_steps);
+    else if (wave == 9) {
+        if (a.logits_out) pool_role<NB>(a, sm, tid & 63, n_steps);
+        else              saver_role<NB>(a, sm, tid & 63, n_steps);
+    } else {
+        tpool_role<NB>(a, sm, tid & 63, n_steps);             // NTH == NT_TRAIN only
+    }
 }
 
 }  // namespace
@@ -497,7 +742,17 @@ __global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
 int nsd_lstm2_fwd48_launch(const Lstm2FwdArgs &a, int nb, int grid, hipStream_t st) {
     // one trial per workgroup: the save ring and the register budget are sized for NB = 1; larger batches loop
     if (nb != 1) { nsd_set_error("lstm2_fwd48: NB=%d not built", nb); return NSD_E_INVALID; }
-    hipLaunchKernelGGL((lstm2_fwd48_kernel<1>), dim3(grid), dim3(NT), 0, st, a);
+    if (a.head_train) {
+        if (!nsd_lstm2_fwd48_head_train_fits(a.T, a.F, a.K) || !a.top || a.logits_out) {
+            nsd_set_error("lstm2_fwd48: fused train head needs T<=%d, F<=64, K<=%d and the training workspace", TT_TMAX, TT_KMAX);
+            return NSD_E_INVALID;
+        }
+        hipLaunchKernelGGL((lstm2_fwd48_kernel<1, NT_TRAIN>), dim3(grid), dim3(NT_TRAIN), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((lstm2_fwd48_kernel<1, NT>), dim3(grid), dim3(NT), 0, st, a);
+    }
     NSD_CHECK_LAUNCH("lstm2_fwd48");
     return NSD_OK;
 }
+
+bool nsd_lstm2_fwd48_head_train_fits(int T, int F, int K) { return T <= TT_TMAX && F <= 64 && K <= TT_KMAX && F >= 1 && K >= 1; }

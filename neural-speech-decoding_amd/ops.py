@@ -223,9 +223,11 @@ def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: tor
 
 def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: torch.Tensor, labels: torch.Tensor,
                      logits: torch.Tensor, grads: torch.Tensor, *, scale: Optional[float] = None, drop_lstm=None,
-                     rrelu_slope=None, drop_head=None, residual: bool = False, adam: Optional[dict] = None) -> None:
-    """The four launches of one training evaluation: lstm fwd, fused head (fwd + mean CE + bwd), lstm bwd, slab
-    reduce -> `grads` (flat, overwritten).  `logits` [B,K] is an output buffer.
+                     rrelu_slope=None, drop_head=None, residual: bool = False, adam: Optional[dict] = None,
+                     fused_head: bool = True) -> None:
+    """The launches of one training evaluation: lstm fwd + head (fwd, mean CE, bwd) in one launch where the shape allows
+    (nsd_lstm_head_train; fused_head=False forces the two separate launches), lstm bwd, slab reduce -> `grads` (flat,
+    overwritten).  `logits` [B,K] is an output buffer.
 
     adam=dict(m=, v=, step=, lr=, beta1=, beta2=, eps=, weight_decay=): single-rank training -- the optimizer update of
     `flat` rides in the reduction launch (nsd_grad_reduce_adam); `grads` is still written."""
@@ -238,8 +240,12 @@ def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: t
     scale = (1.0 / max(B, 1)) if scale is None else float(scale)
     xp, wsp, st = _dev_f32(x, "x", (B, T, spec.C)), _dev_f32(ws, "workspace"), _stream()
     dl, sl, dh = _dev_f32(drop_lstm, "drop_lstm"), _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head")
-    _call("nsd_lstm_fwd", C.byref(d), pp, xp, dl, flags, wsp, st)
-    _call("nsd_head_train", C.byref(d), pp, sl, dh, labels.data_ptr(), scale, wsp, _dev_f32(logits, "logits", (B, spec.K)), st)
+    lp = _dev_f32(logits, "logits", (B, spec.K))
+    if fused_head:
+        _call("nsd_lstm_head_train", C.byref(d), pp, xp, dl, sl, dh, labels.data_ptr(), scale, flags, wsp, lp, st)
+    else:
+        _call("nsd_lstm_fwd", C.byref(d), pp, xp, dl, flags, wsp, st)
+        _call("nsd_head_train", C.byref(d), pp, sl, dh, labels.data_ptr(), scale, wsp, lp, st)
     _call("nsd_lstm_bwd", C.byref(d), pp, xp, dl, flags, wsp, None, st)
     gp = _dev_f32(grads, "grads", (spec.param_count,))
     if adam is None:

@@ -61,6 +61,7 @@ class Trainer:
         self.reducer = FlatGradAllReducer(group)
         self.rank = dist.get_rank(group) if self.reducer.world > 1 else 0
         self.world = self.reducer.world
+        self.fused_head = True           # nsd_lstm_head_train (one launch) where the shape allows; False: two launches
         self.seed = (int(seed) + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF
         self.stochastic = stochastic
         self.step_count = 0
@@ -117,11 +118,11 @@ class Trainer:
         if self.world == 1:
             # no exchange step between reduction and update: one launch does both
             ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
-                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual,
+                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual, fused_head=self.fused_head,
                                  adam=dict(m=self.m, v=self.v, **hyper))
         else:
             ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
-                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual)
+                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual, fused_head=self.fused_head)
             self.reducer(self.grads)
             ops.adam_step(self.flat, self.grads, self.m, self.v, **hyper)
         self._last_B, self._last_T = B, T

@@ -152,6 +152,48 @@ def _hip_loss_grads(nsd, dev, flat_np, x, y, spec=None, scale=None, **masks):
     return loss, g.cpu().numpy(), logits.cpu().numpy()
 
 
+def _hip_step(nsd, dev, flat_np, x, y, fused_head, residual=False, **masks):
+    """ops.train_step_grads (the launch sequence of Trainer.step) -> loss, grads, logits and the head's workspace outputs."""
+    from nsd_amd import ops
+    spec = ops.ModelSpec()
+    B, T, _ = x.shape
+    flat, xt = _t(flat_np, dev), _t(x, dev)
+    ws = ops.new_workspace(spec, B, T, dev)
+    ws.fill_(float("nan"))                                   # nothing may be left unwritten
+    logits = torch.full((B, spec.K), float("nan"), device=dev)
+    grads = torch.empty_like(flat)
+    mk = {k: _t(v, dev) for k, v in masks.items()}
+    ops.train_step_grads(spec, flat, xt, ws, _t(y.astype(np.int32), dev), logits, grads, residual=residual, fused_head=fused_head, **mk)
+    out = {r: ops.ws_view(ws, spec, B, T, r).cpu().numpy().copy() for r in ("alpha", "pooled", "fc0_pre", "dscore", "dpooled", "loss")}
+    out["logits"] = logits.cpu().numpy()
+    out["grads"] = grads.cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize("B,T,residual", [(1, 1, False), (3, 2, False), (32, 250, False), (7, 625, False), (300, 33, False),
+                                          (13, 64, True), (2, 1024, False)])
+def test_single_launch_lstm_plus_head_train(nsd, dev, ref_state, B, T, residual):
+    """nsd_lstm_head_train (pooling along the recurrence, head fwd/loss/bwd in the LSTM kernel's tail) == the two
+    launches it replaces == the oracle, on every output of the head."""
+    flat_np = orc.flatten_state(ref_state, D)
+    x, y = synth_x(B, T, seed=3 * B + T), synth_labels(B, seed=B + 2 * T)
+    dl, sl, dh = counter_masks(B, T, 48, 32, seed=11 * B + T)
+    masks = dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    a = _hip_step(nsd, dev, flat_np, x, y, True, residual=residual, **masks)
+    b = _hip_step(nsd, dev, flat_np, x, y, False, residual=residual, **masks)
+    for k in ("logits", "alpha", "pooled", "fc0_pre", "loss"):
+        assert np.isfinite(a[k]).all(), k
+        assert np.abs(a[k] - b[k]).max() <= 2e-5 * max(1.0, np.abs(b[k]).max()), k
+    for k in ("dscore", "dpooled"):
+        assert np.abs(a[k] - b[k]).max() <= 1e-4 * np.abs(b[k]).max() + 1e-9, k
+    _grad_close(a["grads"], b["grads"], D, rtol=2e-4)
+    if not residual and B * T <= 8000:
+        loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, D, **masks)
+        assert np.abs(a["logits"] - fw["logits"]).max() < LOGIT_TOL
+        assert abs(float(a["loss"].sum()) / B - loss_ref) < 5e-5
+        _grad_close(a["grads"], g_ref, D, rtol=3e-4)
+
+
 def test_gradients_vs_reference_goldens(nsd, dev, golden, ref_state):
     g = golden("grads_32x250")
     flat_np = orc.flatten_state(ref_state, D)

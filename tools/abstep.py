@@ -33,17 +33,18 @@ def main():
     x = (2.7 * torch.randn(args.B, args.T, 8, generator=g)).to(dev)
     y = torch.randint(0, 3, (args.B,), generator=g).to(torch.int32).to(dev)
 
-    def make(split_adam):
+    def make(split_adam, fused_head=True):
         m = nsd_amd.EEG_LSTM()
         m.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files})
         m.to(dev).train()
         tr = Trainer(m, lr=1e-3, seed=1)
         if split_adam:
             tr.world = 2                      # takes the multi-rank launch sequence; the reducer itself is a no-op at world 1
-            tr_scale = tr.step
+        tr.fused_head = fused_head
         return tr
 
-    variants = {"step (fused reduce+adam)": make(False), "step (separate adam)": make(True)}
+    variants = {"step (shipped)": make(False), "step (separate adam)": make(True),
+                "step (separate head launch)": make(False, fused_head=False)}
     host = {}
     for name, tr in variants.items():
         for _ in range(20):
