@@ -66,16 +66,40 @@ __device__ __forceinline__ float gate_act(float x, float a, float b, float c) {
     return fmaf(a, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(b * x)), c);
 }
 
-// wave64 reductions (all lanes get the result)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+// wave64 reductions (all lanes get the result): DPP inside a row of 16 lanes (quad xor 1/2, half-row mirror, row
+// mirror -- each an all-reduce step because both partners end up with the same value), then the four row totals
+// through v_readlane.  No LDS crossbar (ds_bpermute) on the way: ~10 short instructions instead of 6 LDS round trips.
+__device__ __forceinline__ float rows_combine_sum(float v) {      // v uniform inside each row of 16
+    const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float a3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a0 + a1) + (a2 + a3);
+}
+__device__ __forceinline__ float rows_combine_max(float v) {
+    const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float a3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+}
+__device__ __forceinline__ float oct_sum(float v) {               // all-reduce over aligned groups of 8 lanes
+    v += quad_xor1(v);
+    v += quad_xor2(v);
+    v += dpp_quad<0x141>(v);                                      // row_half_mirror: lane i <-> 7 - i
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    v = oct_sum(v);
+    v += dpp_quad<0x140>(v);                                      // row_mirror: lane i <-> 15 - i
+    return rows_combine_sum(v);
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, quad_xor1(v));
+    v = fmaxf(v, quad_xor2(v));
+    v = fmaxf(v, dpp_quad<0x141>(v));
+    v = fmaxf(v, dpp_quad<0x140>(v));
+    return rows_combine_max(v);
 }
 
 // counter-based random stream shared bit-for-bit with oracle/nsd_oracle.c (nsd_oracle_rand_u32)

@@ -411,6 +411,88 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
 }
 
 // ------------------------------------------------------------------------------------------------
+// attention pooling over time as an ONLINE softmax over the layer-1 records of the save ring, one 8-step chunk behind
+// the chain (running max, denominator, weighted sum in lane j).  The update of a chunk is a long dependent sequence
+// (dot products, three reductions, two exponentials, the weighted sum), and this wave stands at the same step
+// barriers as the chains: done in one piece it stretched one step in eight.  So it is cut into four stages, one per
+// step, and every reduction is DPP / v_readlane (no LDS crossbar).  Lane = (kq = lane >> 3: step of the chunk,
+// part = lane & 7: 6 of the 48 units).
+// ------------------------------------------------------------------------------------------------
+struct PoolRun {
+    float awp[6], ab;
+    float mrun, den, pooled;        // running max, denominator, weighted sum (lane j < 48)
+    float sc, pkv, scale;           // chunk in flight
+    bool ok, skip;
+};
+template <int NB>
+__device__ __forceinline__ void pool_init(PoolRun &p, const Lstm2FwdArgs &a, const int lane) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) p.awp[u] = a.attn_w[6 * (lane & 7) + u];
+    p.ab = a.attn_b[0];
+}
+__device__ __forceinline__ void pool_reset(PoolRun &p) { p.mrun = -INFINITY; p.den = 0.f; p.pooled = 0.f; p.skip = true; }
+
+template <int STAGE, int NB>
+__device__ __forceinline__ void pool_stage(PoolRun &p, FSmem<NB> &sm, const int chunk, const int lane, const int T, float *sc_out) {
+    const int kq = lane >> 3, part = lane & 7;
+    if (STAGE == 0) {            // scores of the chunk's 8 steps
+        const int t = SCH * chunk + kq - 2;               // layer-1 time index of ring slot kq of this chunk
+        const float *rec = &sm.sv[(chunk & 1) * SCH + kq][0][1][288];
+        float sc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) sc = fmaf(p.awp[u], rec[6 * part + u], sc);
+        sc = oct_sum(sc);
+        p.ok = (unsigned)t < (unsigned)T;
+        p.sc = p.ok ? sc + p.ab : -INFINITY;
+        if (sc_out && p.ok && part == 0) sc_out[t] = p.sc;
+    } else if (STAGE == 1) {     // new running max, numerators
+        const float cm = rows_combine_max(fmaxf(p.sc, row_ror<8>(p.sc)));
+        const float mnew = fmaxf(p.mrun, cm);
+        p.skip = (mnew == -INFINITY);                     // nothing valid yet (wave-uniform)
+        if (p.skip) return;
+        p.pkv = p.ok ? __expf(p.sc - mnew) : 0.f;
+        p.scale = __expf(p.mrun - mnew);                  // exp(-inf) = 0 on the first valid chunk
+        p.mrun = mnew;
+    } else if (STAGE == 2) {     // denominator
+        if (p.skip) return;
+        const float ps = rows_combine_sum(p.pkv + row_ror<8>(p.pkv));
+        p.den = fmaf(p.den, p.scale, ps);
+        if (part == 0) sm.pk[0][kq] = p.pkv;
+    } else {                     // weighted sum of the 8 rows (pk was published by the barrier after stage 2)
+        if (p.skip) return;
+        float acc = p.pooled * p.scale;
+        if (lane < H) {
+#pragma unroll
+            for (int k = 0; k < SCH; ++k) acc = fmaf(sm.pk[0][k], sm.sv[(chunk & 1) * SCH + k][0][1][288 + lane], acc);
+        }
+        p.pooled = acc;
+    }
+}
+
+// the time loop of a pooling wave: one stage of chunk (m0/8 - 1) per step, then the last chunk in one go
+template <int NB>
+__device__ __forceinline__ void pool_loop(PoolRun &p, FSmem<NB> &sm, const int lane, const int T, const int n_steps, float *sc_out,
+                                          Prof &prof) {
+    for (int m0 = 0; m0 < n_steps; m0 += SCH) {
+        const int done = m0 / SCH - 1;
+        if (done >= 0) pool_stage<0, NB>(p, sm, done, lane, T, sc_out);
+        step_barrier<false>(prof);
+        if (done >= 0) pool_stage<1, NB>(p, sm, done, lane, T, sc_out);
+        step_barrier<false>(prof);
+        if (done >= 0) pool_stage<2, NB>(p, sm, done, lane, T, sc_out);
+        step_barrier<false>(prof);
+        if (done >= 0) pool_stage<3, NB>(p, sm, done, lane, T, sc_out);
+#pragma unroll
+        for (int k = 3; k < SCH; ++k) step_barrier<false>(prof);
+    }
+    const int last = n_steps / SCH - 1;
+    pool_stage<0, NB>(p, sm, last, lane, T, sc_out);
+    pool_stage<1, NB>(p, sm, last, lane, T, sc_out);
+    pool_stage<2, NB>(p, sm, last, lane, T, sc_out);
+    pool_stage<3, NB>(p, sm, last, lane, T, sc_out);     // same wave: the LDS queue is in order, the reads see pk
+}
+
+// ------------------------------------------------------------------------------------------------
 // inference tail (wave 9 when logits_out != null): lstm_eeg_model.py:35-39 and the class softmax of :97 fused into
 // the LSTM kernel.  Attention pooling over time runs as an ONLINE softmax over the layer-1 records of the save ring,
 // one 8-step chunk behind the chain (running max m, denominator, weighted sum in lane j); the [T,H] sequence is
@@ -420,51 +502,16 @@ template <int NB>
 __device__ __forceinline__ void pool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int lane, const int n_steps) {
     static_assert(NB == 1, "inference tail is built for one trial per workgroup");
     const int T = a.T, K = a.K, F = a.F;
-    const int kq = lane >> 3, part = lane & 7;            // scores: 8 steps x 8 parts of 6 units
-    float awp[6];
-#pragma unroll
-    for (int u = 0; u < 6; ++u) awp[u] = a.attn_w[6 * part + u];
-    const float ab = a.attn_b[0];
+    PoolRun pr;
+    pool_init<NB>(pr, a, lane);
     Prof prof = prof_init(a.dbg);
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b = grp;
-        float mrun = -INFINITY, den = 0.f, pooled = 0.f;     // pooled: lane j < 48
-        auto pool_chunk = [&](const int chunk) {
-            const int t = SCH * chunk + kq - 2;               // layer-1 time index of ring slot kq of this chunk
-            const float *rec = &sm.sv[(chunk & 1) * SCH + kq][0][1][288];
-            float sc = 0.f;
-#pragma unroll
-            for (int u = 0; u < 6; ++u) sc = fmaf(awp[u], rec[6 * part + u], sc);
-            sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 4, 64);
-            const bool ok = (unsigned)t < (unsigned)T;
-            sc = ok ? sc + ab : -INFINITY;
-            float cm = sc;
-            cm = fmaxf(cm, __shfl_xor(cm, 8, 64)); cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-            const float mnew = fmaxf(mrun, cm);
-            if (mnew == -INFINITY) return;                    // nothing valid yet (wave-uniform)
-            const float pkv = ok ? __expf(sc - mnew) : 0.f;
-            const float scale = __expf(mrun - mnew);          // exp(-inf) = 0 on the first valid chunk
-            float ps = pkv;
-            ps += __shfl_xor(ps, 8, 64); ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
-            den = fmaf(den, scale, ps);
-            mrun = mnew;
-            if (part == 0) sm.pk[0][kq] = pkv;
-            float acc = pooled * scale;                       // same wave: the LDS queue is in order, the reads see pk
-            if (lane < H) {
-#pragma unroll
-                for (int k = 0; k < SCH; ++k) acc = fmaf(sm.pk[0][k], sm.sv[(chunk & 1) * SCH + k][0][1][288 + lane], acc);
-            }
-            pooled = acc;
-        };
+        pool_reset(pr);
         step_barrier<false>(prof);
-        for (int m0 = 0; m0 < n_steps; m0 += SCH) {
-            const int done = m0 / SCH - 1;
-            if (done >= 0) pool_chunk(done);
-#pragma unroll
-            for (int k = 0; k < SCH; ++k) step_barrier<false>(prof);
-        }
-        pool_chunk(n_steps / SCH - 1);
+        pool_loop<NB>(pr, sm, lane, T, n_steps, nullptr, prof);
+        const float pooled = pr.pooled, den = pr.den;
         // ---- LayerNorm (biased variance, eps in the sqrt), fc.0 -> RReLU(eval) -> fc.3, softmax over classes ----
         const float p = lane < H ? pooled / den : 0.f;
         const float mu = wave_sum(p) * (1.0f / H);
@@ -526,6 +573,7 @@ __device__ __forceinline__ float tail_block_sum(float v, float *red, const int t
 template <int NB>
 __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b) {
     const int T = a.T;
+    if (a.ablate & 256) return;
     const float *top = a.top + (size_t)b * T * H;
     const float mx = sm.md[0], rden = sm.md[1];
     float al[2], dd[2];
@@ -591,11 +639,8 @@ template <int NB>
 __device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int lane, const int n_steps) {
     static_assert(NB == 1, "the fused head is built for one trial per workgroup");
     const int T = a.T, K = a.K, F = a.F;
-    const int kq = lane >> 3, part = lane & 7;            // scores: 8 steps x 8 parts of 6 units
-    float awp[6];
-#pragma unroll
-    for (int u = 0; u < 6; ++u) awp[u] = a.attn_w[6 * part + u];
-    const float ab = a.attn_b[0];
+    PoolRun pr;
+    pool_init<NB>(pr, a, lane);
     // head weights: staged once per workgroup (LDS), per-lane vectors in registers
     for (int e = lane; e < F * H; e += 64) { const int f = e / H; sm.w0[f * TT_W0S + (e - f * H)] = a.fc0_w[e]; }
     for (int e = lane; e < K * F; e += 64) sm.w3[e] = a.fc3_w[e];
@@ -609,45 +654,12 @@ __device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
         const float sl_f = (lane < F && a.rrelu_slope) ? a.rrelu_slope[(size_t)b * F + lane] : a.eval_slope;
         const float mk_f = (lane < F && a.drop_head) ? a.drop_head[(size_t)b * F + lane] : 1.f;
         const int label = a.labels[b];
-        float mrun = -INFINITY, den = 0.f, pooled = 0.f;     // pooled: lane j < 48
-        auto pool_chunk = [&](const int chunk) {
-            const int t = SCH * chunk + kq - 2;               // layer-1 time index of ring slot kq of this chunk
-            const float *rec = &sm.sv[(chunk & 1) * SCH + kq][0][1][288];
-            float sc = 0.f;
-#pragma unroll
-            for (int u = 0; u < 6; ++u) sc = fmaf(awp[u], rec[6 * part + u], sc);
-            sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 4, 64);
-            const bool ok = (unsigned)t < (unsigned)T;
-            sc = ok ? sc + ab : -INFINITY;
-            if (ok && part == 0) sm.sc[t] = sc;
-            float cm = sc;
-            cm = fmaxf(cm, __shfl_xor(cm, 8, 64)); cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-            const float mnew = fmaxf(mrun, cm);
-            if (mnew == -INFINITY) return;                    // nothing valid yet (wave-uniform)
-            const float pkv = ok ? __expf(sc - mnew) : 0.f;
-            const float scale = __expf(mrun - mnew);          // exp(-inf) = 0 on the first valid chunk
-            float ps = pkv;
-            ps += __shfl_xor(ps, 8, 64); ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
-            den = fmaf(den, scale, ps);
-            mrun = mnew;
-            if (part == 0) sm.pk[0][kq] = pkv;
-            float acc = pooled * scale;                       // same wave: the LDS queue is in order, the reads see pk
-            if (lane < H) {
-#pragma unroll
-                for (int k = 0; k < SCH; ++k) acc = fmaf(sm.pk[0][k], sm.sv[(chunk & 1) * SCH + k][0][1][288 + lane], acc);
-            }
-            pooled = acc;
-        };
+        pool_reset(pr);
         step_barrier<false>(prof);
-        for (int m0 = 0; m0 < n_steps; m0 += SCH) {
-            const int done = m0 / SCH - 1;
-            if (done >= 0) pool_chunk(done);
-#pragma unroll
-            for (int k = 0; k < SCH; ++k) step_barrier<false>(prof);
-        }
-        pool_chunk(n_steps / SCH - 1);
+        pool_loop<NB>(pr, sm, lane, T, n_steps, sm.sc, prof);
+        const float pooled = pr.pooled, den = pr.den, mrun = pr.mrun;
         // ---- forward of the dense head (same formulas as head_train_kernel) ----
-        const bool vb = b < a.B;
+        const bool vb = b < a.B && !(a.ablate & 512);
         const float rden = 1.0f / den;
         const float p = lane < H ? pooled * rden : 0.f;
         if (lane < H && vb) a.pooled[(size_t)b * H + lane] = p;

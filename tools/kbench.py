@@ -65,7 +65,15 @@ def main():
         ops.train_backward(spec, flat, x, ws, logits, labels=y, drop_lstm=dl)
         f_med, f_min = timed(lambda: L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, st), args.iters)
         b_med, b_min = timed(lambda: L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st), args.iters)
-        print(f"ablate={ab:3d}  B={B} T={T}  lstm_fwd {f_med:8.1f} us (min {f_min:.1f})   lstm_bwd {b_med:8.1f} us (min {b_min:.1f})", flush=True)
+        sl = ops.rrelu_noise(1, 1, (B, 32), dev); dh = ops.dropout_mask(1, 2, 0.6, (B, 32), dev)
+        lg = torch.empty(B, 3, device=dev)
+        if hasattr(L, "nsd_lstm_head_train"):
+            h_med, h_min = timed(lambda: L.nsd_lstm_head_train(C.byref(d), pp, xp, dlp, sl.data_ptr(), dh.data_ptr(), y.data_ptr(),
+                                                               1.0 / B, flags, wsp, lg.data_ptr(), st), args.iters)
+        else:
+            h_med = h_min = float("nan")
+        print(f"ablate={ab:3d}  B={B} T={T}  lstm_fwd {f_med:8.1f} us (min {f_min:.1f})   lstm_bwd {b_med:8.1f} us (min {b_min:.1f})   "
+              f"lstm_head_train {h_med:8.1f} us (min {h_min:.1f})", flush=True)
         if args.prof:
             for which in ("fwd", "bwd"):
                 dbg = torch.zeros(512, dtype=torch.int64, device=dev)
