@@ -28,6 +28,13 @@ constexpr int H = 48;
 constexpr int G4 = 192;
 constexpr int RING = 8;
 constexpr int NTHREADS = 1024;
+#ifndef NSD_DW_SLEEP
+#define NSD_DW_SLEEP 0
+#endif
+#ifndef NSD_LD_SLEEP
+#define NSD_LD_SLEEP 0
+#endif
+constexpr int DW_SLEEP = NSD_DW_SLEEP, LD_SLEEP = NSD_LD_SLEEP;   // post-barrier s_sleep of the waves off the critical path (step_barrier)
 constexpr int CHUNK = 8;            // macro steps per staged chunk of saved activations
 constexpr int REC = 288;            // floats per (layer, step) record: gates[192] | c[t-1][48] | aux[48]
 constexpr int REC4 = REC / 4;
@@ -319,14 +326,14 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
             // macro step 4G+0 : finish matrix 0 of group G-1, start fetching matrix 0 of group G; etc.
             if (G > 0 && !(a.ablate & 1)) dw_compute<0, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<0, NB>(a, st, G, b0, lane);
-            step_barrier<false>(prof);
+            step_barrier<false, DW_SLEEP>(prof);
             if (G > 0 && !(a.ablate & 1)) dw_compute<1, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<1, NB>(a, st, G, b0, lane);
-            step_barrier<false>(prof);
+            step_barrier<false, DW_SLEEP>(prof);
             if (G > 0 && !(a.ablate & 1)) dw_compute<2, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<2, NB>(a, st, G, b0, lane);
-            step_barrier<false>(prof);
-            step_barrier<false>(prof);
+            step_barrier<false, DW_SLEEP>(prof);
+            step_barrier<false, DW_SLEEP>(prof);
         }
     }
     prof_store(a.dbg, prof);
@@ -444,20 +451,20 @@ __device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm,
             const bool on = !(a.ablate & 16);
             // next chunk: 3 pieces per step during steps 0..5 (+ x rows at step 0); all landed before step 7 ends
             if (on) { loader_issue<NB, 0, 3>(a, sm, d, chunk + 1, nb, b0); loader_issue_x<NB>(a, sm, chunk + 1, nb, b0, lane); }
-            step_barrier<true>(prof);
+            step_barrier<true, LD_SLEEP>(prof);
             if (on) loader_issue<NB, 3, 6>(a, sm, d, chunk + 1, nb, b0);
-            step_barrier<true>(prof);
+            step_barrier<true, LD_SLEEP>(prof);
             if (on) loader_issue<NB, 6, 9>(a, sm, d, chunk + 1, nb, b0);
-            step_barrier<true>(prof);
+            step_barrier<true, LD_SLEEP>(prof);
             if (on) loader_issue<NB, 9, 12>(a, sm, d, chunk + 1, nb, b0);
-            step_barrier<true>(prof);
+            step_barrier<true, LD_SLEEP>(prof);
             if (on) loader_issue<NB, 12, 15>(a, sm, d, chunk + 1, nb, b0);
-            step_barrier<true>(prof);
+            step_barrier<true, LD_SLEEP>(prof);
             if (on) loader_issue<NB, 15, 18>(a, sm, d, chunk + 1, nb, b0);
-            step_barrier<true>(prof);
-            step_barrier<true>(prof);
+            step_barrier<true, LD_SLEEP>(prof);
+            step_barrier<true, LD_SLEEP>(prof);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            step_barrier<true>(prof);
+            step_barrier<true, LD_SLEEP>(prof);
         }
     }
     prof_store(a.dbg, prof);

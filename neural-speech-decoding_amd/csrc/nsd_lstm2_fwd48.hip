@@ -29,7 +29,7 @@ namespace {
 
 constexpr int H = 48;
 constexpr int KS = 12;
-constexpr int NT = 640;
+constexpr int NT = 768;      // 12 waves, 3 per SIMD (see the role table in the kernel)
 constexpr int XCH = 32;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ---- activations for the backward pass leave through LDS: a per-step record written by the chain lanes
@@ -39,10 +39,17 @@ constexpr int SREC = 384;                 // floats per (layer, step): gates[192
 constexpr int SREC4 = SREC / 4;           // 96
 constexpr int SRING = 16;                 // steps kept in LDS (two 8-step chunks)
 constexpr int SCH = 8;
+#ifndef NSD_P_SLEEP
+#define NSD_P_SLEEP 2
+#endif
+#ifndef NSD_S_SLEEP
+#define NSD_S_SLEEP 3
+#endif
+constexpr int P_SLEEP = NSD_P_SLEEP, S_SLEEP = NSD_S_SLEEP;   // see step_barrier
 // fused train head limits (larger shapes use the separate head kernel)
 constexpr int TT_TMAX = 1024, TT_KMAX = 8, TT_W0S = 49;
-constexpr int NT_TRAIN = 704;             // 11 waves
-constexpr int TT_PARTS = NT_TRAIN / 48;   // 14
+constexpr int NT_TRAIN = NT;
+constexpr int TT_PARTS = NT_TRAIN / 48;   // 16
 
 template <int NB>
 struct FSmem {
@@ -92,13 +99,35 @@ __device__ __forceinline__ float reduce_pick(const f32x2 (&acc)[4], const int s)
 }
 
 
-struct GateConst { float a, b, c; };
-__device__ __forceinline__ GateConst gate_const(const int s) {
-    GateConst k;
-    k.a = (s == 2) ? 2.f : 1.f;
-    k.b = (s == 2) ? -2.f * LOG2E_F : -LOG2E_F;
-    k.c = (s == 2) ? -1.f : 0.f;
-    return k;
+// ---- the step's dependent chain, kept as short as the arithmetic allows (every op on it costs ~10 cycles of every
+// step; instructions off it are free) ----
+//  * weights and biases are pre-multiplied by the exp2 argument scale of their gate (-log2e for sigma rows, -2 log2e
+//    for the tanh row), and the input projection + bias is the INITIAL value of the accumulator of the lane's own
+//    gate: the reduced sum is the exp2 argument itself;
+//  * the tanh lane (s == 2) returns KC * tanh with KC = -2 log2e, and the cell state is carried as cK = KC * c, so
+//    that exp2(cK) = e^(-2c) needs no multiply;  c and g are un-scaled off the chain for the saved activations;
+//  * i*g exists only in lane 2 (v_mul_f32_dpp with its own value), f*cK in all lanes, their sum is one
+//    v_add_f32_dpp;  h = o * (2r - 1) is one FMA with 2o and -o prepared while the cell waits.
+constexpr float KC = -2.f * LOG2E_F;
+constexpr float INV_KC = 1.f / KC;
+__host__ __device__ constexpr float gate_scale(const int g) { return g == 2 ? -2.f * LOG2E_F : -LOG2E_F; }
+
+struct CellOut { float gate, c, h; };     // gate: this lane's activation (un-scaled), c: new cell state, h: o * tanh(c) * hmul
+// arg: exp2 argument of this lane's gate; cK: scaled cell state (updated); hmul: multiplier folded into h (dropout)
+__device__ __forceinline__ CellOut cell_step(const float arg, float &cK, const int s, const float hmul) {
+    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
+    const float act = s == 2 ? fmaf(2.f * KC, r, -KC) : r;                 // lane 2: KC * tanh(pre)
+    const float o = quad_bcast<3>(act);
+    const float o2 = (2.f * hmul) * o, on = -hmul * o;                      // off the chain (the cell is still being formed)
+    const float igK = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(act), QP(0, 0, 0, 0), 0xF, 0xF, true)) * act;   // lane 2: i * KC g
+    const float fcK = quad_bcast<1>(act) * cK;
+    cK = quad_bcast<2>(igK) + fcK;
+    const float rc = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cK));
+    CellOut out;
+    out.h = fmaf(o2, rc, on);
+    out.c = cK * INV_KC;
+    out.gate = s == 2 ? act * INV_KC : act;
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -112,16 +141,17 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int row = g * H + j;
-        wx[g].x = (2 * s < C) ? a.w_ih0[(size_t)row * C + 2 * s] : 0.f;
-        wx[g].y = (2 * s + 1 < C) ? a.w_ih0[(size_t)row * C + 2 * s + 1] : 0.f;
+        const float gs = gate_scale(g);
+        wx[g].x = (2 * s < C) ? gs * a.w_ih0[(size_t)row * C + 2 * s] : 0.f;
+        wx[g].y = (2 * s + 1 < C) ? gs * a.w_ih0[(size_t)row * C + 2 * s + 1] : 0.f;
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            wh[g][q].x = a.w_hh0[(size_t)row * H + s * KS + 2 * q];
-            wh[g][q].y = a.w_hh0[(size_t)row * H + s * KS + 2 * q + 1];
+            wh[g][q].x = gs * a.w_hh0[(size_t)row * H + s * KS + 2 * q];
+            wh[g][q].y = gs * a.w_hh0[(size_t)row * H + s * KS + 2 * q + 1];
         }
     }
-    const float bias = a.b_ih0[s * H + j] + a.b_hh0[s * H + j];
-    const GateConst gk = gate_const(s);
+    const float biasK = (s == 2 ? gate_scale(2) : gate_scale(0)) * (a.b_ih0[s * H + j] + a.b_hh0[s * H + j]);
+    const int hslot = (s == 1) ? 0 : s;          // record slot this lane writes its h to (lanes 0 and 1: the same h twice)
     constexpr int XE = NB * XCH * 8;                 // x floats per chunk
     constexpr int XPT = (XE + 191) / 192;
     constexpr int MPT = NB * 2;                      // mask float4 per thread: XCH*H/4 = 384 per trial / 192 threads
@@ -176,20 +206,15 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                         f32x2 acc[4];
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            acc[g] = wx[g] * xv;
+                            acc[g] = pk_fma(wx[g], xv, (f32x2){g == s ? biasK : 0.f, 0.f});
 #pragma unroll
                             for (int q = 0; q < 6; ++q) acc[g] = pk_fma(wh[g][q], hv[q], acc[g]);
                         }
-                        const float pre = reduce_pick(acc, s) + bias;
-                        const float act = gate_act(pre, gk.a, gk.b, gk.c);
-                        const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act);
-                        const float gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
-                        c[n] = fmaf(fg, c[n], ig * gg);
-                        const float h = og * fast_tanh(c[n]);
-                        const float hm = h * mk;
+                        const CellOut o = cell_step(reduce_pick(acc, s), c[n], s, s == 2 ? mk : 1.f);   // lane 2: h * dropout multiplier
                         float *sr = &sm.sv[kr][n][0][0];
-                        sr[4 * j + s] = act;
-                        sr[192 + 48 * s + j] = s == 1 ? c[n] : s == 2 ? hm : h;       // slots: h | c | masked h | spare
+                        sr[192 + 48 * hslot + j] = o.h;                 // slots: h | c | masked h | spare (h again)
+                        sr[192 + 48 + j] = o.c;                         // the quad's four lanes hold the same c
+                        sr[4 * j + s] = o.gate;
                     }
                 }
                 if (k == XCH - 1) {
@@ -220,8 +245,8 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            wi[g][q].x = a.w_ih1[(size_t)(g * H + j) * H + s * KS + 2 * q];
-            wi[g][q].y = a.w_ih1[(size_t)(g * H + j) * H + s * KS + 2 * q + 1];
+            wi[g][q].x = gate_scale(g) * a.w_ih1[(size_t)(g * H + j) * H + s * KS + 2 * q];
+            wi[g][q].y = gate_scale(g) * a.w_ih1[(size_t)(g * H + j) * H + s * KS + 2 * q + 1];
         }
     Prof prof = prof_init(a.dbg);
     const int ngrp = (a.B + NB - 1) / NB;
@@ -246,7 +271,7 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
                     sm.pb[k & 1][n][s * H + j] = reduce_pick(acc, s);
                 }
             }
-            step_barrier<false>(prof);
+            step_barrier<false, P_SLEEP>(prof);
           }
         }
         step_barrier<false>(prof);      // save ring drained
@@ -267,11 +292,11 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            wh[g][q].x = a.w_hh1[(size_t)(g * H + j) * H + s * KS + 2 * q];
-            wh[g][q].y = a.w_hh1[(size_t)(g * H + j) * H + s * KS + 2 * q + 1];
+            wh[g][q].x = gate_scale(g) * a.w_hh1[(size_t)(g * H + j) * H + s * KS + 2 * q];
+            wh[g][q].y = gate_scale(g) * a.w_hh1[(size_t)(g * H + j) * H + s * KS + 2 * q + 1];
         }
-    const float bias = a.b_ih1[s * H + j] + a.b_hh1[s * H + j];
-    const GateConst gk = gate_const(s);
+    const float biasK = (s == 2 ? gate_scale(2) : gate_scale(0)) * (a.b_ih1[s * H + j] + a.b_hh1[s * H + j]);
+    const int hslot = (s == 1) ? 0 : s;
     Prof prof = prof_init(a.dbg);
     const int ngrp = (B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
@@ -288,7 +313,7 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
             const int m = m0 + k;
             const int t = m - 2;
             prof_mark<-1, false>(prof);
-            if (t >= 0 && t < T) {
+            if (t >= 0 && t < T && !(a.ablate & 1024)) {
                 const int prv = (k & 1) ^ 1;
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
@@ -296,28 +321,25 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                     f32x2 hv[6];
                     load_slice(&sm.sv[(k + SRING - 1) & (SRING - 1)][n][1][192 + s * KS], hv);
                     prof_mark<0, true>(prof);        // seg0: LDS operands arrived
+                    const float pjb = pj + biasK;
                     f32x2 acc[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        acc[g] = wh[g][0] * hv[0];
+                        acc[g] = pk_fma(wh[g][0], hv[0], (f32x2){g == s ? pjb : 0.f, 0.f});
 #pragma unroll
                         for (int q = 1; q < 6; ++q) acc[g] = pk_fma(wh[g][q], hv[q], acc[g]);
                     }
                     prof_mark<1, false>(prof);       // seg1: 24 pk_fma issued (not necessarily retired)
-                    const float pre = reduce_pick(acc, s) + (pj + bias);
+                    const float arg = reduce_pick(acc, s);
                     prof_mark<2, false>(prof);       // seg2: quad reduction + select
-                    const float act = gate_act(pre, gk.a, gk.b, gk.c);
-                    const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act);
-                    const float gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
-                    prof_mark<3, false>(prof);       // seg3: gate activation + quad broadcast
-                    c[n] = fmaf(fg, c[n], ig * gg);
-                    const float h = og * fast_tanh(c[n]);
-                    prof_mark<4, true>(prof);        // seg4: cell update, tanh
+                    CellOut o = cell_step(arg, c[n], s, 1.f);
+                    prof_mark<4, true>(prof);        // seg4: gates, cell update, tanh
                     float *sr = &sm.sv[k][n][1][0];
-                    sr[4 * j + s] = act;
-                    float top = h;                                // layer-1 input of step t was written two macro steps ago
-                    if (a.residual) top += sm.sv[(k + SRING - 2) & (SRING - 1)][n][0][288 + j];
-                    sr[192 + 48 * s + j] = s == 1 ? c[n] : s == 2 ? top : h;      // slots: h | c | top | spare
+                    // layer-1 input of step t was written two macro steps ago
+                    if (a.residual && s == 2) o.h += sm.sv[(k + SRING - 2) & (SRING - 1)][n][0][288 + j];
+                    sr[192 + 48 * hslot + j] = o.h;               // slots: h | c | top | spare (h again)
+                    sr[192 + 48 + j] = o.c;
+                    sr[4 * j + s] = o.gate;
                     prof_mark<5, false>(prof);       // seg5: record for the saver wave
                 }
             }
@@ -386,21 +408,21 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
             const int done = m0 / SCH - 1;                 // chunk completed before this one started
             // 24 pieces, 3 per step
             if (done >= 0) flush(done, b0, 0, 3);
-            step_barrier<false>(prof);
+            step_barrier<false, S_SLEEP>(prof);
             if (done >= 0) flush(done, b0, 3, 6);
-            step_barrier<false>(prof);
+            step_barrier<false, S_SLEEP>(prof);
             if (done >= 0) flush(done, b0, 6, 9);
-            step_barrier<false>(prof);
+            step_barrier<false, S_SLEEP>(prof);
             if (done >= 0) flush(done, b0, 9, 12);
-            step_barrier<false>(prof);
+            step_barrier<false, S_SLEEP>(prof);
             if (done >= 0) flush(done, b0, 12, 15);
-            step_barrier<false>(prof);
+            step_barrier<false, S_SLEEP>(prof);
             if (done >= 0) flush(done, b0, 15, 18);
-            step_barrier<false>(prof);
+            step_barrier<false, S_SLEEP>(prof);
             if (done >= 0) flush(done, b0, 18, 21);
-            step_barrier<false>(prof);
+            step_barrier<false, S_SLEEP>(prof);
             if (done >= 0) flush(done, b0, 21, 24);
-            step_barrier<false>(prof);
+            step_barrier<false, S_SLEEP>(prof);
         }
         flush(n_steps / SCH - 1, b0, 0, SPIECES);          // last chunk (its LDS image is complete: barrier above)
         if (a.head_train) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail reads the top rows back
@@ -476,14 +498,14 @@ __device__ __forceinline__ void pool_loop(PoolRun &p, FSmem<NB> &sm, const int l
     for (int m0 = 0; m0 < n_steps; m0 += SCH) {
         const int done = m0 / SCH - 1;
         if (done >= 0) pool_stage<0, NB>(p, sm, done, lane, T, sc_out);
-        step_barrier<false>(prof);
+        step_barrier<false, S_SLEEP>(prof);
         if (done >= 0) pool_stage<1, NB>(p, sm, done, lane, T, sc_out);
-        step_barrier<false>(prof);
+        step_barrier<false, S_SLEEP>(prof);
         if (done >= 0) pool_stage<2, NB>(p, sm, done, lane, T, sc_out);
-        step_barrier<false>(prof);
+        step_barrier<false, S_SLEEP>(prof);
         if (done >= 0) pool_stage<3, NB>(p, sm, done, lane, T, sc_out);
 #pragma unroll
-        for (int k = 3; k < SCH; ++k) step_barrier<false>(prof);
+        for (int k = 3; k < SCH; ++k) step_barrier<false, S_SLEEP>(prof);
     }
     const int last = n_steps / SCH - 1;
     pool_stage<0, NB>(p, sm, last, lane, T, sc_out);
@@ -729,24 +751,43 @@ __device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
     prof_store(a.dbg, prof);
 }
 
-template <int NB, int NTH>
-__global__ __launch_bounds__(NTH) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
+// a wave with no work in this mode: it only keeps the barrier count of the workgroup
+template <int NB>
+__device__ __forceinline__ void idle_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int n_steps) {
+    Prof prof = prof_init(a.dbg);
+    const int ngrp = (a.B + NB - 1) / NB;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        step_barrier<false>(prof);
+        for (int m = 0; m < n_steps; ++m) step_barrier<false>(prof);
+        step_barrier<false>(prof);
+        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, grp * NB);
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
     __shared__ __align__(16) FSmem<NB> sm;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // macro steps 0..T+1, padded to whole x chunks so that every role runs the same number of barriers
     const int n_steps = ((a.T + 2 + XCH - 1) / XCH) * XCH;
-    // wave order = issue priority among equals (older waves win arbitration): the layer-1 chain is the longest
-    // dependent sequence of a step, so it gets the lowest wave ids and the highest s_setprio
-    if (wave < 3)      { __builtin_amdgcn_s_setprio(3); l1_role<NB>(a, sm, tid, n_steps); }
-    else if (wave < 6) { __builtin_amdgcn_s_setprio(2); l0_role<NB>(a, sm, tid - 192, n_steps); }
-    else if (wave < 9) { __builtin_amdgcn_s_setprio(1); p_role<NB>(a, sm, tid - 384, n_steps); }
-    else if (wave == 9) {
-        if (a.logits_out) pool_role<NB>(a, sm, tid & 63, n_steps);
-        else              saver_role<NB>(a, sm, tid & 63, n_steps);
-    } else {
-        tpool_role<NB>(a, sm, tid & 63, n_steps);             // NTH == NT_TRAIN only
+    // Role table.  The step time is set by the VALU issue load of the busiest SIMD, and the dispatcher deals the waves
+    // of a workgroup round-robin over the 4 SIMDs (waves w and w+4 share one; checked with HW_REG_HW_ID).  So roles
+    // are placed by g = wave & 3 (the SIMD) and q = wave >> 2 (the slot on it):
+    //     g = 0..2 :  L1 part g | L0 part g | {saver or inference pool, train pool, idle}[g]
+    //     g = 3    :  P part 0  | P part 1  | P part 2
+    // i.e. ~155 / 150 / 135 / 135 VALU instructions per step and SIMD, instead of one SIMD carrying an L1, an L0 and
+    // a P wave (~180).  s_setprio follows the critical path: L1 > L0 > P > the rest.
+    const int g = wave & 3, q = wave >> 2;
+    if (g == 3)      { __builtin_amdgcn_s_setprio(1); p_role<NB>(a, sm, q * 64 + lane, n_steps); }
+    else if (q == 0) { __builtin_amdgcn_s_setprio(3); l1_role<NB>(a, sm, g * 64 + lane, n_steps); }
+    else if (q == 1) { __builtin_amdgcn_s_setprio(2); l0_role<NB>(a, sm, g * 64 + lane, n_steps); }
+    else if (g == 0) {
+        if (a.logits_out) pool_role<NB>(a, sm, lane, n_steps);
+        else              saver_role<NB>(a, sm, lane, n_steps);
     }
+    else if (g == 1 && a.head_train) tpool_role<NB>(a, sm, lane, n_steps);
+    else idle_role<NB>(a, sm, n_steps);
 }
 
 }  // namespace
@@ -759,10 +800,8 @@ int nsd_lstm2_fwd48_launch(const Lstm2FwdArgs &a, int nb, int grid, hipStream_t 
             nsd_set_error("lstm2_fwd48: fused train head needs T<=%d, F<=64, K<=%d and the training workspace", TT_TMAX, TT_KMAX);
             return NSD_E_INVALID;
         }
-        hipLaunchKernelGGL((lstm2_fwd48_kernel<1, NT_TRAIN>), dim3(grid), dim3(NT_TRAIN), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((lstm2_fwd48_kernel<1, NT>), dim3(grid), dim3(NT), 0, st, a);
     }
+    hipLaunchKernelGGL((lstm2_fwd48_kernel<1>), dim3(grid), dim3(NT), 0, st, a);
     NSD_CHECK_LAUNCH("lstm2_fwd48");
     return NSD_OK;
 }

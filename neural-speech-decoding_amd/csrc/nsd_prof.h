@@ -21,7 +21,9 @@ __device__ __forceinline__ Prof prof_init(long long *dbg) {
     p.last = p.on ? clock64() : 0;
     return p;
 }
-template <bool RAW>
+// SLEEP > 0: s_sleep after the barrier (units of 64 cycles) -- waves off the critical path let the chains' LDS reads
+// enter the (first-come-first-served) LDS queue first
+template <bool RAW, int SLEEP = 0>
 __device__ __forceinline__ void step_barrier(Prof &p) {
     if (kProfile && p.on) {
         const long long t = clock64();
@@ -33,6 +35,7 @@ __device__ __forceinline__ void step_barrier(Prof &p) {
     } else {
         if (RAW) __builtin_amdgcn_s_barrier(); else __syncthreads();
     }
+    if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
 }
 // sub-phase stamp: IDX < 0 only (re)starts the clock; WAIT_LDS drains the LDS queue first so that the segment
 // ends when the data has really arrived
