@@ -38,6 +38,9 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector == FP32 mat
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+TRAFFIC_FILE = "r01_v8_hbm_traffic.json"      # written by tools/pmc_run.sh + tools/pmc_summarize.py for the current kernels
+
+
 def algorithmic_per_trial(T, C, H, L=2, K=3):
     """SURVEY 8(d) contract figures for the fp32 H=48 path (per trial)."""
     macs_step = 0
@@ -80,8 +83,8 @@ class KernelTimer:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)      # the GPU clock ramps over the first tens of steps
     ap.add_argument("--batch-per-gpu", type=int, default=256)
     ap.add_argument("--T", type=int, default=250)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,7 +128,8 @@ def main():
 
     timer = None
     if not args.no_kernel_timing:
-        timer = KernelTimer(["nsd_lstm_fwd", "nsd_lstm_bwd", "nsd_head_train", "nsd_grad_reduce", "nsd_grad_reduce_adam", "nsd_adam_step", "nsd_train_masks"])
+        timer = KernelTimer(["nsd_lstm_head_train", "nsd_lstm_fwd", "nsd_lstm_bwd", "nsd_head_train", "nsd_grad_reduce", "nsd_grad_reduce_adam",
+                             "nsd_adam_step"])
 
     def note(msg):
         if rank == 0:
@@ -187,32 +191,35 @@ def main():
         }
         if timer:
             us = timer.mean_us()
-            flop = {"nsd_lstm_fwd": alg["flop_fwd"], "nsd_lstm_bwd": alg["flop_bwd"]}
-            byts = {"nsd_lstm_fwd": alg["bytes_fwd_kernel"], "nsd_lstm_bwd": alg["bytes_bwd_kernel"]}
-            dom = max(("nsd_lstm_fwd", "nsd_lstm_bwd"), key=lambda n: us[n] or 0.0)
+            fwd_key = "nsd_lstm_head_train" if us.get("nsd_lstm_head_train") else "nsd_lstm_fwd"   # fused LSTM + head launch
+            flop = {fwd_key: alg["flop_fwd"], "nsd_lstm_bwd": alg["flop_bwd"]}
+            byts = {fwd_key: alg["bytes_fwd_kernel"], "nsd_lstm_bwd": alg["bytes_bwd_kernel"]}
+            dom = max((fwd_key, "nsd_lstm_bwd"), key=lambda n: us[n] or 0.0)
             t_s = us[dom] * 1e-6
             tf = flop[dom] * B / t_s / 1e12
             gbs = byts[dom] * B / t_s / 1e9
             out["roofline"] = {
-                "kernel": {"nsd_lstm_fwd": "lstm2_fwd48_kernel<1>", "nsd_lstm_bwd": "lstm2_bwd48_kernel<NB>"}[dom],
+                "kernel": "lstm2_bwd48_kernel<1>" if dom == "nsd_lstm_bwd" else "lstm2_fwd48_kernel<1>",
                 "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_us": round(us[dom], 2), "algorithmic_flop_per_launch": flop[dom] * B,
                 "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": byts[dom] * B},
                 "note": "fp32 path: arithmetic intensity ~110 FLOP/B >> ridge (~20), so the compute roof binds; "
-                        "peak = 157.3 TFLOP/s fp32 (vector == f32 MFMA rate)",
+                        "peak = 157.3 TFLOP/s fp32 (packed-FMA vector rate == f32 MFMA rate on gfx950); the kernel is a "
+                        "per-trial recurrence, one trial per CU at this batch, bound by instruction issue + LDS hand-off "
+                        "latency of the step (DESIGN.md)",
             }
             # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
             # gfx950, + WRITE_SIZE), collected in separate rocprofv3 passes by tools/pmc_run.sh on this workload and
             # committed under profiles/ (bench.py cannot run the profiler on itself)
-            tpath = os.path.join(ROOT, "profiles", "r01_v5_hbm_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
             if os.path.exists(tpath) and B == 256 and T == 250:
-                kname = {"nsd_lstm_fwd": "lstm2_fwd48_kernel", "nsd_lstm_bwd": "lstm2_bwd48_kernel"}[dom]
+                kname = "lstm2_bwd48_kernel" if dom == "nsd_lstm_bwd" else "lstm2_fwd48_kernel"
                 tj = json.load(open(tpath))["kernels"].get(kname)
                 if tj:
                     out["roofline"]["traffic"] = tj["hbm_bytes_per_launch_corrected"]
-                    out["roofline"]["traffic_source"] = "profiles/r01_v5_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                    out["roofline"]["traffic_source"] = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
             out["kernels_us"] = {k: (round(v, 2) if v is not None else None) for k, v in us.items()}
             step_alg = alg["flop_train"] * B / (ms_per_step * 1e-3) / 1e12
             out["step_frac_of_fp32_peak"] = round(step_alg / FP32_PEAK_TFLOPS, 4)

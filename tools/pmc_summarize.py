@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 passes of tools/pmc_run.sh into profiles/<tag>_hbm_traffic.json and
+profiles/<tag>_kernel_stats.csv.
+
+    python tools/pmc_summarize.py <tag>        (reads gpurun_out/prof_<tag>/{trace,fetch,write})
+
+HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): MI355X_MICROARCH.md, HBM / rocprofv3 section -- on
+gfx950 FETCH_SIZE reports half of wide coalesced reads; the counters are collected in separate --pmc passes."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+ALG = {"lstm2_fwd48_kernel": 51200000, "lstm2_bwd48_kernel": 51200000}     # bench.py algorithmic_per_trial x 256 trials
+
+
+def counters(sub, name):
+    files = glob.glob(os.path.join(base, sub, "**", "*counter_collection.csv"), recursive=True)
+    acc = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != name:
+                continue
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("<")[0].split("(")[0]
+            acc[k].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fetch, write = counters("fetch", "FETCH_SIZE"), counters("write", "WRITE_SIZE")
+out = {"workload": "bench.py default (B=256,T=250) on one MI355X",
+       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_run.sh); FETCH_SIZE doubled per "
+               "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); units KB; mean over the launches of the pass",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    if k.startswith("__amd") or "at::" in k:
+        continue
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    e = {"FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1), "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
+    if k in ALG:
+        e["algorithmic_bytes_per_launch"] = ALG[k]
+        e["traffic_over_algorithmic"] = round(e["hbm_bytes_per_launch_corrected"] / ALG[k], 2)
+    out["kernels"][k] = e
+dst = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")
+json.dump(out, open(dst, "w"), indent=1)
+print("wrote", dst)
+stats = glob.glob(os.path.join(base, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+    print("wrote", os.path.join("profiles", f"{tag}_kernel_stats.csv"))
+for k, e in out["kernels"].items():
+    print(f"  {k:32s} {e['hbm_bytes_per_launch_corrected'] / 1e6:9.1f} MB/launch")
