@@ -150,6 +150,23 @@ int nsd_lstm_head_train(const nsd_dims *d, const float *params, const float *x, 
                         float *workspace, float *logits, void *stream);
 
 /*
+ * Train-mode random streams generated INSIDE the kernels (no mask tensors in HBM): the three streams of one step are
+ * value(seed, base_stream + {0: LSTM inter-layer dropout [B,T,H], 1: RReLU slope [B,F], 2: head dropout [B,F]}, index),
+ * the same pure function as nsd_train_masks / oracle -- a step run this way is bit-identical to the same step run with
+ * the masks of nsd_train_masks passed explicitly.  Only where nsd_rng_path(d) != 0 (the single-launch H = 48 shape).
+ */
+typedef struct nsd_rng {
+    uint64_t seed;
+    uint32_t base_stream;
+    float p_lstm, p_head;
+} nsd_rng;
+int nsd_rng_path(const nsd_dims *d);
+int nsd_lstm_head_train_rng(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, const int32_t *labels,
+                            float scale, uint32_t flags, float *workspace, float *logits, void *stream);
+int nsd_lstm_bwd_rng(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, uint32_t flags,
+                     float *workspace, void *stream);
+
+/*
  * Stacked LSTM backward (BPTT) through lstm_eeg_model.py:34 with the activations kept by nsd_lstm_fwd.
  * Partial gradients go to the slabs.  dx: NULL or [B,T,C].
  */

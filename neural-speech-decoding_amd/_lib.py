@@ -17,6 +17,11 @@ NSD_FLAG_RESIDUAL = 1
 NSD_FLAG_TRAIN = 2
 
 
+class Rng(C.Structure):
+    """nsd_rng of include/nsd.h"""
+    _fields_ = [("seed", C.c_uint64), ("base_stream", C.c_uint32), ("p_lstm", C.c_float), ("p_head", C.c_float)]
+
+
 class NsdError(RuntimeError):
     pass
 
@@ -48,6 +53,9 @@ SYMBOLS = {
     "nsd_head_bwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, _fp, _vp]),
     "nsd_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _ip, C.c_float, _fp, _fp, _vp]),
     "nsd_lstm_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, C.c_uint32, _fp, _fp, _vp]),
+    "nsd_rng_path": (C.c_int, [_dp]),
+    "nsd_lstm_head_train_rng": (C.c_int, [_dp, _fp, _fp, _vp, _ip, C.c_float, C.c_uint32, _fp, _fp, _vp]),
+    "nsd_lstm_bwd_rng": (C.c_int, [_dp, _fp, _fp, _vp, C.c_uint32, _fp, _vp]),
     "nsd_lstm_bwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, _fp, _vp]),
     "nsd_grad_reduce": (C.c_int, [_dp, _fp, _fp, C.c_int32, _vp]),
     "nsd_grad_reduce_adam": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [C.c_int32, _vp]),

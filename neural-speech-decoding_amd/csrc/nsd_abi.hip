@@ -200,6 +200,19 @@ static HeadArgs build_head(const nsd_dims *d, const float *params) {
         }                                                                                                  \
     } while (0)
 
+static bool fused_train_shape(const nsd_dims *d) {
+    return fast_path_ok(d) && d->H == 48 && nsd_lstm2_fwd48_head_train_fits(d->T, d->F, d->K);
+}
+static int make_rng(const nsd_rng *r, RngArgs *out) {
+    if (!r) { nsd_set_error("rng: null pointer"); return NSD_E_INVALID; }
+    if (!(r->p_lstm >= 0.f && r->p_lstm < 1.f) || !(r->p_head >= 0.f && r->p_head < 1.f)) { nsd_set_error("rng: p out of [0,1)"); return NSD_E_INVALID; }
+    out->seed = r->seed; out->base = r->base_stream;
+    out->thr_lstm = nsd_drop_threshold(r->p_lstm); out->thr_head = nsd_drop_threshold(r->p_head);
+    out->keep_lstm = 1.0f / (1.0f - r->p_lstm); out->keep_head = 1.0f / (1.0f - r->p_head);
+    out->on = 1;
+    return NSD_OK;
+}
+
 int64_t nsd_infer_scratch_bytes(const nsd_dims *d) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     return (fast_path_ok(d) ? 1 : 2) * align4((int64_t)d->B * d->T * d->H) * (int64_t)sizeof(float);
@@ -315,13 +328,19 @@ int nsd_head_train(const nsd_dims *d, const float *params, const float *rrelu_sl
     return nsd_head_launch(h, true, (hipStream_t)stream);
 }
 
-int nsd_lstm_head_train(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
-                        const float *rrelu_slope, const float *drop_head, const int32_t *labels, float scale, uint32_t flags,
-                        float *workspace, float *logits, void *stream) {
+int nsd_rng_path(const nsd_dims *d) {
+    if (nsd_check_dims(d) != NSD_OK) return 0;
+    return fused_train_shape(d) ? 1 : 0;
+}
+
+static int lstm_head_train_impl(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
+                                const float *rrelu_slope, const float *drop_head, const RngArgs *rng, const int32_t *labels,
+                                float scale, uint32_t flags, float *workspace, float *logits, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !x || !workspace || !logits || !labels) { nsd_set_error("lstm_head_train: null pointer"); return NSD_E_INVALID; }
     if (d->B == 0) return NSD_OK;
-    if (!(fast_path_ok(d) && d->H == 48 && nsd_lstm2_fwd48_head_train_fits(d->T, d->F, d->K))) {
+    if (!fused_train_shape(d)) {
+        if (rng) { nsd_set_error("lstm_head_train_rng: shape outside the single-launch path (nsd_rng_path() == 0)"); return NSD_E_INVALID; }
         // shapes outside the fused kernel: the two launches it replaces
         const int rc = nsd_lstm_fwd(d, params, x, drop_lstm, flags, workspace, stream);
         if (rc != NSD_OK) return rc;
@@ -341,11 +360,25 @@ int nsd_lstm_head_train(const nsd_dims *d, const float *params, const float *x, 
     a.adpack = workspace + w.adpack; a.hslabs = workspace + w.hslabs;
     a.o_ln_w = h.o_ln_w; a.o_ln_b = h.o_ln_b; a.o_attn_w = h.o_attn_w; a.o_attn_b = h.o_attn_b;
     a.o_fc0_w = h.o_fc0_w; a.o_fc0_b = h.o_fc0_b; a.o_fc3_w = h.o_fc3_w; a.o_fc3_b = h.o_fc3_b; a.Ph = h.Ph;
+    if (rng) a.rng = *rng;
     return nsd_lstm2_fwd_launch(a, d->H, (hipStream_t)stream);
 }
 
-int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, uint32_t flags,
-                 float *workspace, float *dx, void *stream) {
+int nsd_lstm_head_train(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
+                        const float *rrelu_slope, const float *drop_head, const int32_t *labels, float scale, uint32_t flags,
+                        float *workspace, float *logits, void *stream) {
+    return lstm_head_train_impl(d, params, x, drop_lstm, rrelu_slope, drop_head, nullptr, labels, scale, flags, workspace, logits, stream);
+}
+
+int nsd_lstm_head_train_rng(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, const int32_t *labels,
+                            float scale, uint32_t flags, float *workspace, float *logits, void *stream) {
+    RngArgs r;
+    if (make_rng(rng, &r) != NSD_OK) return NSD_E_INVALID;
+    return lstm_head_train_impl(d, params, x, nullptr, nullptr, nullptr, &r, labels, scale, flags, workspace, logits, stream);
+}
+
+static int lstm_bwd_impl(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, const RngArgs *rng,
+                         uint32_t flags, float *workspace, float *dx, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !x || !workspace) { nsd_set_error("lstm_bwd: null pointer"); return NSD_E_INVALID; }
     if (dx) { nsd_set_error("lstm_bwd: dx (gradient w.r.t. the EEG window) is not implemented"); return NSD_E_INVALID; }
@@ -378,7 +411,22 @@ int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const f
     a.B = d->B; a.T = d->T; a.C = d->C;
     a.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
     { const char *ab_ = getenv("NSD_ABLATE"); a.ablate = ab_ ? atoi(ab_) : 0; }
+    if (rng) a.rng = *rng;
     return nsd_lstm2_bwd_launch(a, d->H, (hipStream_t)stream);
+}
+
+int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, uint32_t flags,
+                 float *workspace, float *dx, void *stream) {
+    return lstm_bwd_impl(d, params, x, drop_lstm, nullptr, flags, workspace, dx, stream);
+}
+
+int nsd_lstm_bwd_rng(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, uint32_t flags,
+                     float *workspace, void *stream) {
+    RngArgs r;
+    if (make_rng(rng, &r) != NSD_OK) return NSD_E_INVALID;
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (!fused_train_shape(d)) { nsd_set_error("lstm_bwd_rng: shape outside the single-launch path (nsd_rng_path() == 0)"); return NSD_E_INVALID; }
+    return lstm_bwd_impl(d, params, x, nullptr, &r, flags, workspace, nullptr, stream);
 }
 
 int nsd_grad_reduce(const nsd_dims *d, const float *workspace, float *grads, int32_t accumulate, void *stream) {

@@ -25,6 +25,7 @@ struct Lstm2FwdArgs {
     float scale;
     float *logits, *loss, *alpha, *pooled, *fc0_pre, *dscore, *dpooled, *adpack, *hslabs;
     long o_ln_w, o_ln_b, o_attn_w, o_attn_b, o_fc0_w, o_fc0_b, o_fc3_w, o_fc3_b, Ph;
+    RngArgs rng;                             // rng.on: dropout multipliers / RReLU slopes are generated in the kernel
 };
 struct Lstm2BwdArgs {
     const float *x;
@@ -40,6 +41,7 @@ struct Lstm2BwdArgs {
     long long *dbg;                          // diagnostic build of the schedule: per-wave {work, wait} cycle sums of workgroup 0 (null = off)
     int B, T, C, residual;
     int ablate;                              // timing experiments only (env NSD_ABLATE); 0 in production
+    RngArgs rng;                             // rng.on: the inter-layer dropout multipliers are generated in the kernel
 };
 struct HeadArgs {
     const float *top;

@@ -102,6 +102,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return rows_combine_max(v);
 }
 
+// in-kernel train-mode streams (see nsd_rng in nsd.h): thresholds and keep factors precomputed on the host
+struct RngArgs {
+    uint64_t seed;
+    uint32_t base;            // stream ids base, base+1, base+2
+    uint32_t thr_lstm, thr_head;
+    float keep_lstm, keep_head;
+    int on;
+};
+static inline uint32_t nsd_drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
 // counter-based random stream shared bit-for-bit with oracle/nsd_oracle.c (nsd_oracle_rand_u32)
 __host__ __device__ __forceinline__ uint32_t nsd_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;

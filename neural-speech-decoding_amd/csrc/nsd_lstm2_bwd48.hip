@@ -145,7 +145,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
                     const float4 gc = *reinterpret_cast<const float4 *>(rec + 4 * j);
                     const float own = rec[4 * j + s];
                     const float cprev = t > 0 ? rec[192 + j] : 0.f;
-                    const float aux0 = layer == 1 ? rec[240] : (a.mask ? rec[240 + j] : 1.f);
+                    const float aux0 = layer == 1 ? rec[240] : ((a.mask || a.rng.on) ? rec[240 + j] : 1.f);
                     const float aux1 = rec[241];
                     const float ig = gc.x, fg = gc.y, gg = gc.z, og = gc.w;
                     const float tc = fast_tanh(ct[n]);
@@ -318,15 +318,31 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) st.acc[q][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // rng.on: the layer-0 dropout multipliers (the `aux` slot of the layer-0 records) are generated here instead of being
+    // streamed from HBM: 8 steps x 48 units per chunk = one value per dW lane and chunk, a chunk ahead like the loader
+    // (same values as nsd_train_masks / the forward kernel)
+    const int L = dwid * 64 + lane, mk_k = L / H, mk_j = L - mk_k * H;
+    auto gen_mask = [&](const int chunk, const int b0) {
+        const int t = a.T + 1 - (chunk * CHUNK + mk_k);
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int b = b0 + n;
+            if (b < a.B && t >= 0 && t < a.T)
+                sm.stage[chunk & 1][n][0][mk_k][240 + mk_j] =
+                    nsd_rand_u32(a.rng.seed, a.rng.base, ((uint64_t)b * a.T + t) * H + mk_j) < a.rng.thr_lstm ? 0.f : a.rng.keep_lstm;
+        }
+    };
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
+        if (a.rng.on) gen_mask(0, b0);
         step_barrier<false>(prof);      // pairs with the stage-initialisation barrier of the other roles
         for (int G = 0; G < n_groups; ++G) {
             // macro step 4G+0 : finish matrix 0 of group G-1, start fetching matrix 0 of group G; etc.
             if (G > 0 && !(a.ablate & 1)) dw_compute<0, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<0, NB>(a, st, G, b0, lane);
             step_barrier<false, DW_SLEEP>(prof);
+            if (a.rng.on && (G & 1) == 0) gen_mask(G / 2 + 1, b0);     // second step of a chunk: the old records are dead
             if (G > 0 && !(a.ablate & 1)) dw_compute<1, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<1, NB>(a, st, G, b0, lane);
             step_barrier<false, DW_SLEEP>(prof);
@@ -387,7 +403,7 @@ __device__ __forceinline__ void loader_decode(const Lstm2BwdArgs &a, const int l
                                  // lie inside the workspace (hseq precedes cseq) and are ignored by the chain
             d[q].base = (const char *)((layer == 0 ? a.cseq0 : a.cseq1) + (w - 48) * 4) - H * 4; d[q].row_bytes = H * 4;
         } else if (layer == 0) {
-            if (a.mask) { d[q].base = (const char *)(a.mask + (w - 60) * 4); d[q].row_bytes = H * 4; }
+            if (a.mask && !a.rng.on) { d[q].base = (const char *)(a.mask + (w - 60) * 4); d[q].row_bytes = H * 4; }
         } else if (w == 60) {
             d[q].base = (const char *)a.dsc_pack; d[q].row_bytes = 16;
         }

@@ -171,6 +171,14 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
         auto mask_at = [&](int e, int t0) -> float4 {      // e: float4 index in [0, NB*384)
             const int n = e / 384, rem = e - n * 384, tl = rem / 12, q = rem - tl * 12;
             const int b = b0 + n, t = t0 + tl;
+            if (a.rng.on) {                                    // chunk 0 only: later chunks are generated by the P waves
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[u] = (b < B && t < T && nsd_rand_u32(a.rng.seed, a.rng.base, ((uint64_t)b * T + t) * H + 4 * q + u) < a.rng.thr_lstm)
+                               ? 0.f : a.rng.keep_lstm;
+                return (b < B && t < T) ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(1.f, 1.f, 1.f, 1.f);
+            }
             if (a.mask && b < B && t < T) return *reinterpret_cast<const float4 *>(a.mask + ((size_t)b * T + t) * H + 4 * q);
             return make_float4(1.f, 1.f, 1.f, 1.f);
         };
@@ -188,7 +196,7 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
 #pragma unroll
             for (int q = 0; q < XPT; ++q) xr[q] = x_at(r + 192 * q, m0 + XCH);
 #pragma unroll
-            for (int q = 0; q < MPT; ++q) mr[q] = mask_at(r + 192 * q, m0 + XCH);
+            for (int q = 0; q < MPT; ++q) mr[q] = a.rng.on ? make_float4(1.f, 1.f, 1.f, 1.f) : mask_at(r + 192 * q, m0 + XCH);
             const int cb = (m0 / XCH) & 1;
             for (int kh = 0; kh < XCH; kh += SRING) {
 #pragma unroll
@@ -220,8 +228,10 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                 if (k == XCH - 1) {
 #pragma unroll
                     for (int q = 0; q < XPT; ++q) { const int e = r + 192 * q; if (e < XE) (&sm.xs[cb ^ 1][0][0][0])[e] = xr[q]; }
+                    if (!a.rng.on) {
 #pragma unroll
-                    for (int q = 0; q < MPT; ++q) *reinterpret_cast<float4 *>(&sm.ms[cb ^ 1][0][0][0] + 4 * (r + 192 * q)) = mr[q];
+                        for (int q = 0; q < MPT; ++q) *reinterpret_cast<float4 *>(&sm.ms[cb ^ 1][0][0][0] + 4 * (r + 192 * q)) = mr[q];
+                    }
                 }
                 step_barrier<false>(prof);
               }
@@ -673,8 +683,14 @@ __device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b = grp;
         // per-trial scalars, fetched while the recurrence runs
-        const float sl_f = (lane < F && a.rrelu_slope) ? a.rrelu_slope[(size_t)b * F + lane] : a.eval_slope;
-        const float mk_f = (lane < F && a.drop_head) ? a.drop_head[(size_t)b * F + lane] : 1.f;
+        float sl_f = (lane < F && a.rrelu_slope) ? a.rrelu_slope[(size_t)b * F + lane] : a.eval_slope;
+        float mk_f = (lane < F && a.drop_head) ? a.drop_head[(size_t)b * F + lane] : 1.f;
+        if (a.rng.on && lane < F) {                           // same values as nsd_train_masks streams base+1 / base+2
+            const uint64_t idx = (uint64_t)b * F + lane;
+            const float u = (float)(nsd_rand_u32(a.rng.seed, a.rng.base + 1u, idx) >> 8) * (1.0f / 16777216.0f);
+            sl_f = 0.125f + ((float)(1.0 / 3.0) - 0.125f) * u;
+            mk_f = nsd_rand_u32(a.rng.seed, a.rng.base + 2u, idx) >= a.rng.thr_head ? a.rng.keep_head : 0.f;
+        }
         const int label = a.labels[b];
         pool_reset(pr);
         step_barrier<false>(prof);
@@ -751,14 +767,33 @@ __device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
     prof_store(a.dbg, prof);
 }
 
-// a wave with no work in this mode: it only keeps the barrier count of the workgroup
+// The spare wave.  Without in-kernel random streams it only keeps the barrier count of the workgroup; with rng.on it
+// generates the inter-layer dropout multipliers (one row of 48 per step, a whole x chunk ahead of the layer-0 waves that
+// read them from sm.ms; chunk 0 is written by the layer-0 waves themselves).  Same values as nsd_train_masks: the
+// stream index of (b, t, j) is (b*T + t)*48 + j, advanced by additions only.
 template <int NB>
-__device__ __forceinline__ void idle_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int n_steps) {
+__device__ __forceinline__ void spare_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int lane, const int n_steps) {
     Prof prof = prof_init(a.dbg);
+    const int T = a.T;
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        uint64_t idx[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) idx[n] = ((uint64_t)(grp * NB + n) * T + XCH) * H + lane;      // row t = XCH
         step_barrier<false>(prof);
-        for (int m = 0; m < n_steps; ++m) step_barrier<false>(prof);
+        for (int m = 0; m < n_steps; ++m) {
+            if (a.rng.on && lane < H) {
+                const int t = m + XCH;
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    float v = 1.f;
+                    if (grp * NB + n < a.B && t < T) v = nsd_rand_u32(a.rng.seed, a.rng.base, idx[n]) < a.rng.thr_lstm ? 0.f : a.rng.keep_lstm;
+                    sm.ms[((m / XCH) & 1) ^ 1][n][m & (XCH - 1)][lane] = v;
+                    idx[n] += H;
+                }
+            }
+            step_barrier<false, S_SLEEP>(prof);
+        }
         step_barrier<false>(prof);
         if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, grp * NB);
     }
@@ -774,7 +809,7 @@ __global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
     // Role table.  The step time is set by the VALU issue load of the busiest SIMD, and the dispatcher deals the waves
     // of a workgroup round-robin over the 4 SIMDs (waves w and w+4 share one; checked with HW_REG_HW_ID).  So roles
     // are placed by g = wave & 3 (the SIMD) and q = wave >> 2 (the slot on it):
-    //     g = 0..2 :  L1 part g | L0 part g | {saver or inference pool, train pool, idle}[g]
+    //     g = 0..2 :  L1 part g | L0 part g | {saver or inference pool, train pool, spare (dropout stream)}[g]
     //     g = 3    :  P part 0  | P part 1  | P part 2
     // i.e. ~155 / 150 / 135 / 135 VALU instructions per step and SIMD, instead of one SIMD carrying an L1, an L0 and
     // a P wave (~180).  s_setprio follows the critical path: L1 > L0 > P > the rest.
@@ -787,7 +822,7 @@ __global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
         else              saver_role<NB>(a, sm, lane, n_steps);
     }
     else if (g == 1 && a.head_train) tpool_role<NB>(a, sm, lane, n_steps);
-    else idle_role<NB>(a, sm, n_steps);
+    else spare_role<NB>(a, sm, lane, n_steps);
 }
 
 }  // namespace

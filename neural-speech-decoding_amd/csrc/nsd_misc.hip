@@ -214,11 +214,7 @@ __global__ void train_masks_kernel(uint64_t seed, uint32_t base_arg, const long 
         }
     }
 }
-static uint32_t drop_threshold(float p) {
-    double t = (double)p * 4294967296.0;
-    if (t > 4294967295.0) t = 4294967295.0;
-    return (uint32_t)t;
-}
+static uint32_t drop_threshold(float p) { return nsd_drop_threshold(p); }
 int nsd_train_masks_launch(uint64_t seed, uint32_t base, const long long *step_dev, float p_lstm, float p_head, long n_lstm,
                            float *drop_lstm, long n_head, float *rrelu, float *drop_head, hipStream_t st) {
     if (!(p_lstm >= 0.f && p_lstm < 1.f) || !(p_head >= 0.f && p_head < 1.f)) { nsd_set_error("train_masks: p out of [0,1)"); return NSD_E_INVALID; }

@@ -224,10 +224,13 @@ def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: tor
 def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: torch.Tensor, labels: torch.Tensor,
                      logits: torch.Tensor, grads: torch.Tensor, *, scale: Optional[float] = None, drop_lstm=None,
                      rrelu_slope=None, drop_head=None, residual: bool = False, adam: Optional[dict] = None,
-                     fused_head: bool = True) -> None:
+                     fused_head: bool = True, rng: Optional[dict] = None) -> None:
     """The launches of one training evaluation: lstm fwd + head (fwd, mean CE, bwd) in one launch where the shape allows
     (nsd_lstm_head_train; fused_head=False forces the two separate launches), lstm bwd, slab reduce -> `grads` (flat,
     overwritten).  `logits` [B,K] is an output buffer.
+
+    rng=dict(seed=, base_stream=, p_lstm=, p_head=): dropout multipliers and RReLU slopes are generated inside the kernels
+    (bit-identical to passing the tensors of nsd_train_masks with the same seed / stream ids); needs rng_path(spec, B, T).
 
     adam=dict(m=, v=, step=, lr=, beta1=, beta2=, eps=, weight_decay=): single-rank training -- the optimizer update of
     `flat` rides in the reduction launch (nsd_grad_reduce_adam); `grads` is still written."""
@@ -241,12 +244,20 @@ def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: t
     xp, wsp, st = _dev_f32(x, "x", (B, T, spec.C)), _dev_f32(ws, "workspace"), _stream()
     dl, sl, dh = _dev_f32(drop_lstm, "drop_lstm"), _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head")
     lp = _dev_f32(logits, "logits", (B, spec.K))
-    if fused_head:
-        _call("nsd_lstm_head_train", C.byref(d), pp, xp, dl, sl, dh, labels.data_ptr(), scale, flags, wsp, lp, st)
+    if rng is not None:
+        # the three random streams of the step are generated inside the kernels: no mask tensors
+        if drop_lstm is not None or rrelu_slope is not None or drop_head is not None:
+            raise NsdError("train_step_grads: pass either rng= or explicit mask tensors, not both")
+        r = _lib.Rng(int(rng["seed"]) & 0xFFFFFFFFFFFFFFFF, int(rng["base_stream"]) & 0xFFFFFFFF, float(rng["p_lstm"]), float(rng["p_head"]))
+        _call("nsd_lstm_head_train_rng", C.byref(d), pp, xp, C.byref(r), labels.data_ptr(), scale, flags, wsp, lp, st)
+        _call("nsd_lstm_bwd_rng", C.byref(d), pp, xp, C.byref(r), flags, wsp, st)
     else:
-        _call("nsd_lstm_fwd", C.byref(d), pp, xp, dl, flags, wsp, st)
-        _call("nsd_head_train", C.byref(d), pp, sl, dh, labels.data_ptr(), scale, wsp, lp, st)
-    _call("nsd_lstm_bwd", C.byref(d), pp, xp, dl, flags, wsp, None, st)
+        if fused_head:
+            _call("nsd_lstm_head_train", C.byref(d), pp, xp, dl, sl, dh, labels.data_ptr(), scale, flags, wsp, lp, st)
+        else:
+            _call("nsd_lstm_fwd", C.byref(d), pp, xp, dl, flags, wsp, st)
+            _call("nsd_head_train", C.byref(d), pp, sl, dh, labels.data_ptr(), scale, wsp, lp, st)
+        _call("nsd_lstm_bwd", C.byref(d), pp, xp, dl, flags, wsp, None, st)
     gp = _dev_f32(grads, "grads", (spec.param_count,))
     if adam is None:
         _call("nsd_grad_reduce", C.byref(d), wsp, gp, 0, st)
@@ -254,6 +265,12 @@ def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: t
         _call("nsd_grad_reduce_adam", C.byref(d), wsp, gp, pp, _dev_f32(adam["m"], "m", flat.shape), _dev_f32(adam["v"], "v", flat.shape),
               adam.get("lr", 1e-3), adam.get("beta1", 0.9), adam.get("beta2", 0.999), adam.get("eps", 1e-8),
               adam.get("weight_decay", 0.0), 1.0, int(adam["step"]), st)
+
+
+def rng_path(spec: ModelSpec, B: int, T: int) -> bool:
+    """True where the kernels can generate the train-mode random streams themselves (nsd_rng_path)."""
+    d = spec.dims(B, T)
+    return bool(_lib.lib().nsd_rng_path(C.byref(d)))
 
 
 def loss_sum(spec: ModelSpec, ws: torch.Tensor, B: int, T: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

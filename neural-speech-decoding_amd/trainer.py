@@ -62,6 +62,7 @@ class Trainer:
         self.rank = dist.get_rank(group) if self.reducer.world > 1 else 0
         self.world = self.reducer.world
         self.fused_head = True           # nsd_lstm_head_train (one launch) where the shape allows; False: two launches
+        self.in_kernel_rng = True        # dropout / RReLU streams generated inside the kernels where the shape allows
         self.seed = (int(seed) + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF
         self.stochastic = stochastic
         self.step_count = 0
@@ -99,18 +100,23 @@ class Trainer:
         self.step_count += 1
         sid = (self.step_count & 0x3FFFFFFF) * 4
         dl = buf.get("drop_lstm"); sl = buf.get("rrelu"); dh = buf.get("drop_head")
-        if dl is not None and sl is not None and dh is not None:
+        rng = None
+        if "rng_ok" not in buf:
+            buf["rng_ok"] = ops.rng_path(sp, B, T)
+        if self.in_kernel_rng and dl is not None and sl is not None and dh is not None and buf["rng_ok"]:
+            # the three streams of the step are generated inside the LSTM kernels (same values as nsd_train_masks)
+            rng = dict(seed=self.seed, base_stream=sid, p_lstm=self.model.dropout_p, p_head=self.model.head_dropout_p)
+            dl = sl = dh = None
+        elif dl is not None and sl is not None and dh is not None:
             _lib.check(L.nsd_train_masks(self.seed, sid, self.model.dropout_p, self.model.head_dropout_p, dl.numel(),
                                          dl.data_ptr(), sl.numel(), sl.data_ptr(), dh.data_ptr(), st), "train_masks")
-            dl_done = True
         else:
-            dl_done = False
-        if dl is not None and not dl_done:
-            _lib.check(L.nsd_dropout_mask(self.seed, sid, self.model.dropout_p, dl.numel(), dl.data_ptr(), st), "dropout_mask")
-        if sl is not None and not dl_done:
-            _lib.check(L.nsd_rrelu_noise(self.seed, sid + 1, sl.numel(), sl.data_ptr(), st), "rrelu_noise")
-        if dh is not None and not dl_done:
-            _lib.check(L.nsd_dropout_mask(self.seed, sid + 2, self.model.head_dropout_p, dh.numel(), dh.data_ptr(), st), "dropout_mask")
+            if dl is not None:
+                _lib.check(L.nsd_dropout_mask(self.seed, sid, self.model.dropout_p, dl.numel(), dl.data_ptr(), st), "dropout_mask")
+            if sl is not None:
+                _lib.check(L.nsd_rrelu_noise(self.seed, sid + 1, sl.numel(), sl.data_ptr(), st), "rrelu_noise")
+            if dh is not None:
+                _lib.check(L.nsd_dropout_mask(self.seed, sid + 2, self.model.head_dropout_p, dh.numel(), dh.data_ptr(), st), "dropout_mask")
         ws = buf["ws"]
         scale = 1.0 / (B * self.world)
         hyper = dict(step=self.step_count, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
@@ -118,11 +124,11 @@ class Trainer:
         if self.world == 1:
             # no exchange step between reduction and update: one launch does both
             ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
-                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual, fused_head=self.fused_head,
+                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual, fused_head=self.fused_head, rng=rng,
                                  adam=dict(m=self.m, v=self.v, **hyper))
         else:
             ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
-                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual, fused_head=self.fused_head)
+                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual, fused_head=self.fused_head, rng=rng)
             self.reducer(self.grads)
             ops.adam_step(self.flat, self.grads, self.m, self.v, **hyper)
         self._last_B, self._last_T = B, T

@@ -427,6 +427,25 @@ def test_fused_reduce_adam_is_bit_identical_to_separate_launches(nsd, dev, ref_s
     assert not torch.equal(out[True][0], flat0.cpu())
 
 
+@pytest.mark.parametrize("B,T", [(12, 40), (5, 250), (300, 33), (3, 1)])
+def test_in_kernel_random_streams_equal_explicit_masks(nsd, dev, ref_state, B, T):
+    """Trainer.step with the dropout / RReLU streams generated inside the kernels (nsd_lstm_head_train_rng,
+    nsd_lstm_bwd_rng) == the same step with the tensors of nsd_train_masks: same values, same arithmetic."""
+    from nsd_amd.trainer import Trainer
+    x, y = _t(synth_x(B, T, seed=21), dev), _t(synth_labels(B, seed=21), dev)
+    out = []
+    for in_kernel in (True, False):
+        m = _model(nsd, dev, ref_state).train()
+        tr = Trainer(m, lr=1e-3, seed=11)
+        tr.in_kernel_rng = in_kernel
+        for _ in range(2):
+            tr.step(x, y)
+        out.append((tr.grads.clone(), m.flat_parameters().clone(), tr.last_loss()))
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2]
+
+
 def test_graph_replay_step_equals_eager_step(nsd, dev, ref_state):
     """Trainer.step_static (captured hipGraphs, device-side step counter) == Trainer.step (eager launches)."""
     from nsd_amd.trainer import Trainer

@@ -33,7 +33,7 @@ def main():
     x = (2.7 * torch.randn(args.B, args.T, 8, generator=g)).to(dev)
     y = torch.randint(0, 3, (args.B,), generator=g).to(torch.int32).to(dev)
 
-    def make(split_adam, fused_head=True):
+    def make(split_adam, fused_head=True, in_kernel_rng=True):
         m = nsd_amd.EEG_LSTM()
         m.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files})
         m.to(dev).train()
@@ -41,10 +41,12 @@ def main():
         if split_adam:
             tr.world = 2                      # takes the multi-rank launch sequence; the reducer itself is a no-op at world 1
         tr.fused_head = fused_head
+        tr.in_kernel_rng = in_kernel_rng
         return tr
 
     variants = {"step (shipped)": make(False), "step (separate adam)": make(True),
-                "step (separate head launch)": make(False, fused_head=False)}
+                "step (mask tensors, fused head)": make(False, in_kernel_rng=False),
+                "step (mask tensors, separate head launch)": make(False, fused_head=False, in_kernel_rng=False)}
     host = {}
     for name, tr in variants.items():
         for _ in range(20):
@@ -60,7 +62,7 @@ def main():
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             host[name] = (t1 - t0) / args.steps * 1e6
-            print(f"round {r}  {name:28s} {1e6 * (t2 - t0) / args.steps:8.1f} us/step   (host issue {host[name]:6.1f} us/step)", flush=True)
+            print(f"round {r}  {name:42s} {1e6 * (t2 - t0) / args.steps:8.1f} us/step   (host issue {host[name]:6.1f} us/step)", flush=True)
 
 
 if __name__ == "__main__":
