@@ -128,8 +128,8 @@ def main():
 
     timer = None
     if not args.no_kernel_timing:
-        timer = KernelTimer(["nsd_lstm_head_train", "nsd_lstm_fwd", "nsd_lstm_bwd", "nsd_head_train", "nsd_grad_reduce", "nsd_grad_reduce_adam",
-                             "nsd_adam_step"])
+        timer = KernelTimer(["nsd_lstm_head_train_rng", "nsd_lstm_head_train", "nsd_lstm_fwd", "nsd_lstm_bwd_rng", "nsd_lstm_bwd",
+                             "nsd_head_train", "nsd_grad_reduce", "nsd_grad_reduce_adam", "nsd_adam_step"])
 
     def note(msg):
         if rank == 0:
@@ -191,15 +191,17 @@ def main():
         }
         if timer:
             us = timer.mean_us()
-            fwd_key = "nsd_lstm_head_train" if us.get("nsd_lstm_head_train") else "nsd_lstm_fwd"   # fused LSTM + head launch
-            flop = {fwd_key: alg["flop_fwd"], "nsd_lstm_bwd": alg["flop_bwd"]}
-            byts = {fwd_key: alg["bytes_fwd_kernel"], "nsd_lstm_bwd": alg["bytes_bwd_kernel"]}
-            dom = max((fwd_key, "nsd_lstm_bwd"), key=lambda n: us[n] or 0.0)
+            # the launch names depend on the path taken (single-launch fwd + head, in-kernel random streams)
+            fwd_key = next(k for k in ("nsd_lstm_head_train_rng", "nsd_lstm_head_train", "nsd_lstm_fwd") if us.get(k))
+            bwd_key = next(k for k in ("nsd_lstm_bwd_rng", "nsd_lstm_bwd") if us.get(k))
+            flop = {fwd_key: alg["flop_fwd"], bwd_key: alg["flop_bwd"]}
+            byts = {fwd_key: alg["bytes_fwd_kernel"], bwd_key: alg["bytes_bwd_kernel"]}
+            dom = max((fwd_key, bwd_key), key=lambda n: us[n] or 0.0)
             t_s = us[dom] * 1e-6
             tf = flop[dom] * B / t_s / 1e12
             gbs = byts[dom] * B / t_s / 1e9
             out["roofline"] = {
-                "kernel": "lstm2_bwd48_kernel<1>" if dom == "nsd_lstm_bwd" else "lstm2_fwd48_kernel<1>",
+                "kernel": "lstm2_bwd48_kernel<1>" if dom == bwd_key else "lstm2_fwd48_kernel<1>",
                 "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_us": round(us[dom], 2), "algorithmic_flop_per_launch": flop[dom] * B,
@@ -215,12 +217,12 @@ def main():
             # committed under profiles/ (bench.py cannot run the profiler on itself)
             tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
             if os.path.exists(tpath) and B == 256 and T == 250:
-                kname = "lstm2_bwd48_kernel" if dom == "nsd_lstm_bwd" else "lstm2_fwd48_kernel"
+                kname = "lstm2_bwd48_kernel" if dom == bwd_key else "lstm2_fwd48_kernel"
                 tj = json.load(open(tpath))["kernels"].get(kname)
                 if tj:
                     out["roofline"]["traffic"] = tj["hbm_bytes_per_launch_corrected"]
                     out["roofline"]["traffic_source"] = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-            out["kernels_us"] = {k: (round(v, 2) if v is not None else None) for k, v in us.items()}
+            out["kernels_us"] = {k: round(v, 2) for k, v in us.items() if v is not None}
             step_alg = alg["flop_train"] * B / (ms_per_step * 1e-3) / 1e12
             out["step_frac_of_fp32_peak"] = round(step_alg / FP32_PEAK_TFLOPS, 4)
             out["step_hbm_frac"] = round(alg["bytes_train"] * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
