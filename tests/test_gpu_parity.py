@@ -446,6 +446,44 @@ def test_in_kernel_random_streams_equal_explicit_masks(nsd, dev, ref_state, B, T
     assert out[0][2] == out[1][2]
 
 
+def test_multi_rank_launch_sequence_over_rccl_single_rank_group(nsd, dev, ref_state):
+    """The multi-rank step (reduce -> RCCL all-reduce of the flat gradient -> Adam) on a 1-rank `nccl` group: the
+    collective is the identity there, so the result must equal the single-rank fused step bit for bit."""
+    import torch.distributed as dist
+    from nsd_amd.trainer import Trainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        B, T = 24, 50
+        x, y = _t(synth_x(B, T, seed=31), dev), _t(synth_labels(B, seed=31), dev)
+        ma, mb = _model(nsd, dev, ref_state).train(), _model(nsd, dev, ref_state).train()
+        ta, tb = Trainer(ma, lr=1e-3, seed=9), Trainer(mb, lr=1e-3, seed=9)
+        assert ta.seed == tb.seed
+        # force the multi-rank code path of tb (its collective runs over the real RCCL group of size 1)
+        tb.reducer.world = 2
+        tb.world = 2
+        calls = []
+        orig = dist.all_reduce
+        dist.all_reduce = lambda t, **kw: (calls.append(t.numel()), orig(t, **kw))[1]
+        try:
+            ta.step(x, y)
+            tb.step(x, y)
+        finally:
+            dist.all_reduce = orig
+        assert calls == [tb.flat.numel()]                  # exactly one collective per step, the whole flat gradient
+        torch.cuda.synchronize()
+        # tb scaled its CE gradient by 1/(B*2) (a power of two: exact), everything downstream is linear in it
+        assert torch.equal(ta.grads, 2.0 * tb.grads)
+        assert torch.isfinite(mb.flat_parameters()).all() and not torch.equal(mb.flat_parameters(), _t(orc.flatten_state(ref_state, D), dev))
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_graph_replay_step_equals_eager_step(nsd, dev, ref_state):
     """Trainer.step_static (captured hipGraphs, device-side step counter) == Trainer.step (eager launches)."""
     from nsd_amd.trainer import Trainer
