@@ -339,14 +339,14 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
         step_barrier<false>(prof);      // pairs with the stage-initialisation barrier of the other roles
         for (int G = 0; G < n_groups; ++G) {
             // macro step 4G+0 : finish matrix 0 of group G-1, start fetching matrix 0 of group G; etc.
-            if (G > 0 && !(a.ablate & 1)) dw_compute<0, NB>(a, sm, st, G - 1, dwid, lane);
+            if (G > 0 && !ablated(a.ablate, 1)) dw_compute<0, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<0, NB>(a, st, G, b0, lane);
             step_barrier<false, DW_SLEEP>(prof);
             if (a.rng.on && (G & 1) == 0) gen_mask(G / 2 + 1, b0);     // second step of a chunk: the old records are dead
-            if (G > 0 && !(a.ablate & 1)) dw_compute<1, NB>(a, sm, st, G - 1, dwid, lane);
+            if (G > 0 && !ablated(a.ablate, 1)) dw_compute<1, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<1, NB>(a, st, G, b0, lane);
             step_barrier<false, DW_SLEEP>(prof);
-            if (G > 0 && !(a.ablate & 1)) dw_compute<2, NB>(a, sm, st, G - 1, dwid, lane);
+            if (G > 0 && !ablated(a.ablate, 1)) dw_compute<2, NB>(a, sm, st, G - 1, dwid, lane);
             dw_prefetch<2, NB>(a, st, G, b0, lane);
             step_barrier<false, DW_SLEEP>(prof);
             step_barrier<false, DW_SLEEP>(prof);
@@ -464,7 +464,7 @@ __device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm,
         step_barrier<true>(prof);
         for (int m0 = 0; m0 < n_steps; m0 += CHUNK) {
             const int chunk = m0 / CHUNK, nb = (chunk + 1) & 1;
-            const bool on = !(a.ablate & 16);
+            const bool on = !ablated(a.ablate, 16);
             // next chunk: 3 pieces per step during steps 0..5 (+ x rows at step 0); all landed before step 7 ends
             if (on) { loader_issue<NB, 0, 3>(a, sm, d, chunk + 1, nb, b0); loader_issue_x<NB>(a, sm, chunk + 1, nb, b0, lane); }
             step_barrier<true, LD_SLEEP>(prof);

@@ -203,7 +203,7 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
               for (int kr = 0; kr < SRING; ++kr) {
                 const int k = kh + kr;
                 const int m = m0 + k;
-                if (m < T && !(a.ablate & 64)) {
+                if (m < T && !ablated(a.ablate, 64)) {
 #pragma unroll
                     for (int n = 0; n < NB; ++n) {
                         const float mk = sm.ms[cb][n][k][j];
@@ -266,7 +266,7 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
 #pragma unroll
           for (int k = 0; k < SRING; ++k) {
             const int m = m0 + k;
-            if (m >= 1 && m <= T && !(a.ablate & 128)) {
+            if (m >= 1 && m <= T && !ablated(a.ablate, 128)) {
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     f32x2 iv[6];
@@ -323,7 +323,7 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
             const int m = m0 + k;
             const int t = m - 2;
             prof_mark<-1, false>(prof);
-            if (t >= 0 && t < T && !(a.ablate & 1024)) {
+            if (t >= 0 && t < T && !ablated(a.ablate, 1024)) {
                 const int prv = (k & 1) ^ 1;
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
@@ -605,7 +605,7 @@ __device__ __forceinline__ float tail_block_sum(float v, float *red, const int t
 template <int NB>
 __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b) {
     const int T = a.T;
-    if (a.ablate & 256) return;
+    if (ablated(a.ablate, 256)) return;
     const float *top = a.top + (size_t)b * T * H;
     const float mx = sm.md[0], rden = sm.md[1];
     float al[2], dd[2];
@@ -697,7 +697,7 @@ __device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
         pool_loop<NB>(pr, sm, lane, T, n_steps, sm.sc, prof);
         const float pooled = pr.pooled, den = pr.den, mrun = pr.mrun;
         // ---- forward of the dense head (same formulas as head_train_kernel) ----
-        const bool vb = b < a.B && !(a.ablate & 512);
+        const bool vb = b < a.B && !ablated(a.ablate, 512);
         const float rden = 1.0f / den;
         const float p = lane < H ? pooled * rden : 0.f;
         if (lane < H && vb) a.pooled[(size_t)b * H + lane] = p;

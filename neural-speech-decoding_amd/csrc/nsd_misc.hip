@@ -71,9 +71,19 @@ __global__ __launch_bounds__(GR_COLS * GR_GROUPS) void grad_reduce_kernel(
         const float *p; long stride; int n;
         if (e < p_lstm) { p = slabs + e; stride = slab_stride; n = n_slabs; }
         else { p = hslabs + (e - p_lstm); stride = ph; n = n_hslabs; }
+        // 8 independent loads in flight per thread (the sum is latency-bound, not bandwidth-bound: 32 rows per thread)
         int q = grp;
-        for (; q + GR_GROUPS < n; q += 2 * GR_GROUPS) { s0 += p[(size_t)q * stride]; s1 += p[(size_t)(q + GR_GROUPS) * stride]; }
-        if (q < n) s0 += p[(size_t)q * stride];
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f;
+        for (; q + 7 * GR_GROUPS < n; q += 8 * GR_GROUPS) {
+            const float v0 = p[(size_t)q * stride], v1 = p[(size_t)(q + GR_GROUPS) * stride];
+            const float v2 = p[(size_t)(q + 2 * GR_GROUPS) * stride], v3 = p[(size_t)(q + 3 * GR_GROUPS) * stride];
+            const float v4 = p[(size_t)(q + 4 * GR_GROUPS) * stride], v5 = p[(size_t)(q + 5 * GR_GROUPS) * stride];
+            const float v6 = p[(size_t)(q + 6 * GR_GROUPS) * stride], v7 = p[(size_t)(q + 7 * GR_GROUPS) * stride];
+            s0 += v0; s1 += v1; t0 += v2; t1 += v3; t2 += v4; t3 += v5; t4 += v6; t5 += v7;
+        }
+        for (; q < n; q += GR_GROUPS) s0 += p[(size_t)q * stride];
+        s0 = (s0 + t0) + (t2 + t4);
+        s1 = (s1 + t1) + (t3 + t5);
     }
     part[grp][c] = s0 + s1;
     __syncthreads();

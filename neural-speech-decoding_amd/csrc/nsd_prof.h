@@ -8,6 +8,10 @@
 #endif
 constexpr bool kProfile = NSD_PROFILE != 0;
 
+// timing-experiment switches (env NSD_ABLATE, tools/kbench.py --ablate): compiled into the diagnostic build only -- in the
+// shipped library every test folds to false
+__device__ __forceinline__ bool ablated(const int mask, const int bit) { return kProfile && (mask & bit) != 0; }
+
 struct Prof {
     long long work, wait, last;
     long long seg[6], mark;

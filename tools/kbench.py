@@ -2,7 +2,8 @@
 """Per-kernel timing of the LSTM forward / backward launches (HIP events), optionally under the
 NSD_ABLATE timing switches of csrc (results are wrong under ablation; only the clock matters).
 
-    python tools/kbench.py [--B 256] [--T 250] [--iters 20] [--ablate 0,1,2,4,8,16]
+    python tools/kbench.py [--B 256] [--T 250] [--iters 20]
+    NSD_LIB=libnsd_hip_prof.so python tools/kbench.py --ablate 0,1,64,128 [--prof]     (switches exist in the diagnostic build only)
 """
 import argparse
 import os
