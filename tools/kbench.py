@@ -81,7 +81,8 @@ def main():
                 L.nsd_debug_profile_buffer(dbg.data_ptr())
                 if which == "fwd":
                     L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, st)
-                    roles = ["L1"] * 3 + ["L0"] * 3 + ["P"] * 3 + ["saver"]
+                    # role table of lstm2_fwd48_kernel: SIMD g = wave & 3, slot q = wave >> 2
+                    roles = ["L1", "L1", "L1", "P", "L0", "L0", "L0", "P", "saver", "spare", "spare", "P"]
                     nst = ((T + 2 + 31) // 32) * 32
                 else:
                     L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st)
