@@ -194,6 +194,43 @@ def test_single_launch_lstm_plus_head_train(nsd, dev, ref_state, B, T, residual)
         _grad_close(a["grads"], g_ref, D, rtol=3e-4)
 
 
+def test_randomised_shapes_train_step_and_inference_vs_oracle(nsd, dev, ref_state):
+    """Seeded random (B, T) draws: the shipped train-step launch sequence and the single-launch inference against the
+    oracle (ragged batches, T not a multiple of any chunk size, T = 1..70)."""
+    rng = np.random.default_rng(20261003)
+    flat_np = orc.flatten_state(ref_state, D)
+    m = _model(nsd, dev, ref_state).eval()
+    for _ in range(12):
+        B, T = int(rng.integers(1, 41)), int(rng.integers(1, 71))
+        x, y = synth_x(B, T, seed=int(rng.integers(1 << 30))), synth_labels(B, seed=int(rng.integers(1 << 30)))
+        dl, sl, dh = counter_masks(B, T, 48, 32, seed=int(rng.integers(1 << 30)))
+        loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, D, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+        a = _hip_step(nsd, dev, flat_np, x, y, True, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+        assert np.abs(a["logits"] - fw["logits"]).max() < LOGIT_TOL, (B, T)
+        assert abs(float(a["loss"].sum()) / B - loss_ref) < 5e-5, (B, T)
+        _grad_close(a["grads"], g_ref, D, rtol=3e-4)
+        with torch.no_grad():
+            lg = m(_t(x, dev)).cpu().numpy()
+        ref = orc.forward(flat_np, x, D)["logits"]
+        assert np.abs(lg - ref).max() < LOGIT_TOL and np.array_equal(lg.argmax(1), ref.argmax(1)), (B, T)
+
+
+@pytest.mark.parametrize("B,T", [(2, 1023), (2, 1025), (257, 9), (513, 4)])
+def test_fused_path_boundaries(nsd, dev, ref_state, B, T):
+    """Either side of the single-launch limits (T = 1024) and of the one-trial-per-CU grid (B = 256, 512): the fused
+    entry point and the launches it replaces agree on every output."""
+    flat_np = orc.flatten_state(ref_state, D)
+    x, y = synth_x(B, T, seed=B + T), synth_labels(B, seed=B)
+    dl, sl, dh = counter_masks(B, T, 48, 32, seed=B * T)
+    masks = dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    a = _hip_step(nsd, dev, flat_np, x, y, True, **masks)
+    b = _hip_step(nsd, dev, flat_np, x, y, False, **masks)
+    for k in ("logits", "alpha", "pooled", "loss"):
+        assert np.isfinite(a[k]).all(), k
+        assert np.abs(a[k] - b[k]).max() <= 2e-5 * max(1.0, np.abs(b[k]).max()), k
+    _grad_close(a["grads"], b["grads"], D, rtol=2e-4)
+
+
 def test_gradients_vs_reference_goldens(nsd, dev, golden, ref_state):
     g = golden("grads_32x250")
     flat_np = orc.flatten_state(ref_state, D)
