@@ -4,24 +4,25 @@
 // (H=48, L=2, C<=8): torch.nn.LSTM semantics, gate order i,f,g,o, two biases, zero initial state, dropout
 // multipliers on the layer-0 output.
 //
-// Measured facts that shape it (MI355X): one wave issues at most one VALU instruction per
-// 4 cycles, two or more waves on a SIMD reach one per 2 cycles; a step of the recurrence is a dependent
-// chain (LDS -> FMAs -> quad reduction -> sigma/tanh -> LDS -> barrier).  So the step time is set by the
-// instruction count of the slowest wave: the work of a step is spread over 9 waves in three roles, every
-// mat-vec is issued as v_pk_fma_f32 (2 FMA per instruction, pairs along k), and nothing on the chain
-// touches HBM:
+// One workgroup = one trial, one barrier per time step, all weights in VGPRs, operands through LDS, nothing on
+// the recurrence touches HBM.  A step is a dependent chain (LDS -> FMAs -> quad reduction -> sigma/tanh -> LDS ->
+// barrier); what the measurements say about it (MI355X): every mat-vec goes out as v_pk_fma_f32
+// with four independent accumulator pairs; the chain after the FMAs is cut to 16 dependent ops; the LDS serves
+// requests in arrival order, so helper waves sleep a little after each barrier; waves are placed on SIMDs by role.
 //
-//   waves 0-2  "L1"   layer 1, step t = m-2      : W_hh1 h1_{t-1} (24 pk_fma) + P_t, cell update
-//   waves 3-5  "L0"   layer 0, step t = m        : W_ih0 x_t + W_hh0 h0_{t-1}  (28 pk_fma), cell update,
-//                                                  dropout multiplier, h0 / masked h0 to LDS
-//   waves 6-8  "P"    layer-1 input projection of step t = m-1 : W_ih1 in1_t (24 pk_fma) -> LDS
-//   wave  9    "saver" (training) LDS save ring -> HBM, or "pool" (inference) attention pooling + head
-//   wave  10   "tpool" (training with the fused head only) attention pooling along the recurrence + the head's
-//                      forward / loss / backward in the kernel tail
+// 12 waves, role = f(SIMD g = wave & 3, slot q = wave >> 2)   (the dispatcher deals waves round-robin over the SIMDs):
+//   g 0..2, q 0  "L1"   layer 1 part g, step t = m-2 : W_hh1 h1_{t-1} (24 pk_fma) + P_t, cell update
+//   g 0..2, q 1  "L0"   layer 0 part g, step t = m   : W_ih0 x_t + W_hh0 h0_{t-1} (28 pk_fma), cell update,
+//                                                      dropout multiplier, h0 / masked h0 to LDS
+//   g 3,    q 0..2 "P"  layer-1 input projection of step t = m-1 : W_ih1 in1_t (24 pk_fma) -> LDS
+//   g 0, q 2  "saver" (training) LDS save ring -> HBM, or "pool" (inference): attention pooling + head, one launch
+//   g 1, q 2  "tpool" (training with the fused head) attention pooling along the recurrence + the head's
+//                     forward / loss / backward in the kernel tail; otherwise spare
+//   g 2, q 2  "spare"  generates the dropout multipliers when the random streams are drawn in the kernel
 //
 // Thread (unit j, k-slice s) in every chain role: 4 gates x 12 (or 2) weights in VGPRs, operands broadcast from
-// LDS, DPP quad reduction, lane s of the quad evaluates gate s.  One barrier per step.  x and the dropout
-// multipliers are staged through LDS in 32-step chunks, prefetched one chunk ahead.
+// LDS, DPP quad reduction, lane s of the quad evaluates gate s.  x and the dropout multipliers are staged through
+// LDS in 32-step chunks, prefetched one chunk ahead.
 #include "nsd_args.h"
 #include "nsd_prof.h"
 
