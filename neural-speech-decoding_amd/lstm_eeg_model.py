@@ -241,3 +241,25 @@ class SimplePredictor:
         probs = self.model.predict_proba(x_t)[0].cpu().numpy().astype(np.float32)
         y_idx = int(np.argmax(probs))
         return probs, self.class_names[y_idx]
+
+    def predict_windows(self, recording_NxC: np.ndarray, window: int, hop: Optional[int] = None):
+        """Batched / streaming mode: classify every `window`-sample window of a longer recording
+        [N, C], `hop` samples apart (default: back to back, the live loop of tester.py:52-96 run over a file), in ONE
+        launch.  Each window goes through the same preprocess -> model -> softmax as predict(), so
+        predict_windows(r, T)[0][k] == predict(r[k*hop : k*hop + T])[0].  Returns (probs float32 [n, K], labels list[str])."""
+        rec = np.asarray(recording_NxC)
+        if rec.ndim != 2:
+            raise ValueError("recording must be 2-D [N, C]")
+        hop = int(hop) if hop is not None else int(window)
+        if window < 1 or hop < 1:
+            raise ValueError("window and hop must be positive")
+        starts = list(range(0, rec.shape[0] - window + 1, hop))
+        K = len(self.class_names)
+        if not starts:
+            return np.zeros((0, K), np.float32), []
+        # the preprocessor is per window by contract (the MindsAI filter is not shift-invariant): host side, like predict()
+        xs = np.stack([np.ascontiguousarray(self.pre.transform(rec[s0:s0 + window]), dtype=np.float32) for s0 in starts])
+        x_t = torch.from_numpy(xs).to(self.gpu, non_blocking=True)
+        probs = self.model.predict_proba(x_t).cpu().numpy().astype(np.float32)
+        return probs, [self.class_names[int(i)] for i in probs.argmax(1)]
+

@@ -620,6 +620,25 @@ def test_simple_predictor(nsd, dev, golden, ref_state, tmp_path, wrapped):
         pred.predict(np.zeros((2, 3, 4), np.float32))
 
 
+def test_predict_windows_equals_per_window_predict(nsd, dev, golden, ref_state, tmp_path):
+    """Batched / streaming mode: every window of a long recording in one launch == predict() per window."""
+    g = golden("real_trials")
+    pred = nsd.SimplePredictor(_write_pth(str(tmp_path), ref_state, False), sr=125, device="cpu",
+                               class_names=["Food", "Water", "None"])
+    rec = np.concatenate([g["x"][0], g["x"][3], g["x"][9]], axis=0)            # [1875, 8]
+    for window, hop in ((625, None), (250, 100), (625, 625), (2000, 1)):
+        probs, labels = pred.predict_windows(rec, window, hop)
+        h = window if hop is None else hop
+        starts = list(range(0, rec.shape[0] - window + 1, h))
+        assert probs.shape == (len(starts), 3) and len(labels) == len(starts)
+        for k, s0 in enumerate(starts):
+            p1, l1 = pred.predict(rec[s0:s0 + window])
+            assert np.abs(probs[k] - p1).max() < 2e-6 and labels[k] == l1
+    assert np.abs(pred.predict_windows(rec, 625)[0][0] - g["probs"][0]).max() < 1e-5
+    with pytest.raises(ValueError):
+        pred.predict_windows(rec[None], 625)
+
+
 def test_run_trials_replay(nsd, dev, golden, ref_state, tmp_path):
     g = golden("real_trials")
     d = tmp_path / "trials"
