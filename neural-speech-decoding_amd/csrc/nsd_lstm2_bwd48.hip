@@ -351,6 +351,13 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
             step_barrier<false, DW_SLEEP>(prof);
             step_barrier<false, DW_SLEEP>(prof);
         }
+        // the last group: its da sits in the ring until the chains of the next trial start (after this wave's next barrier),
+        // its B operands were fetched during the group -- no extra barrier-synchronised steps for the whole workgroup
+        if (!ablated(a.ablate, 1)) {
+            dw_compute<0, NB>(a, sm, st, n_groups - 1, dwid, lane);
+            dw_compute<1, NB>(a, sm, st, n_groups - 1, dwid, lane);
+            dw_compute<2, NB>(a, sm, st, n_groups - 1, dwid, lane);
+        }
     }
     prof_store(a.dbg, prof);
     // accumulator tile -> slab: lane holds rows 4*(lane>>4)+r, column lane&15 of each 16x16 tile
@@ -491,11 +498,10 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     __shared__ __align__(16) Smem<NB> sm;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // every role runs the same number of barriers: 4 per 4-step group, groups cover macro steps 0..T+2
-    // plus one more group so that the dW waves can drain the last one
-    // groups of 4 macro steps: the last chain step is T+1 and the x1 waves need T+2 (group (T+2)/4); one more group lets the
-    // dW waves drain the last one; rounded up to even because the loader walks whole 8-step chunks
-    const int n_groups = (((a.T + 2) / 4 + 1) + 1 + 1) & ~1;
+    // every role runs the same number of barriers: 4 per 4-step group.  The last chain step is macro step T+1 and the x1
+    // waves need T+2 (group (T+2)/4); rounded up to even because the loader walks whole 8-step chunks.  (The dW waves
+    // finish the last group after the loop, on their own.)
+    const int n_groups = (((a.T + 2) / 4 + 1) + 1) & ~1;
     const int n_steps = 4 * n_groups;
     // issue priority follows the critical path: the two recurrences first, then the hand-off to layer 0
     if (wave < 3)       { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 1, tid, n_steps); }

@@ -87,7 +87,7 @@ def main():
                 else:
                     L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st)
                     roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1"] * 3 + ["dW"] * 6 + ["loader"]
-                    nst = 4 * ((((T + 2) // 4 + 2) + 1) & ~1)
+                    nst = 4 * ((((T + 2) // 4 + 1) + 1) & ~1)
                 torch.cuda.synchronize()
                 L.nsd_debug_profile_buffer(None)
                 hw = dbg.cpu().numpy()[256:]
