@@ -493,7 +493,10 @@ def test_multi_rank_launch_sequence_over_rccl_single_rank_group(nsd, dev, ref_st
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     created = not dist.is_initialized()
     if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        except Exception as e:                                   # environment without a usable RCCL rendezvous
+            pytest.skip(f"cannot create a 1-rank nccl group here: {e}")
     try:
         B, T = 24, 50
         x, y = _t(synth_x(B, T, seed=31), dev), _t(synth_labels(B, seed=31), dev)
