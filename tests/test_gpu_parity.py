@@ -231,6 +231,26 @@ def test_fused_path_boundaries(nsd, dev, ref_state, B, T):
     _grad_close(a["grads"], b["grads"], D, rtol=2e-4)
 
 
+@pytest.mark.parametrize("scale", [1e-6, 50.0, 3000.0])
+def test_tiny_and_saturating_inputs(nsd, dev, ref_state, scale):
+    """Gates driven to both rails (|pre-activation| up to ~1e4) and inputs near zero: no NaN/Inf, logits still within
+    tolerance of the oracle (exp2 overflow must land on the exact sigmoid/tanh limits)."""
+    flat_np = orc.flatten_state(ref_state, D)
+    B, T = 9, 60
+    x = (synth_x(B, T, seed=77) * scale / 2.7).astype(np.float32)
+    y = synth_labels(B, seed=77)
+    m = _model(nsd, dev, ref_state).eval()
+    with torch.no_grad():
+        lg = m(_t(x, dev)).cpu().numpy()
+    ref = orc.forward(flat_np, x, D)["logits"]
+    assert np.isfinite(lg).all()
+    assert np.abs(lg - ref).max() < LOGIT_TOL * max(1.0, np.abs(ref).max() / 10.0)
+    a = _hip_step(nsd, dev, flat_np, x, y, True)
+    loss_ref, g_ref, _ = orc.loss_and_grads(flat_np, x, y, D)
+    assert np.isfinite(a["grads"]).all() and abs(float(a["loss"].sum()) / B - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    _grad_close(a["grads"], g_ref, D, rtol=5e-4)
+
+
 def test_gradients_vs_reference_goldens(nsd, dev, golden, ref_state):
     g = golden("grads_32x250")
     flat_np = orc.flatten_state(ref_state, D)
