@@ -394,19 +394,33 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
         d[q].base = (char *)dst; d[q].row_bytes = rb;
     }
     Prof prof = prof_init(a.dbg);
+    // The LDS reads of a batch of pieces are all issued before the first store: one LDS latency per call instead of one
+    // per piece (the lane conditions are divergent, so the compiler would otherwise serialise read -> wait -> store).
     auto flush = [&](const int chunk, const int b0, const int q0, const int q1) {
+        const float *ring = &sm.sv[(chunk & 1) * SCH][0][0][0];
 #pragma unroll
-        for (int q = 0; q < SPIECES; ++q) {
-            if (q < q0 || q >= q1) continue;
-            const int t = d[q].t0 + SCH * chunk;
-            if (d[q].base && (unsigned)t < (unsigned)T) {
+        for (int qb = 0; qb < SPIECES; qb += 3) {
+            if (qb < q0 || qb >= q1) continue;
+            float4 v[3][NB];
+            bool ok[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int q = qb + u;
+                const int t = d[q].t0 + SCH * chunk;
+                ok[u] = d[q].base && (unsigned)t < (unsigned)T;
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    v[u][n] = ok[u] ? *reinterpret_cast<const float4 *>(ring + d[q].lds_off + n * 2 * SREC) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int q = qb + u;
+                const int t = d[q].t0 + SCH * chunk;
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     const int b = b0 + n;
-                    if (b < a.B) {
-                        const float4 v = *reinterpret_cast<const float4 *>(&sm.sv[(chunk & 1) * SCH][0][0][0] + d[q].lds_off + n * 2 * SREC);
-                        *reinterpret_cast<float4 *>(d[q].base + (size_t)((unsigned)(b * T + t)) * (unsigned)d[q].row_bytes) = v;
-                    }
+                    if (ok[u] && b < a.B)
+                        *reinterpret_cast<float4 *>(d[q].base + (size_t)((unsigned)(b * T + t)) * (unsigned)d[q].row_bytes) = v[u][n];
                 }
             }
         }

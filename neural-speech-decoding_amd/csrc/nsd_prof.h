@@ -10,7 +10,10 @@ constexpr bool kProfile = NSD_PROFILE != 0;
 
 // timing-experiment switches (env NSD_ABLATE, tools/kbench.py --ablate): compiled into the diagnostic build only -- in the
 // shipped library every test folds to false
-__device__ __forceinline__ bool ablated(const int mask, const int bit) { return kProfile && (mask & bit) != 0; }
+#ifndef NSD_ABLATE_HOOKS
+#define NSD_ABLATE_HOOKS 0          // 1: keep the switches without the cycle stamps (tools/sweep.sh ... -DNSD_ABLATE_HOOKS=1)
+#endif
+__device__ __forceinline__ bool ablated(const int mask, const int bit) { return (kProfile || NSD_ABLATE_HOOKS) && (mask & bit) != 0; }
 
 struct Prof {
     long long work, wait, last;
