@@ -456,6 +456,35 @@ def test_trainer_step_matches_oracle_with_its_own_streams(nsd, dev, ref_state):
     assert np.abs(m.flat_parameters().cpu().numpy() - p).max() < 2e-6
 
 
+def test_thirty_step_training_trajectory_matches_oracle(nsd, dev, ref_state):
+    """End to end over many steps: 30 Trainer.step calls (in-kernel random streams, fused launches, Adam) against 30
+    oracle steps with the same counter-based masks: the loss curve and the final parameters stay together."""
+    from nsd_amd.trainer import Trainer
+    m = _model(nsd, dev, ref_state).train()
+    tr = Trainer(m, lr=1e-3, seed=5)
+    B, T = 16, 40
+    x, y = synth_x(B, T, seed=40), synth_labels(B, seed=40)
+    xt, yt = _t(x, dev), _t(y, dev)
+    p = orc.flatten_state(ref_state, D).copy()
+    mm, vv = np.zeros_like(p), np.zeros_like(p)
+    for step in range(1, 31):
+        tr.step(xt, yt)
+        sid = 4 * step
+        dl = orc.dropout_mask(tr.seed, sid, 0.6, (1, B, T, 48))
+        sl = orc.rrelu_noise(tr.seed, sid + 1, (B, 32))
+        dh = orc.dropout_mask(tr.seed, sid + 2, 0.6, (B, 32))
+        loss_ref, g_ref, _ = orc.loss_and_grads(p, x, y, D, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+        orc.adam(p, g_ref, mm, vv, lr=1e-3, step=step)
+        assert abs(tr.last_loss() - loss_ref) < 2e-4 * max(1.0, abs(loss_ref)), (step, tr.last_loss(), loss_ref)
+    got = m.flat_parameters().cpu().numpy()
+    # Adam normalises by sqrt(v): the few entries whose gradient is ~eps (|g| ~ 1e-9) take +-lr steps whose sign is
+    # decided by rounding noise, so the max is bounded only by steps * 2 * lr; everything else must stay together
+    diff = np.abs(got - p)
+    assert diff.max() <= 30 * 2e-3
+    assert np.mean(diff > 1e-4) < 0.01, np.mean(diff > 1e-4)
+    assert np.median(diff) < 2e-6
+
+
 def test_fused_reduce_adam_is_bit_identical_to_separate_launches(nsd, dev, ref_state):
     """nsd_grad_reduce_adam == nsd_grad_reduce followed by nsd_adam_step (same arithmetic, same order)."""
     from nsd_amd import ops
