@@ -54,8 +54,12 @@ int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t
 // One workgroup = 32 consecutive gradient entries x 8 slab groups: lane (c = tid&31, grp = tid>>5) sums its share
 // of the slabs for column c (consecutive lanes read 128 contiguous bytes of a slab row), the 8 partials meet
 // in LDS in a fixed order (deterministic).  ~1000 workgroups for the reference model instead of 124.
+#ifndef GR_COLS
 #define GR_COLS 32
+#endif
+#ifndef GR_GROUPS
 #define GR_GROUPS 8
+#endif
 // optional optimizer tail of the reduction (single-rank training: no all-reduce sits between the two)
 struct AdamTail { float *p, *m, *v; float lr_over_bc1, rsqrt_bc2, beta1, beta2, eps, wd, gscale; };
 
