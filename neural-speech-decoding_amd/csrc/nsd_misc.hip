@@ -60,6 +60,9 @@ int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t
 #ifndef GR_GROUPS
 #define GR_GROUPS 8
 #endif
+#ifndef GR_UNROLL
+#define GR_UNROLL 8
+#endif
 // optional optimizer tail of the reduction (single-rank training: no all-reduce sits between the two)
 struct AdamTail { float *p, *m, *v; float lr_over_bc1, rsqrt_bc2, beta1, beta2, eps, wd, gscale; };
 
@@ -75,19 +78,25 @@ __global__ __launch_bounds__(GR_COLS * GR_GROUPS) void grad_reduce_kernel(
         const float *p; long stride; int n;
         if (e < p_lstm) { p = slabs + e; stride = slab_stride; n = n_slabs; }
         else { p = hslabs + (e - p_lstm); stride = ph; n = n_hslabs; }
-        // 8 independent loads in flight per thread (the sum is latency-bound, not bandwidth-bound: 32 rows per thread)
+        // GR_UNROLL independent loads in flight per thread; fixed association order -> deterministic.  (Measured: 8, 16
+        // and 32 in flight all run at ~4.9 TB/s for the 32.6 MB of slabs -- the sum sits at the memory roof.)
         int q = grp;
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f;
-        for (; q + 7 * GR_GROUPS < n; q += 8 * GR_GROUPS) {
-            const float v0 = p[(size_t)q * stride], v1 = p[(size_t)(q + GR_GROUPS) * stride];
-            const float v2 = p[(size_t)(q + 2 * GR_GROUPS) * stride], v3 = p[(size_t)(q + 3 * GR_GROUPS) * stride];
-            const float v4 = p[(size_t)(q + 4 * GR_GROUPS) * stride], v5 = p[(size_t)(q + 5 * GR_GROUPS) * stride];
-            const float v6 = p[(size_t)(q + 6 * GR_GROUPS) * stride], v7 = p[(size_t)(q + 7 * GR_GROUPS) * stride];
-            s0 += v0; s1 += v1; t0 += v2; t1 += v3; t2 += v4; t3 += v5; t4 += v6; t5 += v7;
+        float acc[GR_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GR_UNROLL; ++u) acc[u] = 0.f;
+        for (; q + (GR_UNROLL - 1) * GR_GROUPS < n; q += GR_UNROLL * GR_GROUPS) {
+            float vload[GR_UNROLL];
+#pragma unroll
+            for (int u = 0; u < GR_UNROLL; ++u) vload[u] = p[(size_t)(q + u * GR_GROUPS) * stride];
+#pragma unroll
+            for (int u = 0; u < GR_UNROLL; ++u) acc[u] += vload[u];
         }
-        for (; q < n; q += GR_GROUPS) s0 += p[(size_t)q * stride];
-        s0 = (s0 + t0) + (t2 + t4);
-        s1 = (s1 + t1) + (t3 + t5);
+        for (; q < n; q += GR_GROUPS) acc[0] += p[(size_t)q * stride];
+#pragma unroll
+        for (int w = GR_UNROLL / 2; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+        s0 = acc[0];
     }
     part[grp][c] = s0 + s1;
     __syncthreads();
