@@ -90,7 +90,8 @@ static nsd_ws_layout make_ws(const nsd_dims *d, bool have_device) {
     w.slabs = p;   p = align4(p + nsl * align4(pl.lstm_total));
     w.hslabs = p;  p = align4(p + B * (pl.total - pl.lstm_total));
     w.da_seq = p;  if (!fast) p = align4(p + B * T * 4 * H);
-    w.din = p;     if (!fast) p = align4(p + 2 * B * T * H);
+    // din: two [B,T,H] ping-pong buffers + the batched path's per-step state [3,B,H] and split-K partials [4][4H x max(C,H)]
+    w.din = p;     if (!fast) p = align4(p + 2 * B * T * H + 3 * B * H + 4 * 4 * H * (H > d->C ? H : (int64_t)d->C));
     w.total = p;
     return w;
 }
@@ -262,6 +263,10 @@ int nsd_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const f
     const nsd_ws_layout w = make_ws(d, true);
     if (!fast_path_ok(d)) {
         const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
+        if (nsd_lstm_batched_ok(d, true))        // large H: per-step batched gate GEMM on the matrix pipe
+            return nsd_lstm_batched_fwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
+                                        workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.top,
+                                        (hipStream_t)stream);
         return nsd_lstm_generic_fwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
                                     workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.top, nullptr,
                                     (hipStream_t)stream);
@@ -386,6 +391,11 @@ static int lstm_bwd_impl(const nsd_dims *d, const float *params, const float *x,
     const nsd_ws_layout w = make_ws(d, true);
     const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
     const int64_t BTH = (int64_t)d->B * d->T * d->H;
+    if (!fast_path_ok(d) && nsd_lstm_batched_ok(d, true))
+        return nsd_lstm_batched_bwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
+                                    workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.alpha,
+                                    workspace + w.dscore, workspace + w.dpooled, workspace + w.da_seq, workspace + w.din,
+                                    workspace + w.din + BTH, workspace + w.din + 2 * BTH, workspace + w.slabs, (hipStream_t)stream);
     if (!fast_path_ok(d))
         return nsd_lstm_generic_bwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
                                     workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.alpha,

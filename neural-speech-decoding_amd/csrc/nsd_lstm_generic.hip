@@ -10,7 +10,7 @@
 //             mat-vecs read W column-wise (coalesced); the weight gradients are NOT accumulated in the time
 //             loop but afterwards as  dW = da_seq^T . operand_seq  by a tiled fp32 GEMM over all (b, t)
 //             (deterministic: one workgroup owns each output tile, fixed summation order).
-// The tuned path for large H (batched gate GEMM on MFMA, bf16 storage) is future work.
+// Large hidden sizes in training take the batched MFMA path of nsd_lstm_batched.hip instead (H % 16 == 0, B >= 16).
 #include <string.h>
 #include "nsd_args.h"
 

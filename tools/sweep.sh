@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../neural-speech-decoding_amd/csrc"
 src=$1; shift
 make -s -j4 >/dev/null 2>&1
 i=0
-objs="nsd_abi.o nsd_lstm2.o nsd_lstm2_fwd48.o nsd_lstm2_bwd48.o nsd_lstm_generic.o nsd_head.o nsd_misc.o"
+objs="nsd_abi.o nsd_lstm2.o nsd_lstm2_fwd48.o nsd_lstm2_bwd48.o nsd_lstm_generic.o nsd_lstm_batched.o nsd_head.o nsd_misc.o"
 libs="libnsd_hip.so"
 for flags in "$@"; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off $flags -c $src -o /tmp/sweep_$i.o
