@@ -216,7 +216,9 @@ static int make_rng(const nsd_rng *r, RngArgs *out) {
 
 int64_t nsd_infer_scratch_bytes(const nsd_dims *d) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
-    return (fast_path_ok(d) ? 1 : 2) * align4((int64_t)d->B * d->T * d->H) * (int64_t)sizeof(float);
+    if (fast_path_ok(d)) return align4((int64_t)d->B * d->T * d->H) * (int64_t)sizeof(float);
+    // two [B,T,H] ping-pong buffers + the batched path's cell-state ping-pong 2 x [B,H]
+    return (2 * align4((int64_t)d->B * d->T * d->H) + align4(2 * (int64_t)d->B * d->H)) * (int64_t)sizeof(float);
 }
 
 int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t flags, float *logits, float *probs,
@@ -245,8 +247,12 @@ int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t f
     } else {
         const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
         float *top = (float *)scratch;
-        rc = nsd_lstm_generic_fwd(d, pl, params, x, nullptr, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, nullptr, nullptr, nullptr, nullptr,
-                                  top, top + align4((int64_t)d->B * d->T * d->H), (hipStream_t)stream);
+        const int64_t bth = align4((int64_t)d->B * d->T * d->H);
+        if (nsd_lstm_batched_ok(d, false) && !(flags & NSD_FLAG_RESIDUAL))
+            rc = nsd_lstm_batched_infer(d, pl, params, x, top, top + bth, top + 2 * bth, (hipStream_t)stream);
+        else
+            rc = nsd_lstm_generic_fwd(d, pl, params, x, nullptr, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, nullptr, nullptr, nullptr, nullptr,
+                                      top, top + bth, (hipStream_t)stream);
     }
     if (rc != NSD_OK) return rc;
     HeadArgs h = build_head(d, params);

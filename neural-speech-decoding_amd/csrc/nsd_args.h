@@ -75,6 +75,8 @@ int nsd_lstm_generic_bwd(const nsd_dims *d, const ParamLayout &pl, const float *
                          const float *alpha, const float *dscore, const float *dpooled, float *da_seq, float *din_a, float *din_b,
                          float *slab, hipStream_t st);
 bool nsd_lstm_batched_ok(const nsd_dims *d, bool training);
+int nsd_lstm_batched_infer(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, float *top_out,
+                           float *scratch2, float *cstate, hipStream_t st);
 int nsd_lstm_batched_fwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,
                          int residual, float *hseq, float *cseq, float *gact, float *inseq, float *top_out, hipStream_t st);
 int nsd_lstm_batched_bwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,

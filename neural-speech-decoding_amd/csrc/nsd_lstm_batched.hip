@@ -105,8 +105,11 @@ struct StepFwdArgs {
     const float *w_ih, *w_hh, *b_ih, *b_hh;
     const float *mask;        // [B,T,H] multipliers on this layer's output (null: none)
     const float *res_in;      // [B,T,H] residual input to add (null: none)
-    float *hseq, *cseq, *gact;   // [B,T,H], [B,T,H], [B,T,H,4]
+    float *hseq, *cseq, *gact;   // [B,T,H], [B,T,H], [B,T,H,4]   (null in inference)
     float *out;               // [B,T,H] linked output = (h + res) * mask
+    const float *hprev;       // sequence h_{t-1} is read from: hseq (training) or out (inference: out == h there)
+    const float *c_in;        // inference: cell state [B,H] of step t-1 ...
+    float *c_out;             // ... and of step t (ping-pong); training reads / writes cseq instead
     int B, T, I, H, t;
 };
 
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdArgs a) {
     for (int seg = 0; seg < 2; ++seg) {
         const int K = seg == 0 ? I : H;
         if (seg == 1 && t == 0) break;
-        const float *src = seg == 0 ? a.in : a.hseq;
+        const float *src = seg == 0 ? a.in : a.hprev;
         const int tt = seg == 0 ? t : t - 1;
         const float *w = seg == 0 ? a.w_ih : a.w_hh;
         if ((K & (KC - 1)) == 0) {
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdArgs a) {
     for (int r = 0; r < 16; ++r) {
         const int b = b0 + 32 * wm + acc_row(r, lane);
         const size_t row = (size_t)(b < a.B ? b : 0) * T + t;
-        cp[r] = t > 0 ? a.cseq[(row - 1) * H + u] : 0.f;
+        const size_t bh = (size_t)(b < a.B ? b : 0) * H + u;
+        cp[r] = t == 0 ? 0.f : (a.cseq ? a.cseq[(row - 1) * H + u] : a.c_in[bh]);
         rs[r] = a.res_in ? a.res_in[row * H + u] : 0.f;
         mk[r] = a.mask ? a.mask[row * H + u] : 1.f;
     }
@@ -186,10 +190,10 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdArgs a) {
         const float h = og * fast_tanh(cn);
         if (b < a.B) {
             const size_t row = (size_t)b * T + t;
-            a.gact[(row * H + u) * 4 + g] = act;
+            if (a.gact) a.gact[(row * H + u) * 4 + g] = act;
             if (g == 0) {
-                a.cseq[row * H + u] = cn;
-                a.hseq[row * H + u] = h;
+                if (a.cseq) { a.cseq[row * H + u] = cn; a.hseq[row * H + u] = h; }
+                else        a.c_out[(size_t)b * H + u] = cn;
                 a.out[row * H + u] = (h + rs[r]) * mk[r];
             }
         }
@@ -380,7 +384,35 @@ __global__ void sum_parts2_kernel(const float *part, int nparts, long n, float *
 // ---------------------------------------------------------------------------------------------------------------
 bool nsd_lstm_batched_ok(const nsd_dims *d, bool training) {
     // (16-byte operand loads: the channel count must be a multiple of 4 as well)
-    return training && d->H % 16 == 0 && d->H >= 64 && d->B >= 16 && d->C % 4 == 0;
+    (void)training;
+    return d->H % 16 == 0 && d->H >= 64 && d->B >= 16 && d->C % 4 == 0;
+}
+
+// inference (no residual): only the linked outputs are produced, ping-ponging between top_out and scratch2 so that the
+// last layer lands in top_out; cstate: 2 x [B,H] cell-state ping-pong
+int nsd_lstm_batched_infer(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, float *top_out,
+                           float *scratch2, float *cstate, hipStream_t st) {
+    const int B = d->B, T = d->T, H = d->H, L = d->L;
+    const float *in = x;
+    for (int l = 0; l < L; ++l) {
+        StepFwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = in; a.I = l == 0 ? d->C : H;
+        a.w_ih = params + pl.w_ih[l]; a.w_hh = params + pl.w_hh[l]; a.b_ih = params + pl.b_ih[l]; a.b_hh = params + pl.b_hh[l];
+        a.out = ((L - 1 - l) & 1) ? scratch2 : top_out;
+        a.hprev = a.out;                                     // no residual, no multipliers: the linked output is h itself
+        a.B = B; a.T = T; a.H = H;
+        const dim3 grid((B + TM - 1) / TM, (H + 15) / 16);
+        for (int t = 0; t < T; ++t) {
+            a.t = t;
+            a.c_in = cstate + (size_t)(t & 1) * B * H;
+            a.c_out = cstate + (size_t)((t + 1) & 1) * B * H;
+            hipLaunchKernelGGL(lstm_step_fwd_mfma, grid, dim3(256), 0, st, a);
+        }
+        NSD_CHECK_LAUNCH("lstm_step_fwd_mfma");
+        in = a.out;
+    }
+    return NSD_OK;
 }
 
 int nsd_lstm_batched_fwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,
@@ -397,6 +429,7 @@ int nsd_lstm_batched_fwd(const nsd_dims *d, const ParamLayout &pl, const float *
         a.res_in = (residual && l >= 1) ? in : nullptr;
         a.hseq = hseq + (int64_t)l * BTH; a.cseq = cseq + (int64_t)l * BTH; a.gact = gact + (int64_t)l * 4 * BTH;
         a.out = (l == L - 1) ? top_out : inseq + (int64_t)l * BTH;
+        a.hprev = a.hseq;
         a.B = B; a.T = T; a.H = H;
         const dim3 grid((B + TM - 1) / TM, (H + 15) / 16);
         for (int t = 0; t < T; ++t) {

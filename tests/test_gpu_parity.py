@@ -385,6 +385,12 @@ def test_batched_mfma_path_vs_oracle(nsd, dev, C, H, L, K, residual, B, T):
     loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, x, y, spec=spec, **kw)
     assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
     _grad_close(grads, g_ref, d, rtol=3e-4)
+    # inference on the same kernels (cell state carried in a [B,H] ping-pong instead of the saved sequences)
+    flat = _t(flat_np, dev)
+    lg, pr = ops.infer(spec, flat, _t(x, dev), residual=residual)
+    ref = orc.forward(flat_np, x, d, residual=residual)
+    assert np.abs(lg.cpu().numpy() - ref["logits"]).max() < LOGIT_TOL
+    assert np.array_equal(lg.argmax(1).cpu().numpy(), ref["logits"].argmax(1))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -15,3 +15,11 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(3): tr.step(x, y)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
 print(f"cfg3 B={B}: {dt*1e3:.2f} ms/step  {B/dt:.0f} trials/s")
+from nsd_amd import ops
+m.eval()
+flat = m.flat_parameters()
+for _ in range(2): ops.infer(m.spec, flat, x)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): ops.infer(m.spec, flat, x)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+print(f"cfg3 B={B} inference: {dt*1e3:.2f} ms  {B/dt:.0f} windows/s")
