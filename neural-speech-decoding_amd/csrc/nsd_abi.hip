@@ -89,9 +89,9 @@ static nsd_ws_layout make_ws(const nsd_dims *d, bool have_device) {
     w.n_slabs = nsl;
     w.slabs = p;   p = align4(p + nsl * align4(pl.lstm_total));
     w.hslabs = p;  p = align4(p + B * (pl.total - pl.lstm_total));
-    w.da_seq = p;  if (!fast) p = align4(p + B * T * 4 * H);
-    // din: two [B,T,H] ping-pong buffers + the batched path's per-step state [3,B,H] and split-K partials [4][4H x max(C,H)]
-    w.din = p;     if (!fast) p = align4(p + 2 * B * T * H + 3 * B * H + 4 * 4 * H * (H > d->C ? H : (int64_t)d->C));
+    w.da_seq = p;  if (!fast) p = align4(p + L * B * T * 4 * H);      // one per layer: the batched path keeps all layers in flight
+    // din: two [B,T,H] ping-pong buffers + the batched path's per-step state [L,3,B,H] and split-K partials [4][4H x max(C,H)]
+    w.din = p;     if (!fast) p = align4(p + 2 * B * T * H + L * 3 * B * H + 4 * 4 * H * (H > d->C ? H : (int64_t)d->C));
     w.total = p;
     return w;
 }
@@ -217,8 +217,8 @@ static int make_rng(const nsd_rng *r, RngArgs *out) {
 int64_t nsd_infer_scratch_bytes(const nsd_dims *d) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (fast_path_ok(d)) return align4((int64_t)d->B * d->T * d->H) * (int64_t)sizeof(float);
-    // two [B,T,H] ping-pong buffers + the batched path's cell-state ping-pong 2 x [B,H]
-    return (2 * align4((int64_t)d->B * d->T * d->H) + align4(2 * (int64_t)d->B * d->H)) * (int64_t)sizeof(float);
+    // two [B,T,H] ping-pong buffers + the batched path's cell-state ping-pong [L][2][B,H]
+    return (2 * align4((int64_t)d->B * d->T * d->H) + align4(2 * (int64_t)d->L * d->B * d->H)) * (int64_t)sizeof(float);
 }
 
 int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t flags, float *logits, float *probs,

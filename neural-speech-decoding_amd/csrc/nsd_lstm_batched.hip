@@ -108,16 +108,25 @@ struct StepFwdArgs {
     float *hseq, *cseq, *gact;   // [B,T,H], [B,T,H], [B,T,H,4]   (null in inference)
     float *out;               // [B,T,H] linked output = (h + res) * mask
     const float *hprev;       // sequence h_{t-1} is read from: hseq (training) or out (inference: out == h there)
-    const float *c_in;        // inference: cell state [B,H] of step t-1 ...
-    float *c_out;             // ... and of step t (ping-pong); training reads / writes cseq instead
-    int B, T, I, H, t;
+    int B, T, I, H;
+};
+// One launch advances EVERY layer by one step, layer l working on t = s - l (the layers are skewed by one step: layer l
+// reads what layer l-1 wrote in the previous launch).  Half the launches of a layer-by-layer schedule for L = 2, and two
+// workgroups per CU in flight instead of one.
+struct StepFwdAll {
+    StepFwdArgs lay[NSD_MAX_LAYERS];
+    const float *c_base;      // inference: cell-state ping-pong, [L][2][B,H]
+    int s;
 };
 
-__global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdArgs a) {
+__global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdAll all) {
     __shared__ float As[TM][LD], Bs[TN][LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int T = a.T, I = a.I, H = a.H, t = a.t;
+    const StepFwdArgs &a = all.lay[blockIdx.z];
+    const int t = all.s - (int)blockIdx.z;
+    if (t < 0 || t >= a.T) return;
+    const int T = a.T, I = a.I, H = a.H;
     const int b0 = blockIdx.x * TM, u0 = blockIdx.y * 16;        // 16 units = 64 gate columns, column c = 4 * unit + gate
     f32x16 acc;
 #pragma unroll
@@ -169,6 +178,10 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdArgs a) {
     const int c = 32 * wn + (lane & 31), g = c & 3, u = u0 + (c >> 2);
     if (u >= H) return;                                           // (whole quads leave together)
     const float bias = a.b_ih[g * H + u] + a.b_hh[g * H + u];
+    // inference: this layer's cell-state ping-pong (read step t-1's buffer, write step t's)
+    float *cst = const_cast<float *>(all.c_base) + (size_t)blockIdx.z * 2 * a.B * H;
+    const float *c_in = cst + (size_t)(t & 1) * a.B * H;
+    float *c_out = cst + (size_t)((t + 1) & 1) * a.B * H;
     // all 16 previous cell states (and residual / multiplier operands) first: one memory latency, not one per row
     float cp[16], rs[16], mk[16];
 #pragma unroll
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdArgs a) {
         const int b = b0 + 32 * wm + acc_row(r, lane);
         const size_t row = (size_t)(b < a.B ? b : 0) * T + t;
         const size_t bh = (size_t)(b < a.B ? b : 0) * H + u;
-        cp[r] = t == 0 ? 0.f : (a.cseq ? a.cseq[(row - 1) * H + u] : a.c_in[bh]);
+        cp[r] = t == 0 ? 0.f : (a.cseq ? a.cseq[(row - 1) * H + u] : c_in[bh]);
         rs[r] = a.res_in ? a.res_in[row * H + u] : 0.f;
         mk[r] = a.mask ? a.mask[row * H + u] : 1.f;
     }
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdArgs a) {
             if (a.gact) a.gact[(row * H + u) * 4 + g] = act;
             if (g == 0) {
                 if (a.cseq) { a.cseq[row * H + u] = cn; a.hseq[row * H + u] = h; }
-                else        a.c_out[(size_t)b * H + u] = cn;
+                else        c_out[(size_t)b * H + u] = cn;
                 a.out[row * H + u] = (h + rs[r]) * mk[r];
             }
         }
@@ -212,11 +225,17 @@ struct CellBwdArgs {
     float *dc;                        // [B,H] dc_{t+1} * f_{t+1} in, dc_t * f_t out
     float *dho;                       // [B,H] d linked output at this step (residual pass-through), may be null
     float *da_seq;                    // [B,T,4H]
-    int B, T, H, t;
+    int B, T, H;
 };
+// The backward launches advance every layer by one step as well: layer l works on t = T-1 - (s - (L-1-l)), one step
+// behind the layer above it, whose d(input) it reads from the previous launch.
+struct CellBwdAll { CellBwdArgs lay[NSD_MAX_LAYERS]; int L, s; };
 
-__global__ __launch_bounds__(256) void lstm_cell_bwd(CellBwdArgs a) {
-    const int H = a.H, T = a.T, t = a.t;
+__global__ __launch_bounds__(256) void lstm_cell_bwd(CellBwdAll all) {
+    const CellBwdArgs &a = all.lay[blockIdx.y];
+    const int H = a.H, T = a.T;
+    const int t = T - 1 - (all.s - (all.L - 1 - (int)blockIdx.y));
+    if (t < 0 || t >= T) return;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)a.B * H) return;
     const int b = (int)(idx / H), j = (int)(idx - (long)b * H);
@@ -248,14 +267,19 @@ struct StepBwdArgs {
     const float *dho;                 // residual pass-through (null: none)
     float *dhrec;                     // [B,H]
     float *din_seq;                   // [B,T,I] (null: not needed)
-    int B, T, I, H, t, n_hh_tiles;
+    int B, T, I, H, n_hh_tiles, n_tiles;
 };
+struct StepBwdAll { StepBwdArgs lay[NSD_MAX_LAYERS]; int L, s; };
 
-__global__ __launch_bounds__(256) void lstm_step_bwd_mfma(StepBwdArgs a) {
+__global__ __launch_bounds__(256) void lstm_step_bwd_mfma(StepBwdAll all) {
     __shared__ float As[TM][LD], Bs[TN][LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int T = a.T, H = a.H, t = a.t, K = 4 * H;
+    const StepBwdArgs &a = all.lay[blockIdx.z];
+    const int T = a.T, H = a.H, K = 4 * H;
+    const int t = T - 1 - (all.s - (all.L - 1 - (int)blockIdx.z));
+    if (t < 0 || t >= T || (int)blockIdx.y >= a.n_tiles) return;
+    if (t == 0 && (int)blockIdx.y < a.n_hh_tiles) return;          // dh_{-1} is not needed
     const bool hh = (int)blockIdx.y < a.n_hh_tiles;
     const int N = hh ? H : a.I;
     const float *w = hh ? a.w_hh : a.w_ih;
@@ -388,30 +412,13 @@ bool nsd_lstm_batched_ok(const nsd_dims *d, bool training) {
     return d->H % 16 == 0 && d->H >= 64 && d->B >= 16 && d->C % 4 == 0;
 }
 
-// inference (no residual): only the linked outputs are produced, ping-ponging between top_out and scratch2 so that the
-// last layer lands in top_out; cstate: 2 x [B,H] cell-state ping-pong
-int nsd_lstm_batched_infer(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, float *top_out,
-                           float *scratch2, float *cstate, hipStream_t st) {
-    const int B = d->B, T = d->T, H = d->H, L = d->L;
-    const float *in = x;
-    for (int l = 0; l < L; ++l) {
-        StepFwdArgs a;
-        memset(&a, 0, sizeof(a));
-        a.in = in; a.I = l == 0 ? d->C : H;
-        a.w_ih = params + pl.w_ih[l]; a.w_hh = params + pl.w_hh[l]; a.b_ih = params + pl.b_ih[l]; a.b_hh = params + pl.b_hh[l];
-        a.out = ((L - 1 - l) & 1) ? scratch2 : top_out;
-        a.hprev = a.out;                                     // no residual, no multipliers: the linked output is h itself
-        a.B = B; a.T = T; a.H = H;
-        const dim3 grid((B + TM - 1) / TM, (H + 15) / 16);
-        for (int t = 0; t < T; ++t) {
-            a.t = t;
-            a.c_in = cstate + (size_t)(t & 1) * B * H;
-            a.c_out = cstate + (size_t)((t + 1) & 1) * B * H;
-            hipLaunchKernelGGL(lstm_step_fwd_mfma, grid, dim3(256), 0, st, a);
-        }
-        NSD_CHECK_LAUNCH("lstm_step_fwd_mfma");
-        in = a.out;
+static int launch_fwd_steps(StepFwdAll &all, int B, int T, int H, int L, hipStream_t st) {
+    const dim3 grid((B + TM - 1) / TM, (H + 15) / 16, L);
+    for (int s = 0; s < T + L - 1; ++s) {
+        all.s = s;
+        hipLaunchKernelGGL(lstm_step_fwd_mfma, grid, dim3(256), 0, st, all);
     }
+    NSD_CHECK_LAUNCH("lstm_step_fwd_mfma");
     return NSD_OK;
 }
 
@@ -419,10 +426,11 @@ int nsd_lstm_batched_fwd(const nsd_dims *d, const ParamLayout &pl, const float *
                          int residual, float *hseq, float *cseq, float *gact, float *inseq, float *top_out, hipStream_t st) {
     const int B = d->B, T = d->T, H = d->H, L = d->L;
     const int64_t BTH = (int64_t)B * T * H;
+    StepFwdAll all;
+    memset(&all, 0, sizeof(all));
     const float *in = x;
     for (int l = 0; l < L; ++l) {
-        StepFwdArgs a;
-        memset(&a, 0, sizeof(a));
+        StepFwdArgs &a = all.lay[l];
         a.in = in; a.I = l == 0 ? d->C : H;
         a.w_ih = params + pl.w_ih[l]; a.w_hh = params + pl.w_hh[l]; a.b_ih = params + pl.b_ih[l]; a.b_hh = params + pl.b_hh[l];
         a.mask = (l < L - 1 && drop_lstm) ? drop_lstm + (int64_t)l * BTH : nullptr;
@@ -431,20 +439,35 @@ int nsd_lstm_batched_fwd(const nsd_dims *d, const ParamLayout &pl, const float *
         a.out = (l == L - 1) ? top_out : inseq + (int64_t)l * BTH;
         a.hprev = a.hseq;
         a.B = B; a.T = T; a.H = H;
-        const dim3 grid((B + TM - 1) / TM, (H + 15) / 16);
-        for (int t = 0; t < T; ++t) {
-            a.t = t;
-            hipLaunchKernelGGL(lstm_step_fwd_mfma, grid, dim3(256), 0, st, a);
-        }
-        NSD_CHECK_LAUNCH("lstm_step_fwd_mfma");
         in = a.out;
     }
-    return NSD_OK;
+    return launch_fwd_steps(all, B, T, H, L, st);
 }
 
-// scratch: `din_a`, `din_b` [B,T,H] ping-pong for d(layer input); the per-step state [B,H] x 3 (dhrec, dc, dho) and the
-// split-K partials live at the end of da_seq's region?  No: they are carved from din buffers' tail is unsafe -- the
-// caller passes `state` (>= 3*B*H + 4 * 4H * max(I,H) floats).
+// inference (no residual): only the linked outputs are produced, ping-ponging between top_out and scratch2 so that the
+// last layer lands in top_out (with the one-step skew a layer overwrites a row two launches after its reader is done);
+// cstate: [L][2][B,H] cell-state ping-pong
+int nsd_lstm_batched_infer(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, float *top_out,
+                           float *scratch2, float *cstate, hipStream_t st) {
+    const int B = d->B, T = d->T, H = d->H, L = d->L;
+    StepFwdAll all;
+    memset(&all, 0, sizeof(all));
+    all.c_base = cstate;
+    const float *in = x;
+    for (int l = 0; l < L; ++l) {
+        StepFwdArgs &a = all.lay[l];
+        a.in = in; a.I = l == 0 ? d->C : H;
+        a.w_ih = params + pl.w_ih[l]; a.w_hh = params + pl.w_hh[l]; a.b_ih = params + pl.b_ih[l]; a.b_hh = params + pl.b_hh[l];
+        a.out = ((L - 1 - l) & 1) ? scratch2 : top_out;
+        a.hprev = a.out;                                     // no residual, no multipliers: the linked output is h itself
+        a.B = B; a.T = T; a.H = H;
+        in = a.out;
+    }
+    return launch_fwd_steps(all, B, T, H, L, st);
+}
+
+// scratch: `din_a`, `din_b` [B,T,H] ping-pong for d(layer input) (one writer and one reader each, a step apart);
+// `state` >= L*3*B*H + 4 * 4H * max(C,H) floats (per-layer dhrec / dc / dho + the split-K partials); da_seq [L][B,T,4H].
 int nsd_lstm_batched_bwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,
                          int residual, const float *hseq, const float *cseq, const float *gact, const float *inseq,
                          const float *alpha, const float *dscore, const float *dpooled, float *da_seq, float *din_a, float *din_b,
@@ -452,57 +475,66 @@ int nsd_lstm_batched_bwd(const nsd_dims *d, const ParamLayout &pl, const float *
     const int B = d->B, T = d->T, H = d->H, L = d->L;
     const int64_t BTH = (int64_t)B * T * H;
     const long rows = (long)B * T;
-    float *dhrec = state, *dc = state + (size_t)B * H, *dho = state + 2 * (size_t)B * H, *parts = state + 3 * (size_t)B * H;
+    // state: [L][3][B,H] (dhrec, dc, dho per layer) + split-K partials; da_seq: [L][B,T,4H]
+    float *parts = state + (size_t)L * 3 * B * H;
     const int NPART = 4;
-    const float *dsrc = nullptr;
+    CellBwdAll call;
+    StepBwdAll sall;
+    memset(&call, 0, sizeof(call));
+    memset(&sall, 0, sizeof(sall));
+    call.L = sall.L = L;
+    int max_tiles = 0;
     for (int l = L - 1; l >= 0; --l) {
         const int I = l == 0 ? d->C : H;
-        CellBwdArgs c;
-        memset(&c, 0, sizeof(c));
+        float *st_l = state + (size_t)l * 3 * B * H;
+        float *da_l = da_seq + (size_t)l * 4 * BTH;
+        float *din_l = l > 0 ? ((l & 1) ? din_a : din_b) : nullptr;             // written by layer l, read by layer l-1
+        const float *dsrc = l < L - 1 ? (((l + 1) & 1) ? din_a : din_b) : nullptr;
+        const bool res_add = residual && l >= 1;
+        CellBwdArgs &c = call.lay[l];
         c.gact = gact + (int64_t)l * 4 * BTH; c.cseq = cseq + (int64_t)l * BTH;
         c.dsrc = dsrc;
         c.mask = (l < L - 1 && drop_lstm) ? drop_lstm + (int64_t)l * BTH : nullptr;
         c.alpha = alpha; c.dscore = dscore; c.dpooled = dpooled; c.attn_w = params + pl.attn_w;
-        c.dhrec = dhrec; c.dc = dc; c.da_seq = da_seq;
-        const bool res_add = residual && l >= 1;
-        c.dho = res_add ? dho : nullptr;
+        c.dhrec = st_l; c.dc = st_l + (size_t)B * H; c.dho = res_add ? st_l + 2 * (size_t)B * H : nullptr;
+        c.da_seq = da_l;
         c.B = B; c.T = T; c.H = H;
-        StepBwdArgs s;
-        memset(&s, 0, sizeof(s));
-        s.da_seq = da_seq; s.w_ih = params + pl.w_ih[l]; s.w_hh = params + pl.w_hh[l];
-        s.dho = res_add ? dho : nullptr;
-        s.dhrec = dhrec;
-        s.din_seq = l > 0 ? ((l & 1) ? din_a : din_b) : nullptr;
+        StepBwdArgs &s = sall.lay[l];
+        s.da_seq = da_l; s.w_ih = params + pl.w_ih[l]; s.w_hh = params + pl.w_hh[l];
+        s.dho = c.dho; s.dhrec = st_l; s.din_seq = din_l;
         s.B = B; s.T = T; s.I = I; s.H = H;
         s.n_hh_tiles = (H + TN - 1) / TN;
-        const int n_ih_tiles = l > 0 ? (I + TN - 1) / TN : 0;
-        const dim3 cgrid((unsigned)(((long)B * H + 255) / 256));
-        const dim3 sgrid((B + TM - 1) / TM, s.n_hh_tiles + n_ih_tiles);
-        for (int t = T - 1; t >= 0; --t) {
-            c.t = t; s.t = t;
-            hipLaunchKernelGGL(lstm_cell_bwd, cgrid, dim3(256), 0, st, c);
-            if (t > 0 || n_ih_tiles > 0)
-                hipLaunchKernelGGL(lstm_step_bwd_mfma, sgrid, dim3(256), 0, st, s);
-        }
-        NSD_CHECK_LAUNCH("lstm_step_bwd_mfma");
-        // weight gradients of this layer: dW_ih = da^T . in_l ; dW_hh = da^T . h_l[t-1] ; db = column sums of da
+        s.n_tiles = s.n_hh_tiles + (l > 0 ? (I + TN - 1) / TN : 0);
+        if (s.n_tiles > max_tiles) max_tiles = s.n_tiles;
+    }
+    const dim3 cgrid((unsigned)(((long)B * H + 255) / 256), L);
+    const dim3 sgrid((B + TM - 1) / TM, max_tiles, L);
+    for (int s = 0; s < T + L - 1; ++s) {
+        call.s = sall.s = s;
+        hipLaunchKernelGGL(lstm_cell_bwd, cgrid, dim3(256), 0, st, call);
+        hipLaunchKernelGGL(lstm_step_bwd_mfma, sgrid, dim3(256), 0, st, sall);
+    }
+    NSD_CHECK_LAUNCH("lstm_step_bwd_mfma");
+    // weight gradients: dW_ih = da^T . in_l ; dW_hh = da^T . h_l[t-1] ; db = column sums of da
+    for (int l = 0; l < L; ++l) {
+        const int I = l == 0 ? d->C : H;
+        const float *da_l = da_seq + (size_t)l * 4 * BTH;
         const float *in_l = l == 0 ? x : inseq + (int64_t)(l - 1) * BTH;
         const int M = 4 * H;
-        hipLaunchKernelGGL(gemm_tn_mfma, dim3((I + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_seq, M, in_l, I,
+        hipLaunchKernelGGL(gemm_tn_mfma, dim3((I + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_l, M, in_l, I,
                            parts, M, I, rows, 0);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(((long)M * I + 255) / 256)), dim3(256), 0, st, parts, NPART, (long)M * I,
                            slab + pl.w_ih[l]);
-        hipLaunchKernelGGL(gemm_tn_mfma, dim3((H + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_seq, M,
+        hipLaunchKernelGGL(gemm_tn_mfma, dim3((H + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_l, M,
                            hseq + (int64_t)l * BTH, H, parts, M, H, rows, T);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(((long)M * H + 255) / 256)), dim3(256), 0, st, parts, NPART, (long)M * H,
                            slab + pl.w_hh[l]);
         {   // bias gradients: column sums of da over all rows, 64 row splits (the partials reuse the split-K buffer)
             const int RS = 64;                                   // RS * M <= NPART * M * max(I,H) since max(I,H) >= 64
-            hipLaunchKernelGGL(colsum_part_kernel, dim3((M + 63) / 64, RS), dim3(256), 0, st, da_seq, M, M, rows, parts);
+            hipLaunchKernelGGL(colsum_part_kernel, dim3((M + 63) / 64, RS), dim3(256), 0, st, da_l, M, M, rows, parts);
             hipLaunchKernelGGL(sum_parts2_kernel, dim3((M + 255) / 256), dim3(256), 0, st, parts, RS, (long)M, slab + pl.b_ih[l], slab + pl.b_hh[l]);
         }
         NSD_CHECK_LAUNCH("batched dW");
-        dsrc = s.din_seq;
     }
     return NSD_OK;
 }
