@@ -365,7 +365,8 @@ def test_generic_path_gradients_vs_oracle(nsd, dev, C, H, L, K, residual):
 
 
 @pytest.mark.parametrize("C,H,L,K,residual,B,T", [(8, 256, 2, 5, False, 20, 21), (8, 112, 2, 3, False, 70, 9), (64, 128, 2, 5, False, 33, 12),
-                                                   (8, 96, 3, 3, True, 17, 10), (8, 256, 2, 5, True, 130, 5), (8, 80, 1, 2, False, 16, 7)])
+                                                   (8, 96, 3, 3, True, 17, 10), (8, 256, 2, 5, True, 130, 5), (8, 80, 1, 2, False, 16, 7),
+                                                   (8, 128, 2, 3, False, 65, 1), (4, 64 + 16, 3, 3, False, 64, 2)])
 def test_batched_mfma_path_vs_oracle(nsd, dev, C, H, L, K, residual, B, T):
     """Large-H path (nsd_lstm_batched.hip: per-step batched gate GEMM on v_mfma_f32_32x32x2_f32 with the LSTM cell in
     the epilogue, H % 16 == 0 and B >= 16) against the oracle: logits, loss and every gradient tensor; ragged tile edges
