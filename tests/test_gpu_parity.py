@@ -366,7 +366,7 @@ def test_generic_path_gradients_vs_oracle(nsd, dev, C, H, L, K, residual):
 
 @pytest.mark.parametrize("C,H,L,K,residual,B,T", [(8, 256, 2, 5, False, 20, 21), (8, 112, 2, 3, False, 70, 9), (64, 128, 2, 5, False, 33, 12),
                                                    (8, 96, 3, 3, True, 17, 10), (8, 256, 2, 5, True, 130, 5), (8, 80, 1, 2, False, 16, 7),
-                                                   (8, 128, 2, 3, False, 65, 1), (4, 64 + 16, 3, 3, False, 64, 2)])
+                                                   (8, 128, 2, 3, False, 65, 1), (4, 64 + 16, 3, 3, False, 64, 2), (8, 64, 2, 3, False, 400, 3)])
 def test_batched_mfma_path_vs_oracle(nsd, dev, C, H, L, K, residual, B, T):
     """Large-H path (nsd_lstm_batched.hip: per-step batched gate GEMM on v_mfma_f32_32x32x2_f32 with the LSTM cell in
     the epilogue, H % 16 == 0 and B >= 16) against the oracle: logits, loss and every gradient tensor; ragged tile edges
@@ -374,7 +374,7 @@ def test_batched_mfma_path_vs_oracle(nsd, dev, C, H, L, K, residual, B, T):
     from nsd_amd import ops
     d = orc.Dims(C=C, H=H, L=L, K=K)
     spec = ops.ModelSpec(C=C, H=H, L=L, K=K)
-    assert not spec.fast_path()
+    assert not spec.fast_path() or (H == 64 and B >= 384)       # H=64: fused kernels for small batches, this path from 384 trials
     flat_np = orc.flatten_state(synth_params(C, H, L, K, seed=C + H + L), d)
     x, y = synth_x(B, T, C=C, seed=H + B), synth_labels(B, K=K, seed=H)
     dl, sl, dh = counter_masks(B, T, H, 32, L=L, seed=H + L)
