@@ -98,7 +98,7 @@ static nsd_ws_layout make_ws(const nsd_dims *d, bool have_device) {
     w.hslabs = p;  p = align4(p + B * (pl.total - pl.lstm_total));
     w.da_seq = p;  if (!fast) p = align4(p + L * B * T * 4 * H);      // one per layer: the batched path keeps all layers in flight
     // din: two [B,T,H] ping-pong buffers + the batched path's per-step state [L,3,B,H] and split-K partials [4][4H x max(C,H)]
-    w.din = p;     if (!fast) p = align4(p + 2 * B * T * H + L * 3 * B * H + 4 * 4 * H * (H > d->C ? H : (int64_t)d->C));
+    w.din = p;     if (!fast) p = align4(p + 2 * B * T * H + L * 3 * B * H + 8 * 4 * H * (H > d->C ? H : (int64_t)d->C));
     w.total = p;
     return w;
 }

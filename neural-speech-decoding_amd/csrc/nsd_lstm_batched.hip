@@ -22,6 +22,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef NSD_DW_SPLITS
+#define NSD_DW_SPLITS 8         // split-K parts of the weight-gradient GEMMs (workspace sized for 8)
+#endif
 constexpr int TM = 64;            // trials (or GEMM rows) per workgroup tile
 constexpr int TN = 64;            // gate columns (or GEMM columns) per workgroup tile
 #ifndef NSD_KC
@@ -467,7 +470,7 @@ int nsd_lstm_batched_infer(const nsd_dims *d, const ParamLayout &pl, const float
 }
 
 // scratch: `din_a`, `din_b` [B,T,H] ping-pong for d(layer input) (one writer and one reader each, a step apart);
-// `state` >= L*3*B*H + 4 * 4H * max(C,H) floats (per-layer dhrec / dc / dho + the split-K partials); da_seq [L][B,T,4H].
+// `state` >= L*3*B*H + 8 * 4H * max(C,H) floats (per-layer dhrec / dc / dho + the split-K partials); da_seq [L][B,T,4H].
 int nsd_lstm_batched_bwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,
                          int residual, const float *hseq, const float *cseq, const float *gact, const float *inseq,
                          const float *alpha, const float *dscore, const float *dpooled, float *da_seq, float *din_a, float *din_b,
@@ -477,7 +480,7 @@ int nsd_lstm_batched_bwd(const nsd_dims *d, const ParamLayout &pl, const float *
     const long rows = (long)B * T;
     // state: [L][3][B,H] (dhrec, dc, dho per layer) + split-K partials; da_seq: [L][B,T,4H]
     float *parts = state + (size_t)L * 3 * B * H;
-    const int NPART = 4;
+    const int NPART = NSD_DW_SPLITS;
     CellBwdAll call;
     StepBwdAll sall;
     memset(&call, 0, sizeof(call));
