@@ -47,6 +47,9 @@ extern "C" {
 /* flags */
 #define NSD_FLAG_RESIDUAL   1u   /* extension (not in the reference): out_l = LSTM_l(in_l) + in_l, l>=1 */
 #define NSD_FLAG_TRAIN      2u   /* keep activations in the workspace for nsd_*_bwd */
+#define NSD_FLAG_BF16       4u   /* large-H batched path only (H % 16 == 0, H >= 64, B >= 16; ignored elsewhere): GEMM operands
+                                    rounded to bf16 at the matrix pipe (fp32 accumulate, fp32 storage and cell arithmetic) --
+                                    BASELINE cfg3's precision; results differ from fp32 at the 1e-2 level */
 
 typedef struct nsd_dims {
     int32_t B, T, C, H, L, K, F;

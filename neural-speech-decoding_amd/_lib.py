@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 NSD_FLAG_RESIDUAL = 1
 NSD_FLAG_TRAIN = 2
+NSD_FLAG_BF16 = 4
 
 
 class Rng(C.Structure):

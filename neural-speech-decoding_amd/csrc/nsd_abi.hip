@@ -253,7 +253,7 @@ int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t f
         float *top = (float *)scratch;
         const int64_t bth = align4((int64_t)d->B * d->T * d->H);
         if (nsd_lstm_batched_ok(d, false) && !(flags & NSD_FLAG_RESIDUAL))
-            rc = nsd_lstm_batched_infer(d, pl, params, x, top, top + bth, top + 2 * bth, (hipStream_t)stream);
+            rc = nsd_lstm_batched_infer(d, pl, params, x, top, top + bth, top + 2 * bth, (flags & NSD_FLAG_BF16) != 0, (hipStream_t)stream);
         else
             rc = nsd_lstm_generic_fwd(d, pl, params, x, nullptr, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, nullptr, nullptr, nullptr, nullptr,
                                       top, top + bth, (hipStream_t)stream);
@@ -276,7 +276,7 @@ int nsd_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const f
         if (nsd_lstm_batched_ok(d, true))        // large H: per-step batched gate GEMM on the matrix pipe
             return nsd_lstm_batched_fwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
                                         workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.top,
-                                        (hipStream_t)stream);
+                                        (flags & NSD_FLAG_BF16) != 0, (hipStream_t)stream);
         return nsd_lstm_generic_fwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
                                     workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.top, nullptr,
                                     (hipStream_t)stream);
@@ -405,7 +405,8 @@ static int lstm_bwd_impl(const nsd_dims *d, const float *params, const float *x,
         return nsd_lstm_batched_bwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
                                     workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.alpha,
                                     workspace + w.dscore, workspace + w.dpooled, workspace + w.da_seq, workspace + w.din,
-                                    workspace + w.din + BTH, workspace + w.din + 2 * BTH, workspace + w.slabs, (hipStream_t)stream);
+                                    workspace + w.din + BTH, workspace + w.din + 2 * BTH, workspace + w.slabs,
+                                    (flags & NSD_FLAG_BF16) != 0, (hipStream_t)stream);
     if (!fast_path_ok(d))
         return nsd_lstm_generic_bwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
                                     workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.alpha,

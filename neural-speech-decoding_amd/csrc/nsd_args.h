@@ -76,13 +76,13 @@ int nsd_lstm_generic_bwd(const nsd_dims *d, const ParamLayout &pl, const float *
                          float *slab, hipStream_t st);
 bool nsd_lstm_batched_ok(const nsd_dims *d, bool training);
 int nsd_lstm_batched_infer(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, float *top_out,
-                           float *scratch2, float *cstate, hipStream_t st);
+                           float *scratch2, float *cstate, bool bf16, hipStream_t st);
 int nsd_lstm_batched_fwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,
-                         int residual, float *hseq, float *cseq, float *gact, float *inseq, float *top_out, hipStream_t st);
+                         int residual, float *hseq, float *cseq, float *gact, float *inseq, float *top_out, bool bf16, hipStream_t st);
 int nsd_lstm_batched_bwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,
                          int residual, const float *hseq, const float *cseq, const float *gact, const float *inseq,
                          const float *alpha, const float *dscore, const float *dpooled, float *da_seq, float *din_a, float *din_b,
-                         float *state, float *slab, hipStream_t st);
+                         float *state, float *slab, bool bf16, hipStream_t st);
 int nsd_head_launch(const HeadArgs &a, bool bwd, hipStream_t st);
 int nsd_head_train_launch(const HeadArgs &a, hipStream_t st);   // 1 launched, 0 shape does not fit, <0 error
 int nsd_zscore_launch(const float *x, float *y, int B, int T, int C, hipStream_t st);

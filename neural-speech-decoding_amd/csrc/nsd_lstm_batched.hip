@@ -97,6 +97,46 @@ __device__ __forceinline__ void store_rows_n(float (*S)[LD], const int k, const 
         S[n + 4][kk] = c.v[j][1].x; S[n + 5][kk] = c.v[j][1].y; S[n + 6][kk] = c.v[j][1].z; S[n + 7][kk] = c.v[j][1].w;
     }
 }
+// ---- optional bf16 operands (NSD_FLAG_BF16: GEMM inputs rounded to bf16 at staging, fp32 accumulate, everything else
+// fp32): v_mfma_f32_32x32x16_bf16, lane (i = lane & 31, kq = lane >> 5) feeds 8 consecutive k: A[i][16 ks + 8 kq ..].
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDH = KC + 8;                                       // halfs per LDS row (16-byte aligned rows, conflict-free b128 reads)
+__device__ __forceinline__ void tile_mfma_bf16(const __bf16 (*Ah)[LDH], const __bf16 (*Bh)[LDH], const int wm, const int wn,
+                                               const int lane, f32x16 &acc) {
+    const int i = lane & 31, kq = lane >> 5;
+    bf16x8 av[KC / 16], bv[KC / 16];
+#pragma unroll
+    for (int k = 0; k < KC / 16; ++k) {
+        av[k] = *reinterpret_cast<const bf16x8 *>(&Ah[32 * wm + i][16 * k + 8 * kq]);
+        bv[k] = *reinterpret_cast<const bf16x8 *>(&Bh[32 * wn + i][16 * k + 8 * kq]);
+    }
+#pragma unroll
+    for (int k = 0; k < KC / 16; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[k], bv[k], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void store_rows_k_h(__bf16 (*S)[LDH], const int row, const int part, const Chunk &c) {
+    __bf16 *d = &S[row][(KC / 4) * part];
+#pragma unroll
+    for (int q = 0; q < CV; ++q) {
+        d[4 * q] = (__bf16)c.v[q].x; d[4 * q + 1] = (__bf16)c.v[q].y; d[4 * q + 2] = (__bf16)c.v[q].z; d[4 * q + 3] = (__bf16)c.v[q].w;
+    }
+}
+__device__ __forceinline__ void store_rows_n_h(__bf16 (*S)[LDH], const int k, const int part, const ChunkN &c) {
+    const int n = 8 * part;
+#pragma unroll
+    for (int j = 0; j < KC / 32; ++j) {
+        const int kk = k + 32 * j;
+        S[n][kk] = (__bf16)c.v[j][0].x; S[n + 1][kk] = (__bf16)c.v[j][0].y; S[n + 2][kk] = (__bf16)c.v[j][0].z; S[n + 3][kk] = (__bf16)c.v[j][0].w;
+        S[n + 4][kk] = (__bf16)c.v[j][1].x; S[n + 5][kk] = (__bf16)c.v[j][1].y; S[n + 6][kk] = (__bf16)c.v[j][1].z; S[n + 7][kk] = (__bf16)c.v[j][1].w;
+    }
+}
+// LDS of a GEMM kernel: the fp32 tiles, or (same bytes, reinterpreted) the bf16 tiles
+struct TileMem {
+    float As[TM][LD], Bs[TN][LD];
+};
+#define TILE_H(mem, Ah, Bh) \
+    __bf16 (*Ah)[LDH] = reinterpret_cast<__bf16 (*)[LDH]>(&(mem).As[0][0]); \
+    __bf16 (*Bh)[LDH] = reinterpret_cast<__bf16 (*)[LDH]>(&(mem).Bs[0][0])
+
 // accumulator register r of lane l holds D[row][col] with col = l & 31, row = 8 * (r / 4) + 4 * (l >> 5) + (r % 4)
 __device__ __forceinline__ int acc_row(const int r, const int lane) { return 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); }
 
@@ -122,8 +162,11 @@ struct StepFwdAll {
     int s;
 };
 
+template <bool BF>
 __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdAll all) {
-    __shared__ float As[TM][LD], Bs[TN][LD];
+    __shared__ __align__(16) TileMem mem;
+    float (*As)[LD] = mem.As; float (*Bs)[LD] = mem.Bs;
+    TILE_H(mem, Ah, Bh);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const StepFwdArgs &a = all.lay[blockIdx.z];
@@ -153,11 +196,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdAll all) {
             Chunk ca = load_rows_k(ap, aok), cb = load_rows_k(bp, bok);
             for (int k0 = 0; k0 < K; k0 += KC) {
                 __syncthreads();
-                store_rows_k(As, row, part, ca);
-                store_rows_k(Bs, row, part, cb);
+                if (BF) { store_rows_k_h(Ah, row, part, ca); store_rows_k_h(Bh, row, part, cb); }
+                else    { store_rows_k(As, row, part, ca); store_rows_k(Bs, row, part, cb); }
                 if (k0 + KC < K) { ca = load_rows_k(ap + k0 + KC, aok); cb = load_rows_k(bp + k0 + KC, bok); }
                 __syncthreads();
-                tile_mfma_full<KC>(As, Bs, wm, wn, lane, acc);
+                if (BF) tile_mfma_bf16(Ah, Bh, wm, wn, lane, acc);
+                else    tile_mfma_full<KC>(As, Bs, wm, wn, lane, acc);
             }
         } else {
             for (int k0 = 0; k0 < K; k0 += KC) {
@@ -274,8 +318,11 @@ struct StepBwdArgs {
 };
 struct StepBwdAll { StepBwdArgs lay[NSD_MAX_LAYERS]; int L, s; };
 
+template <bool BF>
 __global__ __launch_bounds__(256) void lstm_step_bwd_mfma(StepBwdAll all) {
-    __shared__ float As[TM][LD], Bs[TN][LD];
+    __shared__ __align__(16) TileMem mem;
+    float (*As)[LD] = mem.As; float (*Bs)[LD] = mem.Bs;
+    TILE_H(mem, Ah, Bh);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const StepBwdArgs &a = all.lay[blockIdx.z];
@@ -298,16 +345,17 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_mfma(StepBwdAll all) {
         const int kk = tid >> 3, np = tid & 7;                     // B: W rows k, n-contiguous
         const bool bok0 = n0 + 8 * np < N, bok1 = n0 + 8 * np + 4 < N;
         const float *bp = w + (size_t)kk * N + n0 + 8 * np;
-        auto all = [](int) { return true; };
+        auto allk = [](int) { return true; };
         Chunk ca = load_rows_k(ap, aok);
-        ChunkN cb = load_rows_n(bp, N, bok0, bok1, all);
+        ChunkN cb = load_rows_n(bp, N, bok0, bok1, allk);
         for (int k0 = 0; k0 < K; k0 += KC) {
             __syncthreads();
-            store_rows_k(As, row, part, ca);
-            store_rows_n(Bs, kk, np, cb);
-            if (k0 + KC < K) { ca = load_rows_k(ap + k0 + KC, aok); cb = load_rows_n(bp + (size_t)(k0 + KC) * N, N, bok0, bok1, all); }
+            if (BF) { store_rows_k_h(Ah, row, part, ca); store_rows_n_h(Bh, kk, np, cb); }
+            else    { store_rows_k(As, row, part, ca); store_rows_n(Bs, kk, np, cb); }
+            if (k0 + KC < K) { ca = load_rows_k(ap + k0 + KC, aok); cb = load_rows_n(bp + (size_t)(k0 + KC) * N, N, bok0, bok1, allk); }
             __syncthreads();
-            tile_mfma_full<KC>(As, Bs, wm, wn, lane, acc);
+            if (BF) tile_mfma_bf16(Ah, Bh, wm, wn, lane, acc);
+            else    tile_mfma_full<KC>(As, Bs, wm, wn, lane, acc);
         }
     }
     const int n = n0 + 32 * wn + (lane & 31);
@@ -328,9 +376,12 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_mfma(StepBwdAll all) {
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradients: C[M,N] = sum_rows A[row][m] * Bm[src(row)][n], rows = B*T split over gridDim.z parts
 // ---------------------------------------------------------------------------------------------------------------
+template <bool BF>
 __global__ __launch_bounds__(256) void gemm_tn_mfma(const float *A, int lda, const float *Bm, int ldb, float *part, int M, int N,
                                                     long rows, int shiftT) {
-    __shared__ float As[TM][LD], Bs[TN][LD];                      // As[m][k], Bs[n][k]
+    __shared__ __align__(16) TileMem mem;                         // As[m][k], Bs[n][k]
+    float (*As)[LD] = mem.As; float (*Bs)[LD] = mem.Bs;
+    TILE_H(mem, Ah, Bh);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
@@ -356,11 +407,12 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma(const float *A, int lda, con
         ChunkN ca = lda_(r_lo), cb = ldb_(r_lo);
         for (long r0 = r_lo; r0 < r_hi; r0 += KC) {
             __syncthreads();
-            store_rows_n(As, kk, cp, ca);
-            store_rows_n(Bs, kk, cp, cb);
+            if (BF) { store_rows_n_h(Ah, kk, cp, ca); store_rows_n_h(Bh, kk, cp, cb); }
+            else    { store_rows_n(As, kk, cp, ca); store_rows_n(Bs, kk, cp, cb); }
             if (r0 + KC < r_hi) { ca = lda_(r0 + KC); cb = ldb_(r0 + KC); }
             __syncthreads();
-            tile_mfma_full<KC>(As, Bs, wm, wn, lane, acc);
+            if (BF) tile_mfma_bf16(Ah, Bh, wm, wn, lane, acc);
+            else    tile_mfma_full<KC>(As, Bs, wm, wn, lane, acc);
         }
     }
     float *dst = part + (size_t)blockIdx.z * M * N;
@@ -415,18 +467,19 @@ bool nsd_lstm_batched_ok(const nsd_dims *d, bool training) {
     return d->H % 16 == 0 && d->H >= 64 && d->B >= 16 && d->C % 4 == 0;
 }
 
-static int launch_fwd_steps(StepFwdAll &all, int B, int T, int H, int L, hipStream_t st) {
+static int launch_fwd_steps(StepFwdAll &all, int B, int T, int H, int L, bool bf16, hipStream_t st) {
     const dim3 grid((B + TM - 1) / TM, (H + 15) / 16, L);
     for (int s = 0; s < T + L - 1; ++s) {
         all.s = s;
-        hipLaunchKernelGGL(lstm_step_fwd_mfma, grid, dim3(256), 0, st, all);
+        if (bf16) hipLaunchKernelGGL(lstm_step_fwd_mfma<true>, grid, dim3(256), 0, st, all);
+        else      hipLaunchKernelGGL(lstm_step_fwd_mfma<false>, grid, dim3(256), 0, st, all);
     }
     NSD_CHECK_LAUNCH("lstm_step_fwd_mfma");
     return NSD_OK;
 }
 
 int nsd_lstm_batched_fwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,
-                         int residual, float *hseq, float *cseq, float *gact, float *inseq, float *top_out, hipStream_t st) {
+                         int residual, float *hseq, float *cseq, float *gact, float *inseq, float *top_out, bool bf16, hipStream_t st) {
     const int B = d->B, T = d->T, H = d->H, L = d->L;
     const int64_t BTH = (int64_t)B * T * H;
     StepFwdAll all;
@@ -444,14 +497,14 @@ int nsd_lstm_batched_fwd(const nsd_dims *d, const ParamLayout &pl, const float *
         a.B = B; a.T = T; a.H = H;
         in = a.out;
     }
-    return launch_fwd_steps(all, B, T, H, L, st);
+    return launch_fwd_steps(all, B, T, H, L, bf16, st);
 }
 
 // inference (no residual): only the linked outputs are produced, ping-ponging between top_out and scratch2 so that the
 // last layer lands in top_out (with the one-step skew a layer overwrites a row two launches after its reader is done);
 // cstate: [L][2][B,H] cell-state ping-pong
 int nsd_lstm_batched_infer(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, float *top_out,
-                           float *scratch2, float *cstate, hipStream_t st) {
+                           float *scratch2, float *cstate, bool bf16, hipStream_t st) {
     const int B = d->B, T = d->T, H = d->H, L = d->L;
     StepFwdAll all;
     memset(&all, 0, sizeof(all));
@@ -466,7 +519,7 @@ int nsd_lstm_batched_infer(const nsd_dims *d, const ParamLayout &pl, const float
         a.B = B; a.T = T; a.H = H;
         in = a.out;
     }
-    return launch_fwd_steps(all, B, T, H, L, st);
+    return launch_fwd_steps(all, B, T, H, L, bf16, st);
 }
 
 // scratch: `din_a`, `din_b` [B,T,H] ping-pong for d(layer input) (one writer and one reader each, a step apart);
@@ -474,7 +527,7 @@ int nsd_lstm_batched_infer(const nsd_dims *d, const ParamLayout &pl, const float
 int nsd_lstm_batched_bwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,
                          int residual, const float *hseq, const float *cseq, const float *gact, const float *inseq,
                          const float *alpha, const float *dscore, const float *dpooled, float *da_seq, float *din_a, float *din_b,
-                         float *state, float *slab, hipStream_t st) {
+                         float *state, float *slab, bool bf16, hipStream_t st) {
     const int B = d->B, T = d->T, H = d->H, L = d->L;
     const int64_t BTH = (int64_t)B * T * H;
     const long rows = (long)B * T;
@@ -515,7 +568,8 @@ int nsd_lstm_batched_bwd(const nsd_dims *d, const ParamLayout &pl, const float *
     for (int s = 0; s < T + L - 1; ++s) {
         call.s = sall.s = s;
         hipLaunchKernelGGL(lstm_cell_bwd, cgrid, dim3(256), 0, st, call);
-        hipLaunchKernelGGL(lstm_step_bwd_mfma, sgrid, dim3(256), 0, st, sall);
+        if (bf16) hipLaunchKernelGGL(lstm_step_bwd_mfma<true>, sgrid, dim3(256), 0, st, sall);
+        else      hipLaunchKernelGGL(lstm_step_bwd_mfma<false>, sgrid, dim3(256), 0, st, sall);
     }
     NSD_CHECK_LAUNCH("lstm_step_bwd_mfma");
     // weight gradients: dW_ih = da^T . in_l ; dW_hh = da^T . h_l[t-1] ; db = column sums of da
@@ -524,12 +578,17 @@ int nsd_lstm_batched_bwd(const nsd_dims *d, const ParamLayout &pl, const float *
         const float *da_l = da_seq + (size_t)l * 4 * BTH;
         const float *in_l = l == 0 ? x : inseq + (int64_t)(l - 1) * BTH;
         const int M = 4 * H;
-        hipLaunchKernelGGL(gemm_tn_mfma, dim3((I + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_l, M, in_l, I,
-                           parts, M, I, rows, 0);
+        // (layer 0's input has only C columns: its weight gradient stays fp32)
+        if (bf16 && l > 0) hipLaunchKernelGGL(gemm_tn_mfma<true>, dim3((I + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_l, M,
+                                              in_l, I, parts, M, I, rows, 0);
+        else               hipLaunchKernelGGL(gemm_tn_mfma<false>, dim3((I + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_l, M,
+                                              in_l, I, parts, M, I, rows, 0);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(((long)M * I + 255) / 256)), dim3(256), 0, st, parts, NPART, (long)M * I,
                            slab + pl.w_ih[l]);
-        hipLaunchKernelGGL(gemm_tn_mfma, dim3((H + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_l, M,
-                           hseq + (int64_t)l * BTH, H, parts, M, H, rows, T);
+        if (bf16) hipLaunchKernelGGL(gemm_tn_mfma<true>, dim3((H + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_l, M,
+                                     hseq + (int64_t)l * BTH, H, parts, M, H, rows, T);
+        else      hipLaunchKernelGGL(gemm_tn_mfma<false>, dim3((H + TN - 1) / TN, (M + TM - 1) / TM, NPART), dim3(256), 0, st, da_l, M,
+                                     hseq + (int64_t)l * BTH, H, parts, M, H, rows, T);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)(((long)M * H + 255) / 256)), dim3(256), 0, st, parts, NPART, (long)M * H,
                            slab + pl.w_hh[l]);
         {   // bias gradients: column sums of da over all rows, 64 row splits (the partials reuse the split-K buffer)

@@ -87,6 +87,15 @@ def _stream() -> int:
 _launch_hook = None
 
 
+_extra_flags = 0
+
+
+def set_gemm_bf16(on: bool) -> None:
+    """Large-H batched path only (NSD_FLAG_BF16): GEMM operands rounded to bf16 (fp32 accumulate / storage).  Off by default."""
+    global _extra_flags
+    _extra_flags = _lib.NSD_FLAG_BF16 if on else 0
+
+
 def set_launch_hook(hook) -> None:
     """bench.py: hook(name) -> context manager entered around each C-ABI launch (HIP-event timing)."""
     global _launch_hook
@@ -158,7 +167,7 @@ def infer(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, *, residual: boo
     nscr = _lib.lib().nsd_infer_scratch_bytes(C.byref(d))
     scratch = torch.empty(max(int(nscr) // 4, 1), dtype=torch.float32, device=x.device)
     _call("nsd_infer", C.byref(d), _dev_f32(flat, "params", (spec.param_count,)), _dev_f32(x, "x"),
-                               _lib.NSD_FLAG_RESIDUAL if residual else 0, _dev_f32(logits, "logits"),
+                               (_lib.NSD_FLAG_RESIDUAL if residual else 0) | _extra_flags, _dev_f32(logits, "logits"),
                                _dev_f32(probs, "probs"), scratch.data_ptr(), _stream())
     return logits, probs
 
@@ -170,7 +179,7 @@ def train_forward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: torc
     """Train-mode forward keeping activations in `ws` (from new_workspace)."""
     B, T, Cc = x.shape
     d = spec.dims(B, T)
-    flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0)
+    flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0) | _extra_flags
     L = _lib.lib()
     pp = _dev_f32(flat, "params", (spec.param_count,))
     nbytes, _ = workspace_layout(spec, B, T)
@@ -207,7 +216,7 @@ def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: tor
     else:
         lab_ptr = None
     scale = (1.0 / max(B, 1)) if scale is None else float(scale)
-    flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0)
+    flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0) | _extra_flags
     _call("nsd_head_bwd", C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head"),
                          _dev_f32(logits, "logits", (B, spec.K)), _dev_f32(dlogits, "dlogits", (B, spec.K)),
                          lab_ptr, scale, ws.data_ptr(), _stream())
@@ -236,7 +245,7 @@ def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: t
     `flat` rides in the reduction launch (nsd_grad_reduce_adam); `grads` is still written."""
     B, T, _ = x.shape
     d = spec.dims(B, T)
-    flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0)
+    flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0) | _extra_flags
     pp = _dev_f32(flat, "params", (spec.param_count,))
     if labels.dtype != torch.int32 or not labels.is_cuda or not labels.is_contiguous():
         raise NsdError("labels must be a contiguous int32 tensor on the device")

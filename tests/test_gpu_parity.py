@@ -394,6 +394,34 @@ def test_batched_mfma_path_vs_oracle(nsd, dev, C, H, L, K, residual, B, T):
     assert np.array_equal(lg.argmax(1).cpu().numpy(), ref["logits"].argmax(1))
 
 
+@pytest.mark.parametrize("C,H,L,K,B,T", [(8, 256, 2, 5, 40, 30), (8, 128, 3, 3, 70, 12)])
+def test_batched_path_bf16_operands(nsd, dev, C, H, L, K, B, T):
+    """NSD_FLAG_BF16 (BASELINE cfg3's precision; extension, oracle = the fp32 oracle): GEMM operands rounded to bf16 on the
+    matrix pipe, fp32 accumulate.  Tolerances are those of 8-bit mantissas: logits 3e-2, gradients 5 % of each tensor's
+    max; the fp32 default must be unaffected by the switch being toggled back."""
+    from nsd_amd import ops
+    d = orc.Dims(C=C, H=H, L=L, K=K)
+    spec = ops.ModelSpec(C=C, H=H, L=L, K=K)
+    flat_np = orc.flatten_state(synth_params(C, H, L, K, seed=C + H + L), d)
+    x, y = synth_x(B, T, C=C, seed=H + B), synth_labels(B, K=K, seed=H)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, d)
+    ops.set_gemm_bf16(True)
+    try:
+        loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, x, y, spec=spec)
+        lg, _ = ops.infer(spec, _t(flat_np, dev), _t(x, dev))
+    finally:
+        ops.set_gemm_bf16(False)
+    err = np.abs(logits - fw["logits"]).max()
+    assert 1e-6 < err < 3e-2, err                               # really bf16 (not the fp32 path), and within its tolerance
+    assert np.abs(lg.cpu().numpy() - fw["logits"]).max() < 3e-2
+    assert abs(loss - loss_ref) < 2e-2
+    got, ref = orc.unflatten(grads, d), orc.unflatten(g_ref, d)
+    for k in orc.param_names(d):
+        assert np.abs(got[k] - ref[k]).max() <= 5e-2 * max(np.abs(ref[k]).max(), 1e-6) + 1e-6, k
+    loss2, grads2, logits2 = _hip_loss_grads(nsd, dev, flat_np, x, y, spec=spec)
+    assert np.abs(logits2 - fw["logits"]).max() < LOGIT_TOL
+
+
 # ---------------------------------------------------------------------------------------------------
 # full BASELINE sizes through size-independent properties
 # ---------------------------------------------------------------------------------------------------

@@ -23,3 +23,16 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(3): ops.infer(m.spec, flat, x)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
 print(f"cfg3 B={B} inference: {dt*1e3:.2f} ms  {B/dt:.0f} windows/s")
+ops.set_gemm_bf16(True)
+m.train()
+for _ in range(2): tr.step(x, y)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): tr.step(x, y)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+print(f"cfg3 B={B} bf16 GEMM operands: {dt*1e3:.2f} ms/step  {B/dt:.0f} trials/s")
+m.eval()
+for _ in range(2): ops.infer(m.spec, flat, x)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): ops.infer(m.spec, flat, x)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+print(f"cfg3 B={B} bf16 inference: {dt*1e3:.2f} ms  {B/dt:.0f} windows/s")
