@@ -178,6 +178,25 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdAll all) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    // the cell's own operands do not depend on the GEMM: fetch them now, their latency runs under the k loop
+    const int cc = 32 * wn + (lane & 31), g = cc & 3, u = u0 + (cc >> 2);
+    const bool uok = u < H;
+    const float bias = uok ? a.b_ih[g * H + u] + a.b_hh[g * H + u] : 0.f;
+    float *cst = const_cast<float *>(all.c_base) + (size_t)blockIdx.z * 2 * a.B * H;     // inference: cell-state ping-pong
+    const float *c_in = cst + (size_t)(t & 1) * a.B * H;
+    float *c_out = cst + (size_t)((t + 1) & 1) * a.B * H;
+    float cp[16], rs[16], mk[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int b = b0 + 32 * wm + acc_row(r, lane);
+        const size_t row = (size_t)(b < a.B ? b : 0) * T + t;
+        const size_t bh = (size_t)(b < a.B ? b : 0) * H + (uok ? u : 0);
+        const size_t ru = row * H + (uok ? u : 0);
+        cp[r] = t == 0 ? 0.f : (a.cseq ? a.cseq[ru - H] : c_in[bh]);
+        rs[r] = a.res_in ? a.res_in[ru] : 0.f;
+        mk[r] = a.mask ? a.mask[ru] : 1.f;
+    }
+
     // two k segments: the layer input (I wide) and the recurrent state h_{t-1} (H wide; zero at t = 0)
     for (int seg = 0; seg < 2; ++seg) {
         const int K = seg == 0 ? I : H;
@@ -221,25 +240,9 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_mfma(StepFwdAll all) {
         }
     }
 
-    // ---- fused LSTM cell: lane column c = 32*wn + (lane & 31) -> unit u0 + c/4, gate c & 3 (the quad holds i,f,g,o)
-    const int c = 32 * wn + (lane & 31), g = c & 3, u = u0 + (c >> 2);
+    // ---- fused LSTM cell: lane column cc = 32*wn + (lane & 31) -> unit u, gate g (the quad holds i,f,g,o); the operands
+    // of the cell were fetched at the top of the kernel
     if (u >= H) return;                                           // (whole quads leave together)
-    const float bias = a.b_ih[g * H + u] + a.b_hh[g * H + u];
-    // inference: this layer's cell-state ping-pong (read step t-1's buffer, write step t's)
-    float *cst = const_cast<float *>(all.c_base) + (size_t)blockIdx.z * 2 * a.B * H;
-    const float *c_in = cst + (size_t)(t & 1) * a.B * H;
-    float *c_out = cst + (size_t)((t + 1) & 1) * a.B * H;
-    // all 16 previous cell states (and residual / multiplier operands) first: one memory latency, not one per row
-    float cp[16], rs[16], mk[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int b = b0 + 32 * wm + acc_row(r, lane);
-        const size_t row = (size_t)(b < a.B ? b : 0) * T + t;
-        const size_t bh = (size_t)(b < a.B ? b : 0) * H + u;
-        cp[r] = t == 0 ? 0.f : (a.cseq ? a.cseq[(row - 1) * H + u] : c_in[bh]);
-        rs[r] = a.res_in ? a.res_in[row * H + u] : 0.f;
-        mk[r] = a.mask ? a.mask[row * H + u] : 1.f;
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int b = b0 + 32 * wm + acc_row(r, lane);
