@@ -146,7 +146,9 @@ int nsd_head_train(const nsd_dims *d, const float *params, const float *rrelu_sl
 /*
  * nsd_lstm_fwd + nsd_head_train in ONE launch where the shape allows (H = 48, L = 2, T <= 1024, F <= 64, K <= 8: the
  * attention pooling rides along the recurrence and the dense head, loss and head backward run in the kernel's tail);
- * other shapes run the two launches it replaces.  Same outputs, workspace contents and gradient slabs either way.
+ * other shapes run the two launches it replaces.  Same outputs, workspace contents and gradient slabs either way --
+ * except that the single launch does not write the workspace's `top` region when the residual extension is off (it
+ * would duplicate the last layer's hseq, which nsd_lstm_bwd and the kernel's own tail read instead).
  */
 int nsd_lstm_head_train(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
                         const float *rrelu_slope, const float *drop_head, const int32_t *labels, float scale, uint32_t flags,

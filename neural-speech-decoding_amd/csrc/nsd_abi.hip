@@ -369,6 +369,7 @@ static int lstm_head_train_impl(const nsd_dims *d, const float *params, const fl
     a.fc0_w = h.fc0_w; a.fc0_b = h.fc0_b; a.fc3_w = h.fc3_w; a.fc3_b = h.fc3_b;
     a.eval_slope = h.eval_slope; a.K = d->K; a.F = d->F;
     a.head_train = 1;
+    if (!a.residual) a.top = nullptr;      // top == layer-1 h: the kernel's tail reads hseq1, the saver skips the duplicate
     a.labels = labels; a.rrelu_slope = rrelu_slope; a.drop_head = drop_head; a.scale = scale;
     a.logits = logits; a.loss = workspace + w.loss; a.alpha = workspace + w.alpha; a.pooled = workspace + w.pooled;
     a.fc0_pre = workspace + w.fc0_pre; a.dscore = workspace + w.dscore; a.dpooled = workspace + w.dpooled;

@@ -621,7 +621,8 @@ template <int NB>
 __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b) {
     const int T = a.T;
     if (ablated(a.ablate, 256)) return;
-    const float *top = a.top + (size_t)b * T * H;
+    // without the residual extension the attention input IS the layer-1 output: that sequence is not saved twice
+    const float *top = (a.top ? a.top : a.hseq1) + (size_t)b * T * H;
     const float mx = sm.md[0], rden = sm.md[1];
     float al[2], dd[2];
     float lsd = 0.f;
@@ -846,7 +847,7 @@ int nsd_lstm2_fwd48_launch(const Lstm2FwdArgs &a, int nb, int grid, hipStream_t 
     // one trial per workgroup: the save ring and the register budget are sized for NB = 1; larger batches loop
     if (nb != 1) { nsd_set_error("lstm2_fwd48: NB=%d not built", nb); return NSD_E_INVALID; }
     if (a.head_train) {
-        if (!nsd_lstm2_fwd48_head_train_fits(a.T, a.F, a.K) || !a.top || a.logits_out) {
+        if (!nsd_lstm2_fwd48_head_train_fits(a.T, a.F, a.K) || !(a.top || a.hseq1) || a.logits_out) {
             nsd_set_error("lstm2_fwd48: fused train head needs T<=%d, F<=64, K<=%d and the training workspace", TT_TMAX, TT_KMAX);
             return NSD_E_INVALID;
         }
