@@ -38,7 +38,7 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector == FP32 mat
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-TRAFFIC_FILE = "r01_v9_hbm_traffic.json"      # written by tools/pmc_run.sh + tools/pmc_summarize.py for the current kernels
+TRAFFIC_FILE = "r01_v10_hbm_traffic.json"      # written by tools/pmc_run.sh + tools/pmc_summarize.py for the current kernels
 
 
 def algorithmic_per_trial(T, C, H, L=2, K=3):
