@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)      # the GPU clock ramps over the first tens of steps
     ap.add_argument("--batch-per-gpu", type=int, default=256)
     ap.add_argument("--T", type=int, default=250)
-    ap.add_argument("--preheat-ms", type=float, default=150.0, help="untimed load before the warm-up steps (GPU clock ramp)")
+    ap.add_argument("--preheat-steps", type=int, default=500, help="untimed steps before the warm-up steps (GPU clock ramp, ~0.15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events")
@@ -144,12 +144,12 @@ def main():
     else:
         do_step = lambda: trainer.step(x, y)
     # clock ramp: the GPU reaches its sustained clock only after some tens of milliseconds of load; run the same step
-    # untimed for --preheat-ms first (library load, allocator and RCCL set-up happen here too), then the W warm-up steps
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
-        for _ in range(10):
-            do_step()
-        torch.cuda.synchronize()
+    # untimed first (library load, allocator and RCCL set-up happen here too), then the W warm-up steps.  A FIXED number
+    # of steps, not a time budget: with more than one rank every step contains a collective, so all ranks must run
+    # exactly the same number of them.
+    for _ in range(max(args.preheat_steps, 0)):
+        do_step()
+    torch.cuda.synchronize()
     note(f"warm-up: {args.warmup} steps of B={B}/GPU T={T} on {world} GPU(s), {'hipGraph replay' if use_graph else 'eager launches'}")
     for _ in range(max(args.warmup, 1)):
         do_step()
