@@ -107,6 +107,8 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if os.environ.get("NSD_BENCH_ONE_GPU"):      # rehearsal only: all ranks on GPU 0 (with NSD_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     nsd_amd.load_library()

@@ -237,7 +237,8 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # NSD_DIST_BACKEND=gloo: rehearsal of the multi-rank code path where RCCL cannot run (several ranks on one GPU)
+        backend = backend or os.environ.get("NSD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device("cuda", local))
