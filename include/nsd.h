@@ -12,6 +12,9 @@
  * Conventions
  *   - plain C symbols, no C++/torch types; every function returns int:
  *     0 = ok, <0 = error (NSD_E_*); nsd_last_error() gives thread-local text.
+ *   - every entry point that reads or writes the training workspace takes `workspace_bytes`, the size of the
+ *     caller's buffer, and returns NSD_E_WORKSPACE (launching nothing) when it is smaller than
+ *     nsd_workspace_bytes(d) -- a C caller cannot be overrun.
  *   - the CALLER owns every buffer.  All pointers are DEVICE pointers (fp32
  *     unless stated) valid on the current HIP device; the library allocates
  *     nothing and never synchronises: work is enqueued on `stream`
@@ -36,13 +39,13 @@
 extern "C" {
 #endif
 
-#define NSD_VERSION 100          /* 0.1.0 */
+#define NSD_VERSION 200          /* 0.2.0: every entry point that touches the training workspace takes its size */
 #define NSD_MAX_LAYERS 8
 
 #define NSD_OK            0
 #define NSD_E_INVALID    -1      /* bad argument / unsupported shape */
 #define NSD_E_LAUNCH     -2      /* HIP launch or runtime error */
-#define NSD_E_WORKSPACE  -3      /* workspace too small */
+#define NSD_E_WORKSPACE  -3      /* workspace_bytes < nsd_workspace_bytes(d): nothing was launched */
 
 /* flags */
 #define NSD_FLAG_RESIDUAL   1u   /* extension (not in the reference): out_l = LSTM_l(in_l) + in_l, l>=1 */
@@ -115,7 +118,7 @@ int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t f
  * Fills hseq/cseq/gact/inseq/top of the workspace.
  */
 int nsd_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
-                 uint32_t flags, float *workspace, void *stream);
+                 uint32_t flags, float *workspace, int64_t workspace_bytes, void *stream);
 
 /*
  * Head forward: attention pooling over time, LayerNorm, fc (lstm_eeg_model.py:35-39),
@@ -124,7 +127,7 @@ int nsd_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const f
  * drop_head:   NULL or multiplier mask [B,F] (nn.Dropout, lstm_eeg_model.py:28)
  */
 int nsd_head_fwd(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
-                 float *workspace, float *logits, float *probs, void *stream);
+                 float *workspace, int64_t workspace_bytes, float *logits, float *probs, void *stream);
 
 /*
  * Head backward.  Either dlogits[B,K] is given, or labels[B] (int32) with `scale`:
@@ -134,14 +137,14 @@ int nsd_head_fwd(const nsd_dims *d, const float *params, const float *rrelu_slop
  */
 int nsd_head_bwd(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
                  const float *logits, const float *dlogits, const int32_t *labels, float scale,
-                 float *workspace, void *stream);
+                 float *workspace, int64_t workspace_bytes, void *stream);
 
 /*
  * Train-step head: nsd_head_fwd + mean cross-entropy + nsd_head_bwd of every trial in ONE launch (sequence and head
  * parameters staged in LDS once).  Same workspace outputs as the two separate calls; logits[B,K] is written too.
  */
 int nsd_head_train(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
-                   const int32_t *labels, float scale, float *workspace, float *logits, void *stream);
+                   const int32_t *labels, float scale, float *workspace, int64_t workspace_bytes, float *logits, void *stream);
 
 /*
  * nsd_lstm_fwd + nsd_head_train in ONE launch where the shape allows (H = 48, L = 2, T <= 1024, F <= 64, K <= 8: the
@@ -152,7 +155,7 @@ int nsd_head_train(const nsd_dims *d, const float *params, const float *rrelu_sl
  */
 int nsd_lstm_head_train(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
                         const float *rrelu_slope, const float *drop_head, const int32_t *labels, float scale, uint32_t flags,
-                        float *workspace, float *logits, void *stream);
+                        float *workspace, int64_t workspace_bytes, float *logits, void *stream);
 
 /*
  * Train-mode random streams generated INSIDE the kernels (no mask tensors in HBM): the three streams of one step are
@@ -167,28 +170,29 @@ typedef struct nsd_rng {
 } nsd_rng;
 int nsd_rng_path(const nsd_dims *d);
 int nsd_lstm_head_train_rng(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, const int32_t *labels,
-                            float scale, uint32_t flags, float *workspace, float *logits, void *stream);
+                            float scale, uint32_t flags, float *workspace, int64_t workspace_bytes, float *logits, void *stream);
 int nsd_lstm_bwd_rng(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, uint32_t flags,
-                     float *workspace, void *stream);
+                     float *workspace, int64_t workspace_bytes, void *stream);
 
 /*
  * Stacked LSTM backward (BPTT) through lstm_eeg_model.py:34 with the activations kept by nsd_lstm_fwd.
- * Partial gradients go to the slabs.  dx: NULL or [B,T,C].
+ * Partial gradients go to the slabs.  dx (gradient w.r.t. the EEG window) is reserved: it MUST be NULL -- the
+ * parameter gradients are the whole product of this path; a non-NULL dx returns NSD_E_INVALID and launches nothing.
  */
 int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
-                 uint32_t flags, float *workspace, float *dx, void *stream);
+                 uint32_t flags, float *workspace, int64_t workspace_bytes, float *dx, void *stream);
 
 /* grads[P] (=|+=) sum over slabs.  accumulate: 0 overwrite, 1 add to existing. */
-int nsd_grad_reduce(const nsd_dims *d, const float *workspace, float *grads, int32_t accumulate, void *stream);
+int nsd_grad_reduce(const nsd_dims *d, const float *workspace, int64_t workspace_bytes, float *grads, int32_t accumulate, void *stream);
 
 /* Single-rank train step tail: nsd_grad_reduce (grads[] is still written) followed, in the same launch, by
  * nsd_adam_step on the reduced gradient -- same arithmetic in the same order as the two separate calls.  With more
  * than one rank the all-reduce sits between the two and the separate entry points are used. */
-int nsd_grad_reduce_adam(const nsd_dims *d, const float *workspace, float *grads, float *p, float *m, float *v, float lr,
+int nsd_grad_reduce_adam(const nsd_dims *d, const float *workspace, int64_t workspace_bytes, float *grads, float *p, float *m, float *v, float lr,
                          float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t step, void *stream);
 
 /* sum of the per-trial losses written by nsd_head_bwd -> out[0] (device) */
-int nsd_loss_sum(const nsd_dims *d, const float *workspace, float *out, void *stream);
+int nsd_loss_sum(const nsd_dims *d, const float *workspace, int64_t workspace_bytes, float *out, void *stream);
 
 /* torch.optim.Adam semantics (no amsgrad); step counted from 1; all vectors length n */
 int nsd_adam_step(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
@@ -218,12 +222,6 @@ int nsd_train_masks_dev(uint64_t seed, const int64_t *step_dev, float p_lstm, fl
                         int64_t n_head, float *rrelu_slope, float *drop_head, void *stream);
 int nsd_adam_step_dev(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2, float eps,
                       float weight_decay, float grad_scale, const int64_t *step_dev, void *stream);
-
-/*
- * Diagnostics: when set to a device buffer of >= 64 int64, the LSTM backward kernel's workgroup 0 stores per wave
- * {cycles working, cycles waiting at the step barrier}.  NULL (default) switches the stamps off.
- */
-int nsd_debug_profile_buffer(void *device_int64_buffer);
 
 #ifdef __cplusplus
 }

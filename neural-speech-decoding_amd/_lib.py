@@ -49,22 +49,21 @@ SYMBOLS = {
     "nsd_zscore_fwd": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "nsd_infer_scratch_bytes": (C.c_int64, [_dp]),
     "nsd_infer": (C.c_int, [_dp, _fp, _fp, C.c_uint32, _fp, _fp, _vp, _vp]),
-    "nsd_lstm_fwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, _vp]),
-    "nsd_head_fwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
-    "nsd_head_bwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, _fp, _vp]),
-    "nsd_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _ip, C.c_float, _fp, _fp, _vp]),
-    "nsd_lstm_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, C.c_uint32, _fp, _fp, _vp]),
+    "nsd_lstm_fwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, C.c_int64, _vp]),
+    "nsd_head_fwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, _vp]),
+    "nsd_head_bwd": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, _fp, C.c_int64, _vp]),
+    "nsd_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _ip, C.c_float, _fp, C.c_int64, _fp, _vp]),
+    "nsd_lstm_head_train": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp, _ip, C.c_float, C.c_uint32, _fp, C.c_int64, _fp, _vp]),
     "nsd_rng_path": (C.c_int, [_dp]),
-    "nsd_lstm_head_train_rng": (C.c_int, [_dp, _fp, _fp, _vp, _ip, C.c_float, C.c_uint32, _fp, _fp, _vp]),
-    "nsd_lstm_bwd_rng": (C.c_int, [_dp, _fp, _fp, _vp, C.c_uint32, _fp, _vp]),
-    "nsd_lstm_bwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, _fp, _vp]),
-    "nsd_grad_reduce": (C.c_int, [_dp, _fp, _fp, C.c_int32, _vp]),
-    "nsd_grad_reduce_adam": (C.c_int, [_dp, _fp, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [C.c_int32, _vp]),
-    "nsd_loss_sum": (C.c_int, [_dp, _fp, _fp, _vp]),
+    "nsd_lstm_head_train_rng": (C.c_int, [_dp, _fp, _fp, _vp, _ip, C.c_float, C.c_uint32, _fp, C.c_int64, _fp, _vp]),
+    "nsd_lstm_bwd_rng": (C.c_int, [_dp, _fp, _fp, _vp, C.c_uint32, _fp, C.c_int64, _vp]),
+    "nsd_lstm_bwd": (C.c_int, [_dp, _fp, _fp, _fp, C.c_uint32, _fp, C.c_int64, _fp, _vp]),
+    "nsd_grad_reduce": (C.c_int, [_dp, _fp, C.c_int64, _fp, C.c_int32, _vp]),
+    "nsd_grad_reduce_adam": (C.c_int, [_dp, _fp, C.c_int64, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [C.c_int32, _vp]),
+    "nsd_loss_sum": (C.c_int, [_dp, _fp, C.c_int64, _fp, _vp]),
     "nsd_adam_step": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [C.c_int32, _vp]),
     "nsd_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint32, C.c_float, C.c_int64, _fp, _vp]),
     "nsd_rrelu_noise": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int64, _fp, _vp]),
-    "nsd_debug_profile_buffer": (C.c_int, [_vp]),
     "nsd_step_counter_inc": (C.c_int, [_vp, _vp]),
     "nsd_train_masks_dev": (C.c_int, [C.c_uint64, _vp, C.c_float, C.c_float, C.c_int64, _fp, C.c_int64, _fp, _fp, _vp]),
     "nsd_adam_step_dev": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [_vp, _vp]),
@@ -99,6 +98,10 @@ def lib() -> C.CDLL:
                 continue
             fn = getattr(L, name)        # AttributeError if the ABI and the header ever diverge
             fn.restype, fn.argtypes = res, args
+        if diag and hasattr(L, "nsd_debug_profile_buffer"):      # diagnostic build only; not part of include/nsd.h
+            L.nsd_debug_profile_buffer.restype, L.nsd_debug_profile_buffer.argtypes = C.c_int, [_vp]
+        if L.nsd_version() < 200 and not diag:
+            raise NsdError(f"{LIB_PATH} is ABI v{L.nsd_version()}, this binding needs >= 200: rebuild it")
         _lib = L
     return _lib
 

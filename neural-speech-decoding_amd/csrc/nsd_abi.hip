@@ -103,7 +103,32 @@ static nsd_ws_layout make_ws(const nsd_dims *d, bool have_device) {
     return w;
 }
 
+// Diagnostic build only (make prof -> libnsd_hip_prof.so, or -DNSD_ABLATE_HOOKS=1): the cycle-stamp buffer and the
+// NSD_ABLATE timing switches.  The shipped library has neither the symbol nor the getenv.
+#if NSD_PROFILE || NSD_ABLATE_HOOKS
 static long long *g_dbg = nullptr;
+static int ablate_mask() {
+    static int mask = -1;
+    if (mask < 0) { const char *e = getenv("NSD_ABLATE"); mask = e ? atoi(e) : 0; }
+    return mask;
+}
+extern "C" int nsd_debug_profile_buffer(void *p) { g_dbg = (long long *)p; return NSD_OK; }
+#else
+static long long *const g_dbg = nullptr;
+static int ablate_mask() { return 0; }
+#endif
+
+// workspace size check shared by every entry point that touches the training workspace
+static int check_ws(const nsd_dims *d, const void *workspace, int64_t workspace_bytes, const char *who, nsd_ws_layout *w) {
+    if (!workspace) { nsd_set_error("%s: workspace is NULL", who); return NSD_E_INVALID; }
+    *w = make_ws(d, true);
+    const int64_t need = w->total * (int64_t)sizeof(float);
+    if (workspace_bytes < need) {
+        nsd_set_error("%s: workspace of %lld bytes is smaller than nsd_workspace_bytes() = %lld", who, (long long)workspace_bytes, (long long)need);
+        return NSD_E_WORKSPACE;
+    }
+    return NSD_OK;
+}
 
 static bool device_present() {
     int n = 0;
@@ -165,7 +190,7 @@ static int build_lstm_fwd(const nsd_dims *d, const float *params, const float *x
     a.dbg = g_dbg;
     a.B = d->B; a.T = d->T; a.C = d->C;
     a.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
-    { const char *ab_ = getenv("NSD_ABLATE"); a.ablate = ab_ ? atoi(ab_) : 0; }
+    a.ablate = ablate_mask();
     const int64_t BTH = (int64_t)d->B * d->T * d->H;
     if (train) {
         a.hseq0 = ws + w.hseq; a.hseq1 = ws + w.hseq + BTH;
@@ -266,11 +291,12 @@ int nsd_infer(const nsd_dims *d, const float *params, const float *x, uint32_t f
 }
 
 int nsd_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, uint32_t flags,
-                 float *workspace, void *stream) {
+                 float *workspace, int64_t workspace_bytes, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !x || !workspace) { nsd_set_error("lstm_fwd: null pointer"); return NSD_E_INVALID; }
+    nsd_ws_layout w;
+    if (const int rc = check_ws(d, workspace, workspace_bytes, "lstm_fwd", &w)) return rc;
     if (d->B == 0) return NSD_OK;
-    const nsd_ws_layout w = make_ws(d, true);
     if (!fast_path_ok(d)) {
         const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
         if (nsd_lstm_batched_ok(d, true))        // large H: per-step batched gate GEMM on the matrix pipe
@@ -287,11 +313,12 @@ int nsd_lstm_fwd(const nsd_dims *d, const float *params, const float *x, const f
 }
 
 int nsd_head_fwd(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
-                 float *workspace, float *logits, float *probs, void *stream) {
+                 float *workspace, int64_t workspace_bytes, float *logits, float *probs, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !workspace || !logits) { nsd_set_error("head_fwd: null pointer"); return NSD_E_INVALID; }
+    nsd_ws_layout w;
+    if (const int rc = check_ws(d, workspace, workspace_bytes, "head_fwd", &w)) return rc;
     if (d->B == 0) return NSD_OK;
-    const nsd_ws_layout w = make_ws(d, true);
     HeadArgs h = build_head(d, params);
     h.top = workspace + w.top;
     h.rrelu_slope = rrelu_slope; h.drop_head = drop_head;
@@ -302,15 +329,16 @@ int nsd_head_fwd(const nsd_dims *d, const float *params, const float *rrelu_slop
 
 int nsd_head_bwd(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
                  const float *logits, const float *dlogits, const int32_t *labels, float scale, float *workspace,
-                 void *stream) {
+                 int64_t workspace_bytes, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !workspace) { nsd_set_error("head_bwd: null pointer"); return NSD_E_INVALID; }
     if (!dlogits && !(labels && logits)) {
         nsd_set_error("head_bwd: need dlogits, or labels together with logits");
         return NSD_E_INVALID;
     }
+    nsd_ws_layout w;
+    if (const int rc = check_ws(d, workspace, workspace_bytes, "head_bwd", &w)) return rc;
     if (d->B == 0) return NSD_OK;
-    const nsd_ws_layout w = make_ws(d, true);
     HeadArgs h = build_head(d, params);
     h.top = workspace + w.top;
     h.rrelu_slope = rrelu_slope; h.drop_head = drop_head;
@@ -323,11 +351,12 @@ int nsd_head_bwd(const nsd_dims *d, const float *params, const float *rrelu_slop
 }
 
 int nsd_head_train(const nsd_dims *d, const float *params, const float *rrelu_slope, const float *drop_head,
-                   const int32_t *labels, float scale, float *workspace, float *logits, void *stream) {
+                   const int32_t *labels, float scale, float *workspace, int64_t workspace_bytes, float *logits, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !workspace || !logits || !labels) { nsd_set_error("head_train: null pointer"); return NSD_E_INVALID; }
+    nsd_ws_layout w;
+    if (const int rc = check_ws(d, workspace, workspace_bytes, "head_train", &w)) return rc;
     if (d->B == 0) return NSD_OK;
-    const nsd_ws_layout w = make_ws(d, true);
     HeadArgs h = build_head(d, params);
     h.top = workspace + w.top;
     h.rrelu_slope = rrelu_slope; h.drop_head = drop_head;
@@ -350,18 +379,19 @@ int nsd_rng_path(const nsd_dims *d) {
 
 static int lstm_head_train_impl(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
                                 const float *rrelu_slope, const float *drop_head, const RngArgs *rng, const int32_t *labels,
-                                float scale, uint32_t flags, float *workspace, float *logits, void *stream) {
+                                float scale, uint32_t flags, float *workspace, int64_t workspace_bytes, float *logits, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !x || !workspace || !logits || !labels) { nsd_set_error("lstm_head_train: null pointer"); return NSD_E_INVALID; }
+    nsd_ws_layout w;
+    if (const int rc = check_ws(d, workspace, workspace_bytes, "lstm_head_train", &w)) return rc;
     if (d->B == 0) return NSD_OK;
     if (!fused_train_shape(d)) {
         if (rng) { nsd_set_error("lstm_head_train_rng: shape outside the single-launch path (nsd_rng_path() == 0)"); return NSD_E_INVALID; }
         // shapes outside the fused kernel: the two launches it replaces
-        const int rc = nsd_lstm_fwd(d, params, x, drop_lstm, flags, workspace, stream);
+        const int rc = nsd_lstm_fwd(d, params, x, drop_lstm, flags, workspace, workspace_bytes, stream);
         if (rc != NSD_OK) return rc;
-        return nsd_head_train(d, params, rrelu_slope, drop_head, labels, scale, workspace, logits, stream);
+        return nsd_head_train(d, params, rrelu_slope, drop_head, labels, scale, workspace, workspace_bytes, logits, stream);
     }
-    const nsd_ws_layout w = make_ws(d, true);
     Lstm2FwdArgs a;
     build_lstm_fwd(d, params, x, drop_lstm, flags, workspace, w, true, nullptr, &a);
     const HeadArgs h = build_head(d, params);
@@ -382,24 +412,25 @@ static int lstm_head_train_impl(const nsd_dims *d, const float *params, const fl
 
 int nsd_lstm_head_train(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
                         const float *rrelu_slope, const float *drop_head, const int32_t *labels, float scale, uint32_t flags,
-                        float *workspace, float *logits, void *stream) {
-    return lstm_head_train_impl(d, params, x, drop_lstm, rrelu_slope, drop_head, nullptr, labels, scale, flags, workspace, logits, stream);
+                        float *workspace, int64_t workspace_bytes, float *logits, void *stream) {
+    return lstm_head_train_impl(d, params, x, drop_lstm, rrelu_slope, drop_head, nullptr, labels, scale, flags, workspace, workspace_bytes, logits, stream);
 }
 
 int nsd_lstm_head_train_rng(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, const int32_t *labels,
-                            float scale, uint32_t flags, float *workspace, float *logits, void *stream) {
+                            float scale, uint32_t flags, float *workspace, int64_t workspace_bytes, float *logits, void *stream) {
     RngArgs r;
     if (make_rng(rng, &r) != NSD_OK) return NSD_E_INVALID;
-    return lstm_head_train_impl(d, params, x, nullptr, nullptr, nullptr, &r, labels, scale, flags, workspace, logits, stream);
+    return lstm_head_train_impl(d, params, x, nullptr, nullptr, nullptr, &r, labels, scale, flags, workspace, workspace_bytes, logits, stream);
 }
 
 static int lstm_bwd_impl(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, const RngArgs *rng,
-                         uint32_t flags, float *workspace, float *dx, void *stream) {
+                         uint32_t flags, float *workspace, int64_t workspace_bytes, float *dx, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !x || !workspace) { nsd_set_error("lstm_bwd: null pointer"); return NSD_E_INVALID; }
-    if (dx) { nsd_set_error("lstm_bwd: dx (gradient w.r.t. the EEG window) is not implemented"); return NSD_E_INVALID; }
+    if (dx) { nsd_set_error("lstm_bwd: dx is reserved and must be NULL (include/nsd.h)"); return NSD_E_INVALID; }
+    nsd_ws_layout w;
+    if (const int rc = check_ws(d, workspace, workspace_bytes, "lstm_bwd", &w)) return rc;
     if (d->B == 0) return NSD_OK;
-    const nsd_ws_layout w = make_ws(d, true);
     const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
     const int64_t BTH = (int64_t)d->B * d->T * d->H;
     if (!fast_path_ok(d) && nsd_lstm_batched_ok(d, true))
@@ -432,50 +463,53 @@ static int lstm_bwd_impl(const nsd_dims *d, const float *params, const float *x,
     a.o_w_ih1 = pl.w_ih[1]; a.o_w_hh1 = pl.w_hh[1]; a.o_b_ih1 = pl.b_ih[1]; a.o_b_hh1 = pl.b_hh[1];
     a.B = d->B; a.T = d->T; a.C = d->C;
     a.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
-    { const char *ab_ = getenv("NSD_ABLATE"); a.ablate = ab_ ? atoi(ab_) : 0; }
+    a.ablate = ablate_mask();
     if (rng) a.rng = *rng;
     return nsd_lstm2_bwd_launch(a, d->H, (hipStream_t)stream);
 }
 
 int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, uint32_t flags,
-                 float *workspace, float *dx, void *stream) {
-    return lstm_bwd_impl(d, params, x, drop_lstm, nullptr, flags, workspace, dx, stream);
+                 float *workspace, int64_t workspace_bytes, float *dx, void *stream) {
+    return lstm_bwd_impl(d, params, x, drop_lstm, nullptr, flags, workspace, workspace_bytes, dx, stream);
 }
 
 int nsd_lstm_bwd_rng(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, uint32_t flags,
-                     float *workspace, void *stream) {
+                     float *workspace, int64_t workspace_bytes, void *stream) {
     RngArgs r;
     if (make_rng(rng, &r) != NSD_OK) return NSD_E_INVALID;
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!fused_train_shape(d)) { nsd_set_error("lstm_bwd_rng: shape outside the single-launch path (nsd_rng_path() == 0)"); return NSD_E_INVALID; }
-    return lstm_bwd_impl(d, params, x, nullptr, &r, flags, workspace, nullptr, stream);
+    return lstm_bwd_impl(d, params, x, nullptr, &r, flags, workspace, workspace_bytes, nullptr, stream);
 }
 
-int nsd_grad_reduce(const nsd_dims *d, const float *workspace, float *grads, int32_t accumulate, void *stream) {
+int nsd_grad_reduce(const nsd_dims *d, const float *workspace, int64_t workspace_bytes, float *grads, int32_t accumulate, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!workspace || !grads) { nsd_set_error("grad_reduce: null pointer"); return NSD_E_INVALID; }
-    const nsd_ws_layout w = make_ws(d, true);
+    nsd_ws_layout w;
+    if (const int rc = check_ws(d, workspace, workspace_bytes, "grad_reduce", &w)) return rc;
     const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
     return nsd_grad_reduce_launch(workspace + w.slabs, align4(pl.lstm_total), d->B > 0 ? (int)w.n_slabs : 0, pl.lstm_total,
                                   workspace + w.hslabs, pl.total - pl.lstm_total, d->B, grads, accumulate,
                                   (hipStream_t)stream);
 }
 
-int nsd_grad_reduce_adam(const nsd_dims *d, const float *workspace, float *grads, float *p, float *m, float *v, float lr,
+int nsd_grad_reduce_adam(const nsd_dims *d, const float *workspace, int64_t workspace_bytes, float *grads, float *p, float *m, float *v, float lr,
                          float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t step, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!workspace || !grads || !p || !m || !v) { nsd_set_error("grad_reduce_adam: null pointer"); return NSD_E_INVALID; }
-    const nsd_ws_layout w = make_ws(d, true);
+    nsd_ws_layout w;
+    if (const int rc = check_ws(d, workspace, workspace_bytes, "grad_reduce_adam", &w)) return rc;
     const ParamLayout pl = nsd_make_layout(d->C, d->H, d->L, d->K, d->F);
     return nsd_grad_reduce_adam_launch(workspace + w.slabs, align4(pl.lstm_total), d->B > 0 ? (int)w.n_slabs : 0, pl.lstm_total,
                                        workspace + w.hslabs, pl.total - pl.lstm_total, d->B, grads, p, m, v, lr, beta1, beta2,
                                        eps, weight_decay, grad_scale, step, (hipStream_t)stream);
 }
 
-int nsd_loss_sum(const nsd_dims *d, const float *workspace, float *out, void *stream) {
+int nsd_loss_sum(const nsd_dims *d, const float *workspace, int64_t workspace_bytes, float *out, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!workspace || !out) { nsd_set_error("loss_sum: null pointer"); return NSD_E_INVALID; }
-    const nsd_ws_layout w = make_ws(d, true);
+    nsd_ws_layout w;
+    if (const int rc = check_ws(d, workspace, workspace_bytes, "loss_sum", &w)) return rc;
     return nsd_loss_sum_launch(workspace + w.loss, d->B, out, (hipStream_t)stream);
 }
 
@@ -516,8 +550,6 @@ int nsd_step_counter_inc(int64_t *step_dev, void *stream) {
     if (!step_dev) { nsd_set_error("step_counter_inc: null pointer"); return NSD_E_INVALID; }
     return nsd_step_inc_launch((long long *)step_dev, (hipStream_t)stream);
 }
-
-int nsd_debug_profile_buffer(void *p) { g_dbg = (long long *)p; return NSD_OK; }
 
 int nsd_dropout_mask(uint64_t seed, uint32_t stream_id, float p, int64_t n, float *out, void *stream) {
     if (n < 0 || !out) { nsd_set_error("dropout_mask: null pointer or n<0"); return NSD_E_INVALID; }

@@ -85,6 +85,23 @@ def load_trials(directory: str, label_map: Optional[Dict[str, int]] = None, *, s
     return TrialSet(x=x, y=y, prefix=prefix, files=files, label_map=label_map)
 
 
+def load_trials_npz(path: str, label_map: Optional[Dict[str, int]] = None) -> TrialSet:
+    """The same TrialSet from a packed copy of the data set (`x` [N,T,C] float32, `prefix` [N], `stem` [N]; written by
+    tests/golden/make_trials_fixture.py with load_trials itself) -- the form in which the recorded trials travel to
+    machines that do not hold the CSV directory."""
+    label_map = dict(LABELS_3CLASS_CHECKPOINT if label_map is None else label_map)
+    z = np.load(path, allow_pickle=False)
+    prefix_all = [str(p) for p in z["prefix"]]
+    keep = np.array([p in label_map for p in prefix_all])
+    if not keep.any():
+        raise FileNotFoundError(f"no trials with prefixes {sorted(label_map)} in {path!r}")
+    prefix = [p for p, k in zip(prefix_all, keep) if k]
+    files = [str(s) + ".csv" for s, k in zip(z["stem"], keep) if k]
+    x = np.ascontiguousarray(z["x"][keep], dtype=np.float32)
+    y = np.array([label_map[p] for p in prefix], np.int32)
+    return TrialSet(x=x, y=y, prefix=prefix, files=files, label_map=label_map)
+
+
 def stratified_split(y: Sequence[int], val_fraction: float = 0.2, seed: int = 0) -> Tuple[np.ndarray, np.ndarray]:
     """Indices (train, val): every class contributes round(val_fraction * count) trials to the validation set."""
     y = np.asarray(y)

@@ -11,6 +11,8 @@ There is no CPU implementation: parameters and inputs must be on the GPU, otherw
 """
 from __future__ import annotations
 
+import importlib
+import importlib.util
 import math
 from typing import Optional
 
@@ -182,20 +184,57 @@ class EEG_LSTM(nn.Module):
         return probs
 
 
-def _default_preprocessor(sr: int, tailoring_lambda: float):
-    """The reference filters every window with the third-party MindsAI filter (preprocessor.py:21-36),
-    which is out of scope here (non-commercial licence, host-side numpy).  When this module is dropped
-    into the reference tree the reference's own PreProcessor is importable and is used unchanged;
-    otherwise windows are passed through (same shape / dtype contract, same ValueError)."""
+# Module names under which the reference's PreProcessor can live, in the reference's own resolution order
+# (lstm_eeg_model.py:7-10): package import first (Frontend/app.py:22-28 puts Neuro-Alpha-App/ on sys.path and imports
+# Utilities.tester -> Utilities.lstm_eeg_model -> `.preprocessor`), then the script form with Utilities/ itself on the path.
+_REFERENCE_PREPROCESSOR_MODULES = ("Utilities.preprocessor", "preprocessor")
+
+
+def _find_module(name: str) -> bool:
     try:
-        from preprocessor import PreProcessor  # type: ignore  (reference tree on sys.path)
-        return PreProcessor(sr=sr, tailoring_lambda=tailoring_lambda)
-    except Exception:
-        return _IdentityPreProcessor(sr, tailoring_lambda)
+        return importlib.util.find_spec(name) is not None
+    except (ImportError, ValueError):          # parent package missing / half-initialised entry in sys.modules
+        return False
 
 
-class _IdentityPreProcessor:
-    def __init__(self, sr: int, tailoring_lambda: float = 1.25e-29):
+def resolve_reference_preprocessor(package: Optional[str] = None):
+    """The reference's `PreProcessor` class (preprocessor.py:7-36, the MindsAI filter) as the reference would import
+    it at lstm_eeg_model.py:7-10, or None when no such module is importable.  `package`: name of the package the
+    re-exporting stub lives in (its `__package__`); tried first as `<package>.preprocessor`.
+
+    Only the *lookup* is guarded: once the module is found, errors raised while importing it (e.g. its own MindsAI
+    dependency missing, preprocessor.py:3-6,18-19) propagate, exactly as they would from the reference."""
+    names = ([f"{package}.preprocessor"] if package else []) + list(_REFERENCE_PREPROCESSOR_MODULES)
+    for name in names:
+        if name.split(".")[0] == __name__.split(".")[0]:
+            continue                              # never resolve to this package itself
+        if _find_module(name):
+            return getattr(importlib.import_module(name), "PreProcessor")
+    return None
+
+
+def _default_preprocessor(sr: int, tailoring_lambda: float, package: Optional[str] = None):
+    """The reference always filters the window with the third-party MindsAI filter before the model
+    (lstm_eeg_model.py:66,91).  The filter is out of scope here (non-commercial licence, host-side numpy) and is never
+    restated: the facade uses the reference's own class when it is importable in either of the reference's import
+    modes, and otherwise REFUSES to guess -- skipping the filter changes the probabilities (max |delta| ~ 38 uV on a
+    real trial), so running without it must be asked for explicitly with `preprocess="identity"`."""
+    cls = resolve_reference_preprocessor(package)
+    if cls is None:
+        raise NsdError(
+            "SimplePredictor: the reference's PreProcessor (Utilities/preprocessor.py, MindsAI filter) is not importable "
+            f"as any of {list(_REFERENCE_PREPROCESSOR_MODULES)}; the reference applies it to every window "
+            "(lstm_eeg_model.py:91).  Put Neuro-Alpha-App/ (or Neuro-Alpha-App/Utilities/) on sys.path, pass "
+            "preprocess=<object with .transform([T,C]) -> [T,C]>, or pass preprocess=\"identity\" to run the model "
+            "on unfiltered windows on purpose.")
+    return cls(sr=sr, tailoring_lambda=tailoring_lambda)
+
+
+class IdentityPreProcessor:
+    """Explicit opt-out of the MindsAI filter: same shape / dtype / ValueError contract as the reference's
+    PreProcessor.transform (preprocessor.py:21-36), no filtering.  Selected with `preprocess="identity"`."""
+
+    def __init__(self, sr: int = 125, tailoring_lambda: float = 1.25e-29):
         self.sr, self.tailoring_lambda = sr, tailoring_lambda
 
     def transform(self, chunk_samples_by_channels: np.ndarray) -> np.ndarray:
@@ -212,15 +251,27 @@ class SimplePredictor:
     `device` keeps the reference's keyword and default ("cpu", what tester.py:83 passes) but only names
     where the caller's arrays live: numpy in, numpy out.  The model itself always runs on the GPU
     (`gpu` argument, default "cuda"); if none is available construction fails loudly.
+
+    `preprocess`: None (default) = the reference's own PreProcessor, resolved the way lstm_eeg_model.py:7-10 does
+    (`preprocess_package`: the stub's `__package__`); construction FAILS when it cannot be found.
+    "identity" = no filtering, on purpose.  Any object with `.transform([T,C]) -> [T,C]` is used as given.
     """
 
     def __init__(self, pth_path: str, sr: int, channel_order=None, input_size: int = 8, hidden_size: int = 48,
                  num_layers: int = 2, num_classes: int = 3, dropout: float = 0.60, device: str = "cpu",
-                 tailoring_lambda: float = 1.25e-29, class_names=None, *, preprocess=None, gpu: str = "cuda",
-                 residual: bool = False, normalize: bool = False):
+                 tailoring_lambda: float = 1.25e-29, class_names=None, *, preprocess=None,
+                 preprocess_package: Optional[str] = None, gpu: str = "cuda", residual: bool = False,
+                 normalize: bool = False):
         self.device = torch.device(device)
         self.class_names = class_names or CLASS_NAMES
-        self.pre = preprocess if preprocess is not None else _default_preprocessor(sr, tailoring_lambda)
+        if preprocess is None:
+            self.pre = _default_preprocessor(sr, tailoring_lambda, preprocess_package)
+        elif isinstance(preprocess, str):
+            if preprocess != "identity":
+                raise ValueError(f"preprocess={preprocess!r}: the only named preprocessor is \"identity\"")
+            self.pre = IdentityPreProcessor(sr, tailoring_lambda)
+        else:
+            self.pre = preprocess
         if not torch.cuda.is_available():
             raise NsdError("SimplePredictor needs an MI355X: torch.cuda.is_available() is False and the HIP path has "
                            "no CPU fallback")

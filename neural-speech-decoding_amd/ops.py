@@ -59,7 +59,7 @@ class ModelSpec:
     def offsets(self) -> Dict[str, int]:
         n = 4 * self.L + 8
         offs = (C.c_int64 * n)()
-        _call("nsd_param_layout", self.C, self.H, self.L, self.K, self.F, offs)
+        _call("nsd_param_layout", None, self.C, self.H, self.L, self.K, self.F, offs)
         return dict(zip(self.names(), [int(o) for o in offs]))
 
     def fast_path(self) -> bool:
@@ -80,8 +80,11 @@ def _dev_f32(t: Optional[torch.Tensor], name: str, shape=None) -> Optional[int]:
     return t.data_ptr()
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+class _StreamOf:
+    """Placeholder argument: replaced by the current HIP stream of the launch device inside _call's device guard."""
+
+
+STREAM = _StreamOf()
 
 
 _launch_hook = None
@@ -102,13 +105,26 @@ def set_launch_hook(hook) -> None:
     _launch_hook = hook
 
 
-def _call(name: str, *args) -> None:
+def _call(name: str, dev, *args) -> None:
+    """Launch `name` on device `dev` (the device of the tensors whose pointers are in `args`): the C ABI enqueues on the
+    CURRENT device, so the call is wrapped in a device guard and its stream is that device's current stream -- tensors
+    on cuda:1 while cuda:0 is current would otherwise launch on the wrong GPU."""
     fn = getattr(_lib.lib(), name)
-    if _launch_hook is None:
+    if dev is None:                                   # host-only entry points (layouts, counts)
         check(fn(*args), name)
-    else:
-        with _launch_hook(name):
+        return
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        args = tuple(st if a is STREAM else a for a in args)
+        if _launch_hook is None:
             check(fn(*args), name)
+        else:
+            with _launch_hook(name):
+                check(fn(*args), name)
+
+
+def _nbytes(t: torch.Tensor) -> int:
+    return int(t.numel()) * t.element_size()
 
 
 def workspace_layout(spec: ModelSpec, B: int, T: int) -> Tuple[int, WsLayout]:
@@ -148,7 +164,7 @@ def zscore(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     x3 = x3.contiguous()
     y = torch.empty_like(x3) if out is None else out
     B, T, Cc = x3.shape
-    _call("nsd_zscore_fwd", _dev_f32(x3, "x"), _dev_f32(y, "y", x3.shape), B, T, Cc, _stream())
+    _call("nsd_zscore_fwd", x3.device, _dev_f32(x3, "x"), _dev_f32(y, "y", x3.shape), B, T, Cc, STREAM)
     return y[0] if squeeze else y
 
 
@@ -166,9 +182,9 @@ def infer(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, *, residual: boo
         return logits, probs
     nscr = _lib.lib().nsd_infer_scratch_bytes(C.byref(d))
     scratch = torch.empty(max(int(nscr) // 4, 1), dtype=torch.float32, device=x.device)
-    _call("nsd_infer", C.byref(d), _dev_f32(flat, "params", (spec.param_count,)), _dev_f32(x, "x"),
-                               (_lib.NSD_FLAG_RESIDUAL if residual else 0) | _extra_flags, _dev_f32(logits, "logits"),
-                               _dev_f32(probs, "probs"), scratch.data_ptr(), _stream())
+    _call("nsd_infer", x.device, C.byref(d), _dev_f32(flat, "params", (spec.param_count,)), _dev_f32(x, "x"),
+          (_lib.NSD_FLAG_RESIDUAL if residual else 0) | _extra_flags, _dev_f32(logits, "logits"),
+          _dev_f32(probs, "probs"), scratch.data_ptr(), STREAM)
     return logits, probs
 
 
@@ -182,17 +198,13 @@ def train_forward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: torc
     flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0) | _extra_flags
     L = _lib.lib()
     pp = _dev_f32(flat, "params", (spec.param_count,))
-    nbytes, _ = workspace_layout(spec, B, T)
-    if ws.numel() * 4 < nbytes:
-        raise NsdError(f"workspace too small: {ws.numel() * 4} < {nbytes} bytes")
-    _call("nsd_lstm_fwd", C.byref(d), pp, _dev_f32(x, "x", (B, T, spec.C)),
-                         _dev_f32(drop_lstm, "drop_lstm", (spec.L - 1, B, T, spec.H)), flags,
-                         _dev_f32(ws, "workspace"), _stream())
+    _call("nsd_lstm_fwd", x.device, C.byref(d), pp, _dev_f32(x, "x", (B, T, spec.C)),
+          _dev_f32(drop_lstm, "drop_lstm", (spec.L - 1, B, T, spec.H)), flags, _dev_f32(ws, "workspace"), _nbytes(ws), STREAM)
     logits = torch.empty((B, spec.K), dtype=torch.float32, device=x.device)
     probs = torch.empty_like(logits) if want_probs else None
-    _call("nsd_head_fwd", C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope", (B, spec.F)),
-                         _dev_f32(drop_head, "drop_head", (B, spec.F)), ws.data_ptr(), logits.data_ptr(),
-                         _dev_f32(probs, "probs"), _stream())
+    _call("nsd_head_fwd", x.device, C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope", (B, spec.F)),
+          _dev_f32(drop_head, "drop_head", (B, spec.F)), ws.data_ptr(), _nbytes(ws), logits.data_ptr(),
+          _dev_f32(probs, "probs"), STREAM)
     return logits, probs
 
 
@@ -217,16 +229,15 @@ def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: tor
         lab_ptr = None
     scale = (1.0 / max(B, 1)) if scale is None else float(scale)
     flags = _lib.NSD_FLAG_TRAIN | (_lib.NSD_FLAG_RESIDUAL if residual else 0) | _extra_flags
-    _call("nsd_head_bwd", C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head"),
-                         _dev_f32(logits, "logits", (B, spec.K)), _dev_f32(dlogits, "dlogits", (B, spec.K)),
-                         lab_ptr, scale, ws.data_ptr(), _stream())
-    _call("nsd_lstm_bwd", C.byref(d), pp, _dev_f32(x, "x"), _dev_f32(drop_lstm, "drop_lstm"), flags,
-                         ws.data_ptr(), None, _stream())
+    wsp, wsn = _dev_f32(ws, "workspace"), _nbytes(ws)
+    _call("nsd_head_bwd", x.device, C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head"),
+          _dev_f32(logits, "logits", (B, spec.K)), _dev_f32(dlogits, "dlogits", (B, spec.K)), lab_ptr, scale, wsp, wsn, STREAM)
+    _call("nsd_lstm_bwd", x.device, C.byref(d), pp, _dev_f32(x, "x"), _dev_f32(drop_lstm, "drop_lstm"), flags, wsp, wsn, None, STREAM)
     if grads is None:
         grads = torch.empty(spec.param_count, dtype=torch.float32, device=x.device)
         accumulate = False
-    _call("nsd_grad_reduce", C.byref(d), ws.data_ptr(), _dev_f32(grads, "grads", (spec.param_count,)),
-                            1 if accumulate else 0, _stream())
+    _call("nsd_grad_reduce", x.device, C.byref(d), wsp, wsn, _dev_f32(grads, "grads", (spec.param_count,)),
+          1 if accumulate else 0, STREAM)
     return grads
 
 
@@ -250,7 +261,7 @@ def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: t
     if labels.dtype != torch.int32 or not labels.is_cuda or not labels.is_contiguous():
         raise NsdError("labels must be a contiguous int32 tensor on the device")
     scale = (1.0 / max(B, 1)) if scale is None else float(scale)
-    xp, wsp, st = _dev_f32(x, "x", (B, T, spec.C)), _dev_f32(ws, "workspace"), _stream()
+    xp, wsp, wsn, st, dev = _dev_f32(x, "x", (B, T, spec.C)), _dev_f32(ws, "workspace"), _nbytes(ws), STREAM, x.device
     dl, sl, dh = _dev_f32(drop_lstm, "drop_lstm"), _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head")
     lp = _dev_f32(logits, "logits", (B, spec.K))
     if rng is not None:
@@ -258,20 +269,20 @@ def train_step_grads(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: t
         if drop_lstm is not None or rrelu_slope is not None or drop_head is not None:
             raise NsdError("train_step_grads: pass either rng= or explicit mask tensors, not both")
         r = _lib.Rng(int(rng["seed"]) & 0xFFFFFFFFFFFFFFFF, int(rng["base_stream"]) & 0xFFFFFFFF, float(rng["p_lstm"]), float(rng["p_head"]))
-        _call("nsd_lstm_head_train_rng", C.byref(d), pp, xp, C.byref(r), labels.data_ptr(), scale, flags, wsp, lp, st)
-        _call("nsd_lstm_bwd_rng", C.byref(d), pp, xp, C.byref(r), flags, wsp, st)
+        _call("nsd_lstm_head_train_rng", dev, C.byref(d), pp, xp, C.byref(r), labels.data_ptr(), scale, flags, wsp, wsn, lp, st)
+        _call("nsd_lstm_bwd_rng", dev, C.byref(d), pp, xp, C.byref(r), flags, wsp, wsn, st)
     else:
         if fused_head:
-            _call("nsd_lstm_head_train", C.byref(d), pp, xp, dl, sl, dh, labels.data_ptr(), scale, flags, wsp, lp, st)
+            _call("nsd_lstm_head_train", dev, C.byref(d), pp, xp, dl, sl, dh, labels.data_ptr(), scale, flags, wsp, wsn, lp, st)
         else:
-            _call("nsd_lstm_fwd", C.byref(d), pp, xp, dl, flags, wsp, st)
-            _call("nsd_head_train", C.byref(d), pp, sl, dh, labels.data_ptr(), scale, wsp, lp, st)
-        _call("nsd_lstm_bwd", C.byref(d), pp, xp, dl, flags, wsp, None, st)
+            _call("nsd_lstm_fwd", dev, C.byref(d), pp, xp, dl, flags, wsp, wsn, st)
+            _call("nsd_head_train", dev, C.byref(d), pp, sl, dh, labels.data_ptr(), scale, wsp, wsn, lp, st)
+        _call("nsd_lstm_bwd", dev, C.byref(d), pp, xp, dl, flags, wsp, wsn, None, st)
     gp = _dev_f32(grads, "grads", (spec.param_count,))
     if adam is None:
-        _call("nsd_grad_reduce", C.byref(d), wsp, gp, 0, st)
+        _call("nsd_grad_reduce", dev, C.byref(d), wsp, wsn, gp, 0, st)
     else:
-        _call("nsd_grad_reduce_adam", C.byref(d), wsp, gp, pp, _dev_f32(adam["m"], "m", flat.shape), _dev_f32(adam["v"], "v", flat.shape),
+        _call("nsd_grad_reduce_adam", dev, C.byref(d), wsp, wsn, gp, pp, _dev_f32(adam["m"], "m", flat.shape), _dev_f32(adam["v"], "v", flat.shape),
               adam.get("lr", 1e-3), adam.get("beta1", 0.9), adam.get("beta2", 0.999), adam.get("eps", 1e-8),
               adam.get("weight_decay", 0.0), 1.0, int(adam["step"]), st)
 
@@ -286,7 +297,7 @@ def loss_sum(spec: ModelSpec, ws: torch.Tensor, B: int, T: int, out: Optional[to
     """Sum of the per-trial CE losses written by the labels form of train_backward (device scalar)."""
     d = spec.dims(B, T)
     out = torch.empty(1, dtype=torch.float32, device=ws.device) if out is None else out
-    _call("nsd_loss_sum", C.byref(d), ws.data_ptr(), out.data_ptr(), _stream())
+    _call("nsd_loss_sum", ws.device, C.byref(d), _dev_f32(ws, "workspace"), _nbytes(ws), out.data_ptr(), STREAM)
     return out
 
 
@@ -294,20 +305,17 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0,
               grad_scale: float = 1.0) -> None:
     n = p.numel()
-    _call("nsd_adam_step", n, _dev_f32(p, "p"), _dev_f32(g, "g", p.shape), _dev_f32(m, "m", p.shape),
-                                   _dev_f32(v, "v", p.shape), lr, beta1, beta2, eps, weight_decay, grad_scale,
-                                   step, _stream())
+    _call("nsd_adam_step", p.device, n, _dev_f32(p, "p"), _dev_f32(g, "g", p.shape), _dev_f32(m, "m", p.shape),
+          _dev_f32(v, "v", p.shape), lr, beta1, beta2, eps, weight_decay, grad_scale, step, STREAM)
 
 
 def dropout_mask(seed: int, stream_id: int, p: float, shape, device) -> torch.Tensor:
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    _call("nsd_dropout_mask", seed & 0xFFFFFFFFFFFFFFFF, stream_id, p, out.numel(), _dev_f32(out, "out"),
-                                      _stream())
+    _call("nsd_dropout_mask", out.device, seed & 0xFFFFFFFFFFFFFFFF, stream_id, p, out.numel(), _dev_f32(out, "out"), STREAM)
     return out
 
 
 def rrelu_noise(seed: int, stream_id: int, shape, device) -> torch.Tensor:
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    _call("nsd_rrelu_noise", seed & 0xFFFFFFFFFFFFFFFF, stream_id, out.numel(), _dev_f32(out, "out"),
-                                     _stream())
+    _call("nsd_rrelu_noise", out.device, seed & 0xFFFFFFFFFFFFFFFF, stream_id, out.numel(), _dev_f32(out, "out"), STREAM)
     return out

@@ -37,7 +37,9 @@ def evaluate(model: EEG_LSTM, x: torch.Tensor, y: torch.Tensor, batch: int = 512
 
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--data", help="directory with <prefix>_*.csv trials (reference: EEG_data_collection/)")
+    ap.add_argument("--data", help="directory with <prefix>_*.csv trials (reference: EEG_data_collection/), or a packed .npz "
+                                   "of them (data.load_trials_npz)")
+    ap.add_argument("--log-jsonl", default=None, help="also append the per-epoch JSON lines to this file (rank 0)")
     ap.add_argument("--synthetic", type=int, default=0, help="use N synthetic windows x = 2.7*N(0,1) instead of --data")
     ap.add_argument("--classes", type=int, default=3, choices=(3, 5))
     ap.add_argument("--label-order", default="checkpoint", choices=("checkpoint", "code"))
@@ -73,26 +75,36 @@ def main(argv=None) -> int:
         if not args.data:
             ap.error("give --data or --synthetic")
         lm = D.LABELS_5CLASS if args.classes == 5 else (D.LABELS_3CLASS_CHECKPOINT if args.label_order == "checkpoint" else D.LABELS_3CLASS_CODE)
-        ts = D.load_trials(args.data, lm, samples=args.T)
+        ts = D.load_trials_npz(args.data, lm) if args.data.endswith(".npz") else D.load_trials(args.data, lm, samples=args.T)
+        if ts.x.shape[1] != args.T:
+            ap.error(f"--T {args.T} but the trials have {ts.x.shape[1]} samples")
         x_np, y_np = ts.x, ts.y
         tr_idx, va_idx = D.stratified_split(y_np, args.val_fraction, args.seed)
     x_all = torch.from_numpy(x_np).to(dev)
     y_all = torch.from_numpy(y_np).to(dev)
 
-    torch.manual_seed(args.seed)          # same initial weights on every rank
+    torch.manual_seed(args.seed)          # (Trainer also broadcasts rank 0's parameters when world > 1)
     model = EEG_LSTM(8, args.hidden, 2, args.classes, args.dropout, normalize=args.normalize).to(dev).train()
     trainer = Trainer(model, lr=args.lr, weight_decay=args.weight_decay, seed=args.seed + 1)
     tr_dev = torch.from_numpy(tr_idx).to(dev)
+
+    def emit(rec: dict) -> None:
+        line = json.dumps(rec)
+        print(line, flush=True)
+        if args.log_jsonl:
+            with open(args.log_jsonl, "a") as f:
+                f.write(line + "\n")
+
     best = (-1.0, -1)
     t0 = time.time()
     for epoch in range(args.epochs):
         n_seen, loss_sum = 0, 0.0
         for idx in D.epoch_batches(len(tr_idx), args.batch, args.seed, epoch, drop_last=len(tr_idx) >= args.batch):
+            # every rank takes part in every step (the step ends in a collective): a rank whose shard of a short tail
+            # batch is empty passes zero trials and contributes a zero gradient; the mean is over the GLOBAL batch
             lo, hi = shard_range(len(idx), rank, world)
-            if hi <= lo:
-                continue
             sel = tr_dev[torch.from_numpy(idx[lo:hi]).to(dev)]
-            trainer.step(x_all[sel].contiguous(), y_all[sel].contiguous())
+            trainer.step(x_all[sel].contiguous(), y_all[sel].contiguous(), global_batch=len(idx))
             n_seen += hi - lo
         if rank == 0 and (epoch % args.log_every == 0 or epoch == args.epochs - 1):
             acc_tr = evaluate(model, x_all[tr_dev], y_all[tr_dev])
@@ -100,13 +112,13 @@ def main(argv=None) -> int:
             if acc_va > best[0]:
                 best = (acc_va, epoch)
                 save_reference_checkpoint(model, args.out)
-            print(json.dumps({"epoch": epoch, "loss_last_batch": round(trainer.last_loss(), 5), "acc_train": round(acc_tr, 4),
-                              "acc_val": round(acc_va, 4), "elapsed_s": round(time.time() - t0, 2)}), flush=True)
+            emit({"epoch": epoch, "loss_last_batch": round(trainer.last_loss(), 5), "acc_train": round(acc_tr, 4),
+                  "acc_val": round(acc_va, 4), "elapsed_s": round(time.time() - t0, 2)})
     if rank == 0:
         if best[1] < 0:
             save_reference_checkpoint(model, args.out)
-        print(json.dumps({"done": True, "best_val_acc": best[0], "best_epoch": best[1], "checkpoint": args.out,
-                          "world": world}), flush=True)
+        emit({"done": True, "best_val_acc": best[0], "best_epoch": best[1], "checkpoint": args.out, "world": world,
+              "n_train": int(len(tr_idx)), "n_val": int(len(va_idx)), "args": {k: v for k, v in vars(args).items()}})
     return 0
 
 

@@ -5,12 +5,18 @@ The reference's training notebook (DeepLearning/lstm_trainer.ipynb) is not part 
     zero_grad -> CE(model(x), y) -> backward -> Adam(lr=1e-3)
 with the reference model's train-mode stochastic parts (inter-layer dropout p, RReLU noise, head dropout p).
 
-Per step and per GPU the stream sees: 3 mask kernels, lstm fwd, head fwd, head bwd (CE fused), lstm bwd,
-slab reduce, [one all-reduce of the flat fp32 gradient over RCCL], Adam.  Nothing synchronises the host.
+Per step and per GPU the stream sees, for the reference model's shape, three launches: LSTM forward + attention
+pooling + head + CE + head backward (nsd_lstm_head_train_rng, the dropout / RReLU streams drawn in the kernel), BPTT
+(nsd_lstm_bwd_rng), slab reduction + Adam (nsd_grad_reduce_adam); with more than one rank the last becomes
+nsd_grad_reduce -> ONE all-reduce of the flat fp32 gradient over RCCL -> nsd_adam_step.  Other shapes run the unfused
+equivalents (ops.train_step_grads).  Nothing synchronises the host.
 
-Data parallelism: trials are independent, so the global batch is split contiguously over
-ranks; every rank scales its CE gradient by 1/B_global, the flat gradient vector (31 764 floats = 127 KB
-for the reference model) is summed with ONE all-reduce, and every rank applies the same Adam update.
+Data parallelism: trials are independent, so the global batch is split contiguously over ranks
+(shard_range; shards may differ by one trial and may be EMPTY); every rank scales its CE gradient by 1/B_global, the flat
+gradient vector (31 764 floats = 127 KB for the reference model) is summed with ONE all-reduce, and every rank applies
+the same Adam update.  Every rank enters the collective in every step -- a rank without trials contributes a zero
+gradient -- and the parameters are broadcast from rank 0 once at construction, so identical replicas do not rest on
+identical seeding.
 """
 from __future__ import annotations
 
@@ -46,6 +52,44 @@ class FlatGradAllReducer:
         return flat_grad
 
 
+def _on_own_device(method):
+    """Run a Trainer method with the trainer's GPU as the current device (the C ABI enqueues on the current device)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *a, **kw):
+        with torch.cuda.device(self.flat.device):
+            return method(self, *a, **kw)
+    return wrapped
+
+
+class DataParallelStep:
+    """The rank-level control flow of one optimisation step, separated from how the numbers are produced so that the
+    CPU tests (gloo, world_size 2 and 3, uneven and empty shards) drive exactly this code with an injected gradient
+    function.  `local_grads(x, y, scale)` must leave this rank's share of the gradient of sum_b CE_b * scale in the
+    flat buffer `grads`; `zero_grads()` clears it; `apply_update()` consumes it."""
+
+    def __init__(self, grads: torch.Tensor, reducer: FlatGradAllReducer, local_grads, zero_grads, apply_update):
+        self.grads, self.reducer = grads, reducer
+        self.local_grads, self.zero_grads, self.apply_update = local_grads, zero_grads, apply_update
+
+    def __call__(self, x, y, global_batch: int) -> None:
+        if global_batch < 1:
+            raise ValueError("global_batch must be >= 1 (the number of trials of the step over all ranks)")
+        if int(x.shape[0]) > 0:
+            self.local_grads(x, y, 1.0 / float(global_batch))
+        else:
+            self.zero_grads()              # empty shard: still take part in the collective, with a zero gradient
+        self.reducer(self.grads)           # EVERY rank, EVERY step
+        self.apply_update()
+
+
+def broadcast_parameters(flat: torch.Tensor, group=None, src: int = 0) -> None:
+    """Make every replica start from rank `src`'s parameters (one collective on the flat vector)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+
+
 class Trainer:
     def __init__(self, model: EEG_LSTM, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, seed: int = 1234, stochastic: bool = True, group=None):
@@ -61,6 +105,7 @@ class Trainer:
         self.reducer = FlatGradAllReducer(group)
         self.rank = dist.get_rank(group) if self.reducer.world > 1 else 0
         self.world = self.reducer.world
+        broadcast_parameters(self.flat, group)     # identical replicas by construction, not by seeding
         self.fused_head = True           # nsd_lstm_head_train (one launch) where the shape allows; False: two launches
         self.in_kernel_rng = True        # dropout / RReLU streams generated inside the kernels where the shape allows
         self.seed = (int(seed) + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF
@@ -89,15 +134,40 @@ class Trainer:
             self._bufs = {key: buf}      # keep only the current shape (workspaces are large)
         return self._bufs[key]
 
-    def step(self, x: torch.Tensor, y: torch.Tensor) -> None:
-        """One optimisation step on this rank's shard: x [B,T,C] fp32, y [B] int32 (device tensors)."""
+    @_on_own_device
+    def step(self, x: torch.Tensor, y: torch.Tensor, global_batch: Optional[int] = None) -> None:
+        """One optimisation step on this rank's shard: x [B,T,C] fp32, y [B] int32 (device tensors).  `global_batch`: trials
+        of this step over ALL ranks (default B * world, i.e. equal shards); the CE gradient is scaled by 1/global_batch so
+        that the all-reduced sum is the global mean whatever the shard sizes.  B may be 0 when world > 1."""
+        B = int(x.shape[0])
+        if global_batch is None:
+            global_batch = B * self.world
+        self.step_count += 1
+        if self.world == 1:
+            if B == 0:
+                raise ops.NsdError("Trainer.step: empty batch")
+            # no exchange step between reduction and update: one launch does both
+            self._local_grads(x, y, 1.0 / float(global_batch), fuse_adam=True)
+        else:
+            DataParallelStep(self.grads, self.reducer, self._local_grads, self.grads.zero_, self._adam)(x, y, global_batch)
+        if B > 0:
+            self._last_B, self._last_T = B, int(x.shape[1])
+
+    def _hyper(self) -> dict:
+        return dict(step=self.step_count, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                    weight_decay=self.weight_decay)
+
+    def _adam(self) -> None:
+        ops.adam_step(self.flat, self.grads, self.m, self.v, **self._hyper())
+
+    def _local_grads(self, x: torch.Tensor, y: torch.Tensor, scale: float, fuse_adam: bool = False) -> None:
+        """Launches that leave this shard's gradient (scaled) in self.grads; fuse_adam: the update rides in the last one."""
         from . import _lib
         sp = self.spec
         B, T, _ = x.shape
         buf = self._buffers(B, T)
         L = _lib.lib()
         st = torch.cuda.current_stream().cuda_stream
-        self.step_count += 1
         sid = (self.step_count & 0x3FFFFFFF) * 4
         dl = buf.get("drop_lstm"); sl = buf.get("rrelu"); dh = buf.get("drop_head")
         rng = None
@@ -117,21 +187,9 @@ class Trainer:
                 _lib.check(L.nsd_rrelu_noise(self.seed, sid + 1, sl.numel(), sl.data_ptr(), st), "rrelu_noise")
             if dh is not None:
                 _lib.check(L.nsd_dropout_mask(self.seed, sid + 2, self.model.head_dropout_p, dh.numel(), dh.data_ptr(), st), "dropout_mask")
-        ws = buf["ws"]
-        scale = 1.0 / (B * self.world)
-        hyper = dict(step=self.step_count, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
-                     weight_decay=self.weight_decay)
-        if self.world == 1:
-            # no exchange step between reduction and update: one launch does both
-            ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
-                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual, fused_head=self.fused_head, rng=rng,
-                                 adam=dict(m=self.m, v=self.v, **hyper))
-        else:
-            ops.train_step_grads(sp, self.flat, x, ws, y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
-                                 rrelu_slope=sl, drop_head=dh, residual=self.model.residual, fused_head=self.fused_head, rng=rng)
-            self.reducer(self.grads)
-            ops.adam_step(self.flat, self.grads, self.m, self.v, **hyper)
-        self._last_B, self._last_T = B, T
+        ops.train_step_grads(sp, self.flat, x, buf["ws"], y, buf["logits"], self.grads, scale=scale, drop_lstm=dl,
+                             rrelu_slope=sl, drop_head=dh, residual=self.model.residual, fused_head=self.fused_head, rng=rng,
+                             adam=dict(m=self.m, v=self.v, **self._hyper()) if fuse_adam else None)
 
     # ---- hipGraph path ------------------------------------------------------------------------------------
     def static_inputs(self, B: int, T: int):
@@ -168,6 +226,7 @@ class Trainer:
                                                 self.v.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
                                                 self.weight_decay, 1.0, self._step_dev.data_ptr(), st), "adam_step_dev")
 
+    @_on_own_device
     def step_static(self, B: int, T: int) -> None:
         """One optimisation step on the trainer's static input buffers, replayed from captured hipGraphs.
         world == 1: one graph.  world > 1: graph A, the eager RCCL all-reduce of the flat gradient, graph B (Adam)."""
@@ -205,6 +264,7 @@ class Trainer:
             gb.replay()
         self._last_B, self._last_T = B, T
 
+    @_on_own_device
     def last_loss(self) -> float:
         """Mean CE loss of this rank's shard in the most recent step (synchronises)."""
         if not self._last_B:

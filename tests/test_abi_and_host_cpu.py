@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in nsd.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert L.nsd_version() == 100
+    assert L.nsd_version() == 200
+    assert not hasattr(L, "nsd_debug_profile_buffer")           # diagnostics are not in the shipped library
 
 
 @pytest.mark.parametrize("dims", [orc.Dims(), orc.Dims(H=256, K=5), orc.Dims(C=64, H=512, L=3, K=5), orc.Dims(L=1)])
@@ -69,6 +70,26 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert L.nsd_workspace_bytes(C.byref(bad), None) < 0
     assert L.nsd_adam_step(-1, None, None, None, None, 0, 0, 0, 0, 0, 1, 1, None) == -1
     assert L.nsd_param_count(8, 48, 9, 3, 32) < 0                  # more than NSD_MAX_LAYERS
+    # a short workspace is refused before anything is launched (NSD_E_WORKSPACE), for every entry point that touches it
+    need = L.nsd_workspace_bytes(C.byref(d), None)
+    fake = 4096                                                    # never dereferenced: the size check comes first
+    E_WS = -3
+    assert L.nsd_lstm_fwd(C.byref(d), fake, fake, None, 2, fake, need - 4, None) == E_WS
+    assert b"smaller than nsd_workspace_bytes" in L.nsd_last_error()
+    assert L.nsd_head_fwd(C.byref(d), fake, None, None, fake, need - 4, fake, None, None) == E_WS
+    assert L.nsd_head_bwd(C.byref(d), fake, None, None, fake, fake, None, 1.0, fake, 0, None) == E_WS
+    assert L.nsd_head_train(C.byref(d), fake, None, None, fake, 1.0, fake, need - 4, fake, None) == E_WS
+    assert L.nsd_lstm_head_train(C.byref(d), fake, fake, None, None, None, fake, 1.0, 2, fake, need - 4, fake, None) == E_WS
+    assert L.nsd_lstm_bwd(C.byref(d), fake, fake, None, 2, fake, need - 4, None, None) == E_WS
+    assert L.nsd_grad_reduce(C.byref(d), fake, need - 4, fake, 0, None) == E_WS
+    assert L.nsd_grad_reduce_adam(C.byref(d), fake, need - 4, fake, fake, fake, fake, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1, None) == E_WS
+    assert L.nsd_loss_sum(C.byref(d), fake, need - 4, fake, None) == E_WS
+    rng = _lib.Rng(1, 4, 0.6, 0.6)
+    assert L.nsd_lstm_head_train_rng(C.byref(d), fake, fake, C.byref(rng), fake, 1.0, 2, fake, need - 4, fake, None) == E_WS
+    assert L.nsd_lstm_bwd_rng(C.byref(d), fake, fake, C.byref(rng), 2, fake, need - 4, None) == E_WS
+    # dx is reserved: header and implementation agree that it must be NULL
+    assert L.nsd_lstm_bwd(C.byref(d), fake, fake, None, 2, fake, need, fake, None) == -1
+    assert b"must be NULL" in L.nsd_last_error()
 
 
 def test_facade_surface_matches_reference(ref_state):
@@ -109,7 +130,7 @@ def test_no_cpu_fallback():
         ops.zscore(torch.zeros(2, 10, 8))
     if not torch.cuda.is_available():
         with pytest.raises(nsd_amd.NsdError, match="MI355X"):
-            nsd_amd.SimplePredictor("missing.pth", sr=125)
+            nsd_amd.SimplePredictor("missing.pth", sr=125, preprocess="identity")
 
 
 def test_product_never_imports_the_oracle():
@@ -165,3 +186,72 @@ def test_synthetic_producer_and_dead_producer():
     with pytest.raises(RuntimeError, match="Producer exited unexpectedly"):
         nsd_amd.run_trials(trials=1, serial_port="/dev/cu.usbserial-FTB6SPL3", model_path="unused", verbose=False,
                            queue_timeout=0.5)
+
+
+# ---- which preprocessor does the drop-in resolve?  (reference lstm_eeg_model.py:7-10,66,91; Frontend/app.py:22-28) --------
+REFERENCE_APP = "/root/reference/Neuro-Alpha-App"
+_RESOLVE_SNIPPET = r"""
+import sys
+sys.dont_write_bytecode = True                      # the reference tree is read-only
+sys.path[:0] = [{repo!r}] + {extra!r}
+import nsd_amd
+from nsd_amd import lstm_eeg_model as M
+cls = M.resolve_reference_preprocessor({package!r})
+print("RESOLVED", None if cls is None else cls.__module__ + "." + cls.__qualname__)
+if cls is not None:
+    import numpy as np
+    pre = M._default_preprocessor(125, 1.25e-29, {package!r})
+    assert type(pre) is cls and pre.sr == 125 and pre.tailoring_lambda == 1.25e-29
+    try:
+        pre.transform(np.zeros((2, 3, 4), np.float32))
+    except ValueError:
+        print("VALUEERROR ok")
+"""
+
+
+def _resolve_in_subprocess(extra_path, package=None):
+    import subprocess, sys
+    code = _RESOLVE_SNIPPET.format(repo=ROOT, extra=list(extra_path), package=package)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_APP), reason="reference tree not present (GPU box)")
+def test_default_preprocessor_is_the_references_in_both_import_modes():
+    # package mode: what the Streamlit app does (Neuro-Alpha-App/ on sys.path, `Utilities.*` imports)
+    out = _resolve_in_subprocess([REFERENCE_APP])
+    assert "RESOLVED Utilities.preprocessor.PreProcessor" in out and "VALUEERROR ok" in out
+    # script mode: Utilities/ itself on sys.path (`python tester.py`)
+    out = _resolve_in_subprocess([os.path.join(REFERENCE_APP, "Utilities")])
+    assert "RESOLVED preprocessor.PreProcessor" in out and "VALUEERROR ok" in out
+    # a stub that names its own package gets that package's module first
+    out = _resolve_in_subprocess([REFERENCE_APP], package="Utilities")
+    assert "RESOLVED Utilities.preprocessor.PreProcessor" in out
+
+
+def test_missing_reference_preprocessor_is_an_error_not_an_identity():
+    out = _resolve_in_subprocess([])
+    assert "RESOLVED None" in out
+    from nsd_amd import lstm_eeg_model as M
+    if M.resolve_reference_preprocessor() is None:
+        with pytest.raises(nsd_amd.NsdError, match="identity"):
+            M._default_preprocessor(125, 1.25e-29)
+    pre = nsd_amd.IdentityPreProcessor(125)
+    x = np.arange(12, dtype=np.float64).reshape(4, 3)
+    y = pre.transform(x)
+    assert y.dtype == np.float32 and np.array_equal(y, x.astype(np.float32))
+    with pytest.raises(ValueError):
+        pre.transform(np.zeros((2, 3, 4)))
+
+
+def test_default_model_path_is_checked_before_use(tmp_path, monkeypatch):
+    from nsd_amd import tester
+    monkeypatch.delenv("NSD_MODEL_PATH", raising=False)
+    with pytest.raises(FileNotFoundError, match="does not exist"):
+        tester.resolve_model_path(str(tmp_path / "nope.pth"))
+    p = tmp_path / "m.pth"
+    p.write_bytes(b"x")
+    monkeypatch.setenv("NSD_MODEL_PATH", str(p))
+    assert tester.resolve_model_path(tester.DEFAULT_MODEL) == str(p)      # the default can be redirected
+    assert tester.resolve_model_path(str(p)) == str(p)

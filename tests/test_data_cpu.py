@@ -60,3 +60,24 @@ def test_reference_dataset_counts():
     assert counts == {"backgroundnoise": 40, "food": 69, "no": 71, "water": 70, "yes": 74}     # SURVEY 2 (#9)
     assert ts.x.shape == (324, 625, 8) and np.isfinite(ts.x).all()
     assert abs(float(ts.x.std()) - 2.73) < 0.05
+
+
+FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "recorded_trials.npz")
+
+
+def test_packed_fixture_is_the_recorded_data_set():
+    """tests/golden/recorded_trials.npz (the form in which the trials reach the GPU box) == what load_trials parses
+    from the reference's CSV directory, for the 3-class and the 5-class label maps."""
+    five = D.load_trials_npz(FIXTURE, D.LABELS_5CLASS)
+    assert five.x.shape == (324, 625, 8) and five.x.dtype == np.float32 and five.num_classes == 5
+    assert {p: five.prefix.count(p) for p in D.PREFIXES} == {"backgroundnoise": 40, "food": 69, "no": 71, "water": 70, "yes": 74}
+    three = D.load_trials_npz(FIXTURE)
+    assert len(three) == 179 and sorted(set(three.prefix)) == ["backgroundnoise", "food", "water"]
+    assert [int((three.y == c).sum()) for c in range(3)] == [70, 69, 40]               # water, food, backgroundnoise
+    with pytest.raises(FileNotFoundError):
+        D.load_trials_npz(FIXTURE, {"nothing": 0})
+    if os.path.isdir(REF_DATA):
+        for lm, packed in ((None, three), (D.LABELS_5CLASS, five)):
+            ts = D.load_trials(REF_DATA, lm)
+            assert np.array_equal(ts.x, packed.x) and np.array_equal(ts.y, packed.y)
+            assert [os.path.basename(f) for f in ts.files] == packed.files

@@ -80,3 +80,75 @@ def test_reducer_is_identity_without_a_process_group():
     g = torch.arange(8, dtype=torch.float32)
     r = FlatGradAllReducer()
     assert r.world == 1 and torch.equal(r(g.clone()), g)
+
+
+# ---- the rank-level control flow of a step (trainer.DataParallelStep), world 2 and 3, uneven and EMPTY shards -------------
+def _dp_worker(rank, world, port, golden_dir, out_dir, batches):
+    from nsd_amd.trainer import DataParallelStep, broadcast_parameters
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = np.load(os.path.join(golden_dir, "weights_3class.npz"))
+        flat0 = orc.flatten_state({k: w[k] for k in w.files}, D)
+        # replicas start DIFFERENT on purpose: the broadcast from rank 0 must make them identical
+        flat = torch.from_numpy((flat0 + (0.01 * rank)).astype(np.float32))
+        broadcast_parameters(flat)
+        assert np.array_equal(flat.numpy(), flat0)
+        grads = torch.zeros_like(flat)
+        m, v = np.zeros_like(flat0), np.zeros_like(flat0)
+        calls = {"grads": 0, "zero": 0, "update": 0, "step": 0}
+
+        def local_grads(x, y, scale):                      # injected: the oracle stands in for the HIP kernels
+            calls["grads"] += 1
+            _, g, _ = orc.loss_and_grads(flat.numpy().copy(), x, y, D, scale=scale)
+            grads.copy_(torch.from_numpy(g))
+
+        def zero():
+            calls["zero"] += 1
+            grads.zero_()
+
+        def update():
+            calls["update"] += 1
+            p = flat.numpy()
+            orc.adam(p, grads.numpy(), m, v, lr=1e-3, step=calls["step"])
+
+        step = DataParallelStep(grads, FlatGradAllReducer(), local_grads, zero, update)
+        T = 12
+        for k, B in enumerate(batches):
+            calls["step"] = k + 1
+            x, y = synth_x(B, T, seed=20 + k), synth_labels(B, seed=20 + k)
+            lo, hi = shard_range(B, rank, world)
+            step(x[lo:hi], y[lo:hi], global_batch=B)      # hi == lo on some ranks: must not deadlock
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), p=flat.numpy(), g=grads.numpy(),
+                 calls=np.array([calls["grads"], calls["zero"], calls["update"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,batches", [(2, (7, 1, 4)), (3, (8, 2, 1, 6))])
+def test_data_parallel_step_uneven_and_empty_shards(tmp_path, world, batches):
+    """Every rank enters the all-reduce every step (an empty shard contributes zeros), the mean is over the GLOBAL batch,
+    replicas are made identical by a broadcast: N ranks == one rank on the full batches, step after step."""
+    golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    mp.spawn(_dp_worker, args=(world, _free_port(), golden_dir, str(tmp_path), batches), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in res[1:]:
+        assert np.array_equal(r["p"], res[0]["p"]) and np.array_equal(r["g"], res[0]["g"])
+    n_empty = sum(1 for B in batches for r in range(world) if shard_range(B, r, world)[1] == shard_range(B, r, world)[0])
+    assert n_empty > 0                                                       # the case the old CLI deadlocked on
+    assert sum(int(r["calls"][1]) for r in res) == n_empty
+    assert all(int(r["calls"][2]) == len(batches) for r in res)              # every rank applied every update
+    # single-rank reference: same batches, mean CE over each full batch, same Adam
+    w = np.load(os.path.join(golden_dir, "weights_3class.npz"))
+    p = orc.flatten_state({k: w[k] for k in w.files}, D)
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for k, B in enumerate(batches):
+        x, y = synth_x(B, 12, seed=20 + k), synth_labels(B, seed=20 + k)
+        _, g, _ = orc.loss_and_grads(p.copy(), x, y, D)
+        orc.adam(p, g, m, v, lr=1e-3, step=k + 1)
+    assert np.abs(res[0]["g"] - g).max() <= 1e-5 * np.abs(g).max()
+    # Adam divides by sqrt(v): where a gradient element is ~0 its update is +-lr whatever its size, so a summation-order
+    # difference can move such an element by up to 2*lr per step; everywhere else the trajectories coincide
+    dp = np.abs(res[0]["p"] - p)
+    assert dp.max() <= 2 * 1e-3 * len(batches) and (dp > 2e-5).mean() < 0.01

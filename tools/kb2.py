@@ -26,6 +26,6 @@ for B, T in [(256, 250), (256, 125), (128, 250), (512, 250), (1024, 250), (1, 62
     logits = torch.empty(B, 3, device=dev); probs = torch.empty(B, 3, device=dev)
     scratch = torch.empty(B*T*48+16, device=dev)
     t_inf = timed(lambda: L.nsd_infer(C.byref(d), flat.data_ptr(), x.data_ptr(), 0, logits.data_ptr(), probs.data_ptr(), scratch.data_ptr(), st))
-    t_fwd = timed(lambda: L.nsd_lstm_fwd(C.byref(d), flat.data_ptr(), x.data_ptr(), None, 2, ws.data_ptr(), st))
-    t_hd = timed(lambda: L.nsd_head_fwd(C.byref(d), flat.data_ptr(), None, None, ws.data_ptr(), logits.data_ptr(), probs.data_ptr(), st))
+    t_fwd = timed(lambda: L.nsd_lstm_fwd(C.byref(d), flat.data_ptr(), x.data_ptr(), None, 2, ws.data_ptr(), ws.numel() * 4, st))
+    t_hd = timed(lambda: L.nsd_head_fwd(C.byref(d), flat.data_ptr(), None, None, ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), st))
     print(f"B={B:5d} T={T:4d}: infer(lstm+head) {t_inf:8.1f} us   train lstm_fwd(no mask) {t_fwd:8.1f} us   head_fwd {t_hd:6.1f} us", flush=True)

@@ -58,19 +58,19 @@ def main():
     d = spec.dims(B, T)
     st = torch.cuda.current_stream().cuda_stream
     flags = _lib.NSD_FLAG_TRAIN
-    pp, xp, wsp = flat.data_ptr(), x.data_ptr(), ws.data_ptr()
+    pp, xp, wsp, wsn = flat.data_ptr(), x.data_ptr(), ws.data_ptr(), ws.numel() * 4
     dlp = dl.data_ptr() if dl is not None else None
     for ab in [int(v) for v in args.ablate.split(",")]:
         os.environ["NSD_ABLATE"] = str(ab)
         logits, _ = ops.train_forward(spec, flat, x, ws, drop_lstm=dl)
         ops.train_backward(spec, flat, x, ws, logits, labels=y, drop_lstm=dl)
-        f_med, f_min = timed(lambda: L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, st), args.iters)
-        b_med, b_min = timed(lambda: L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st), args.iters)
+        f_med, f_min = timed(lambda: L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, wsn, st), args.iters)
+        b_med, b_min = timed(lambda: L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, wsn, None, st), args.iters)
         sl = ops.rrelu_noise(1, 1, (B, 32), dev); dh = ops.dropout_mask(1, 2, 0.6, (B, 32), dev)
         lg = torch.empty(B, 3, device=dev)
         if hasattr(L, "nsd_lstm_head_train"):
             h_med, h_min = timed(lambda: L.nsd_lstm_head_train(C.byref(d), pp, xp, dlp, sl.data_ptr(), dh.data_ptr(), y.data_ptr(),
-                                                               1.0 / B, flags, wsp, lg.data_ptr(), st), args.iters)
+                                                               1.0 / B, flags, wsp, wsn, lg.data_ptr(), st), args.iters)
         else:
             h_med = h_min = float("nan")
         print(f"ablate={ab:3d}  B={B} T={T}  lstm_fwd {f_med:8.1f} us (min {f_min:.1f})   lstm_bwd {b_med:8.1f} us (min {b_min:.1f})   "
@@ -80,12 +80,12 @@ def main():
                 dbg = torch.zeros(512, dtype=torch.int64, device=dev)
                 L.nsd_debug_profile_buffer(dbg.data_ptr())
                 if which == "fwd":
-                    L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, st)
+                    L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, wsn, st)
                     # role table of lstm2_fwd48_kernel: SIMD g = wave & 3, slot q = wave >> 2
                     roles = ["L1", "L1", "L1", "P", "L0", "L0", "L0", "P", "saver", "spare", "spare", "P"]
                     nst = ((T + 2 + 31) // 32) * 32
                 else:
-                    L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, None, st)
+                    L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, wsn, None, st)
                     roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1"] * 3 + ["dW"] * 6 + ["loader"]
                     nst = 4 * ((((T + 2) // 4 + 1) + 1) & ~1)
                 torch.cuda.synchronize()

@@ -9,7 +9,7 @@ ws = ops.new_workspace(spec, B, T, dev); ws.normal_()
 g = torch.zeros(spec.param_count, device=dev); p = torch.zeros_like(g); m = torch.zeros_like(g); v = torch.zeros_like(g)
 st = torch.cuda.current_stream().cuda_stream
 def run():
-    L.nsd_grad_reduce_adam(C.byref(d), ws.data_ptr(), g.data_ptr(), p.data_ptr(), m.data_ptr(), v.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1, st)
+    L.nsd_grad_reduce_adam(C.byref(d), ws.data_ptr(), ws.numel() * 4, g.data_ptr(), p.data_ptr(), m.data_ptr(), v.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1, st)
 for _ in range(200): run()
 torch.cuda.synchronize()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
