@@ -796,12 +796,12 @@ def test_reference_logits_on_every_recorded_window(nsd, dev, ref_state):
         lg = m(_t(ts.x, dev)).cpu().numpy()
     assert np.abs(lg - ref).max() < 1e-4
     assert np.array_equal(lg.argmax(-1), ref.argmax(-1))
-    # accuracy anchor of SURVEY 6, here on RAW windows (no MindsAI filter): checkpoint label order water/food/noise
+    # same confusion behaviour as the reference on the 179 three-class windows (checkpoint label order water/food/noise;
+    # fed RAW the reference checkpoint scores 45.8 % -- its 68.7 % of SURVEY 6 needs the MindsAI filter it was trained with)
     three = Dm.load_trials_npz(RECORDED)
     keep = np.array([p in three.label_map for p in ts.prefix])
     acc = float((lg[keep].argmax(-1) == three.y).mean())
-    assert acc == pytest.approx(float((ref[keep].argmax(-1) == three.y).mean()))
-    assert acc > 0.5
+    assert acc == pytest.approx(float((ref[keep].argmax(-1) == three.y).mean())) and acc == pytest.approx(82 / 179)
 
 
 @pytest.mark.timeout(900)
