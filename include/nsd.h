@@ -223,6 +223,23 @@ int nsd_train_masks_dev(uint64_t seed, const int64_t *step_dev, float p_lstm, fl
 int nsd_adam_step_dev(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2, float eps,
                       float weight_decay, float grad_scale, const int64_t *step_dev, void *stream);
 
+/*
+ * ---- sequence-batched path for large hidden sizes (BASELINE cfg3: H=256, K=5, B=1024 bf16; cfg5: bidirectional H=512) ----
+ *
+ * Building block, exported so that it can be tested and timed on its own: C[M,N] = A . B with bf16 operands (device
+ * pointers to bf16 bit patterns) and fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+ *   a_kmajor == 0: A is [M][lda], k contiguous;  != 0: A is [K][lda], m contiguous
+ *   b_kmajor == 0: B is [N][ldb], k contiguous;  != 0: B is [K][ldb], n contiguous; row k is then taken from row
+ *                  k + b_shift, rows outside [0, K) read as zero (h_{t-1} for the recurrent weight gradient)
+ *   epilogue 0: C fp32 [M][ldc]; splits > 1 writes split z to C + z*M*ldc (the caller sums the parts)
+ *            1: C bf16 [M][ldc]
+ *            2: C bf16 as 32x32 accumulator tiles [N/32][M/32][64][16] (+ bias[m]): the layout the scan kernels' lanes load
+ * Contiguous dimensions and leading dimensions must be multiples of 8 elements.
+ */
+int nsd_gemm_bf16(const void *A, int64_t lda, int32_t a_kmajor, const void *B, int64_t ldb, int32_t b_kmajor, int64_t b_shift,
+                  void *C, int64_t ldc, int32_t epilogue, const float *bias, int32_t M, int32_t N, int64_t K, int32_t splits,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

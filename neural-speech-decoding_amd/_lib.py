@@ -67,6 +67,8 @@ SYMBOLS = {
     "nsd_step_counter_inc": (C.c_int, [_vp, _vp]),
     "nsd_train_masks_dev": (C.c_int, [C.c_uint64, _vp, C.c_float, C.c_float, C.c_int64, _fp, C.c_int64, _fp, _fp, _vp]),
     "nsd_adam_step_dev": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [_vp, _vp]),
+    "nsd_gemm_bf16": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int64, C.c_int32, C.c_int64, _vp, C.c_int64, C.c_int32, _fp,
+                                C.c_int32, C.c_int32, C.c_int64, C.c_int32, _vp]),
     "nsd_train_masks": (C.c_int, [C.c_uint64, C.c_uint32, C.c_float, C.c_float, C.c_int64, _fp, C.c_int64, _fp, _fp, _vp]),
 }
 

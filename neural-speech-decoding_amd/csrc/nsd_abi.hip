@@ -4,6 +4,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include "nsd_args.h"
+#include "nsd_bf16.h"
 
 // ---- error text -------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -559,6 +560,16 @@ int nsd_dropout_mask(uint64_t seed, uint32_t stream_id, float p, int64_t n, floa
 int nsd_rrelu_noise(uint64_t seed, uint32_t stream_id, int64_t n, float *out, void *stream) {
     if (n < 0 || !out) { nsd_set_error("rrelu_noise: null pointer or n<0"); return NSD_E_INVALID; }
     return nsd_rrelu_noise_launch(seed, stream_id, n, out, (hipStream_t)stream);
+}
+
+int nsd_gemm_bf16(const void *A, int64_t lda, int32_t a_kmajor, const void *B, int64_t ldb, int32_t b_kmajor, int64_t b_shift,
+                  void *C, int64_t ldc, int32_t epilogue, const float *bias, int32_t M, int32_t N, int64_t K, int32_t splits,
+                  void *stream) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t *)A; g.B = (const bf16_t *)B; g.lda = lda; g.ldb = ldb; g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
+    g.b_shift = b_shift; g.C = C; g.ldc = ldc; g.bias = bias; g.M = M; g.N = N; g.K = K; g.splits = splits; g.epi = epilogue;
+    return nsd_gemm_bf16_launch(g, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,103 @@
+// nsd_bf16.h -- bf16 / MFMA building blocks of the sequence-batched path (nsd_gemm_bf16.hip, nsd_scan.hip, nsd_head_tm.hip).
+// gfx950 only: v_mfma_f32_32x32x16_bf16, ds_read_b64_tr_b16, sc1 (agent-scope, write-through) loads and stores.
+#pragma once
+#include "nsd_common.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Accumulator map of v_mfma_f32_32x32x16_bf16 (and every other 32x32 MFMA): register r of lane l holds
+// D[row = 8*(r/4) + 4*(l>>5) + (r%4)][col = l & 31].
+__device__ __forceinline__ int mfma32_row(const int r, const int lane) { return 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); }
+
+// Operand maps (32x32x16 bf16): lane l (i = l & 31, kq = l >> 5) holds A[row i][k = 8 kq + j] and B[k = 8 kq + j][col i],
+// j = 0..7, i.e. 8 k-consecutive elements = one 16-byte piece of a k-contiguous row of either operand.
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// two fp32 -> one dword of two bf16 (round to nearest even; v_cvt_pk_bf16_f32 at -O3), low half = a
+__device__ __forceinline__ unsigned pack_bf16x2(const float a, const float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf16_lo(const unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(const unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// Transposed LDS read: per group of 16 lanes a block of 4 rows x 16 columns of 16-bit elements; lane 4q+p of the group gives
+// the address of row q, columns 4p..4p+3 (8 bytes, 8-byte aligned); lane i receives column i, element q = row q.
+// EXEC must be all ones.  `p` is this lane's address (generic pointer into LDS).
+__device__ __forceinline__ s16x4 lds_read_tr16(const bf16_t *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(p));
+}
+__device__ __forceinline__ bf16x8 cat_tr(const s16x4 lo, const s16x4 hi) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// ---- agent-scope (sc1) accesses for data exchanged between workgroups inside one launch --------------------------------
+// Stores write through (the line is not kept in the XCD's L2), loads bypass the CU's L1: together with a drained
+// vmcnt + a flag they are the hand-off of MI355X guide, Guideline 16 (R1), with no release/acquire fence.
+__device__ __forceinline__ void st_sc1_u64(void *p, const unsigned long long v) {
+    __hip_atomic_store((unsigned long long *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_u32(void *p, const unsigned v) {
+    __hip_atomic_store((unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_sc1_u32(const void *p) {
+    return __hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16-byte sc1 load / store through a buffer descriptor (aux bit 4 = sc1)
+typedef __amdgpu_buffer_rsrc_t nsd_rsrc;
+__device__ __forceinline__ nsd_rsrc make_rsrc(const void *base, const unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 ld_sc1_b128(const nsd_rsrc r, const unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ void st_sc1_b128(const nsd_rsrc r, const unsigned byte_off, const u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ void st_sc1_b64(const nsd_rsrc r, const unsigned byte_off, const u32x2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)byte_off, 0, 16);
+}
+
+// ---- GEMM entry (nsd_gemm_bf16.hip) -------------------------------------------------------------------------------------
+// C[M,N] = sum_k A(m,k) * B(k,n), bf16 operands, fp32 accumulate.
+//   a_kmajor == 0: A is [M][lda] (k contiguous);  != 0: A is [K][lda] (m contiguous, transposed LDS reads)
+//   b_kmajor == 0: B is [N][ldb] (k contiguous);  != 0: B is [K][ldb] (n contiguous)
+// Rows of the K dimension can be shifted per operand (row k of the operand is taken from row k + shift; rows outside
+// [0, K) read as zero): the recurrent weight gradient multiplies da_t with h_{t-1}, i.e. the same sequence one time step away.
+enum GemmEpi {
+    GEMM_EPI_F32 = 0,        // C fp32 [M][ldc]; split z writes to C + z * M * ldc
+    GEMM_EPI_BF16 = 1,       // C bf16 [M][ldc]
+    GEMM_EPI_TILE_BF16 = 2,  // C bf16 in 32x32 accumulator tiles: [N/32][M/32][64 lanes][16]  (+ bias[m])  -- what the scan's lanes load
+};
+struct GemmArgs {
+    const bf16_t *A, *B;
+    long lda, ldb;
+    int a_kmajor, b_kmajor;
+    long b_shift;            // K-row shift of operand B (k-major B only)
+    void *C;
+    long ldc;
+    const float *bias;       // [M] (GEMM_EPI_TILE_BF16) or null
+    int M, N;
+    long K;
+    int splits;              // split-K parts (GEMM_EPI_F32 only)
+    int epi;
+};
+int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st);

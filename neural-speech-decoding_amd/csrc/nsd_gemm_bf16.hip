@@ -1,0 +1,184 @@
+// nsd_gemm_bf16.hip -- bf16 MFMA GEMM of the sequence-batched path (large hidden sizes; BASELINE cfg3 / cfg5).
+//
+// Everything in that path that is NOT the serial recurrence is a contraction over the whole sequence and runs here:
+//   input projection of a layer     xproj[4H, T*B]  = W_ih'[4H, I] . in[T*B, I]^T           (both operands k-contiguous)
+//   gradient w.r.t. a layer's input  d_in[T*B, I]    = da[T*B, 4H] . W_ih^T'[I, 4H]^T         (both operands k-contiguous)
+//   weight gradients                 dW[4H, I | H]   = da[T*B, 4H]^T . {in | h_prev}[T*B, .]  (both operands k-major: the
+//                                                       contraction runs over the rows -> transposed LDS reads, split-K)
+// (torch.nn.LSTM of Neuro-Alpha-App/Utilities/lstm_eeg_model.py:16-22,34 and autograd through it, for the layers whose
+// input is a full sequence).  One kernel: 128x128 tile, K chunks of 64, 4 waves as 2x2, each wave 2x2 v_mfma_f32_32x32x16_bf16
+// tiles; operands staged global -> registers -> LDS with the next chunk's loads in flight during the MFMAs.
+// LDS images: k-contiguous operand [128 rows][64 k + 8 pad] (ds_read_b128 fragments, conflict-free), k-major operand
+// [64 k][128 + 32 pad] (ds_read_b64_tr_b16 fragments: row stride = 16 dwords mod 64 keeps the 4 k-rows x 2 column blocks of
+// a 32-lane half on disjoint banks).
+#include "nsd_bf16.h"
+
+namespace {
+
+constexpr int GM = 128, GN = 128, GK = 64;
+constexpr int LDR = GK + 8;        // halves per LDS row, k-contiguous image
+constexpr int LDT = 128 + 32;      // halves per LDS row, k-major image
+constexpr int OPBYTES = (GM * LDR > GK * LDT ? GM * LDR : GK * LDT) * 2;
+
+struct Pieces { u32x4 v[4]; };
+
+// k-contiguous operand P[rows][ld]: tile rows r0.., k chunk k0..
+__device__ __forceinline__ Pieces load_rowmajor(const bf16_t *P, const long ld, const int r0, const int nrows, const long k0, const long k_hi,
+                                                const int tid) {
+    Pieces p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, row = e >> 3, kc = e & 7;
+        const long k = k0 + 8 * kc;
+        const bool ok = r0 + row < nrows && k < k_hi;
+        p.v[i] = ok ? *reinterpret_cast<const u32x4 *>(P + (long)(r0 + row) * ld + k) : u32x4{0u, 0u, 0u, 0u};
+    }
+    return p;
+}
+__device__ __forceinline__ void store_rowmajor(bf16_t *S, const Pieces &p, const int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, row = e >> 3, kc = e & 7;
+        *reinterpret_cast<u32x4 *>(S + row * LDR + 8 * kc) = p.v[i];
+    }
+}
+// k-major operand P[K][ld]: chunk rows k0.. (shifted by `shift`, rows outside [0, K) are zero), columns c0..
+__device__ __forceinline__ Pieces load_kmajor(const bf16_t *P, const long ld, const int c0, const int ncols, const long k0, const long k_hi,
+                                              const long shift, const long K, const int tid) {
+    Pieces p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, kr = e >> 4, cc = e & 15;
+        const long k = k0 + kr, ks = k + shift;
+        const bool ok = k < k_hi && ks >= 0 && ks < K && c0 + 8 * cc < ncols;
+        p.v[i] = ok ? *reinterpret_cast<const u32x4 *>(P + ks * ld + c0 + 8 * cc) : u32x4{0u, 0u, 0u, 0u};
+    }
+    return p;
+}
+__device__ __forceinline__ void store_kmajor(bf16_t *S, const Pieces &p, const int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, kr = e >> 4, cc = e & 15;
+        *reinterpret_cast<u32x4 *>(S + kr * LDT + 8 * cc) = p.v[i];
+    }
+}
+// fragment of the 32 rows (or columns) starting at `base` of the tile, k step ks (16 k)
+__device__ __forceinline__ bf16x8 frag_rowmajor(const bf16_t *S, const int base, const int ks, const int lane) {
+    return *reinterpret_cast<const bf16x8 *>(S + (base + (lane & 31)) * LDR + 16 * ks + 8 * (lane >> 5));
+}
+__device__ __forceinline__ bf16x8 frag_kmajor(const bf16_t *S, const int base, const int ks, const int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    const bf16_t *a = S + (16 * ks + 8 * (g >> 1) + q) * LDT + base + 16 * (g & 1) + 4 * p;
+    return cat_tr(lds_read_tr16(a), lds_read_tr16(a + 4 * LDT));
+}
+
+template <bool AK, bool BK, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
+    __shared__ __align__(16) unsigned char smem[2 * OPBYTES];
+    bf16_t *As = reinterpret_cast<bf16_t *>(smem), *Bs = reinterpret_cast<bf16_t *>(smem + OPBYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    // split-K range (whole chunks)
+    const long nchunks = (g.K + GK - 1) / GK;
+    const long per = (nchunks + g.splits - 1) / g.splits;
+    const long c_lo = (long)blockIdx.z * per, c_hi = (c_lo + per < nchunks) ? c_lo + per : nchunks;
+    const long k_lo = c_lo * GK, k_hi = (c_hi * GK < g.K) ? c_hi * GK : g.K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+
+    auto lda_ = [&](long k0) { return AK ? load_kmajor(g.A, g.lda, m0, g.M, k0, k_hi, 0, g.K, tid) : load_rowmajor(g.A, g.lda, m0, g.M, k0, k_hi, tid); };
+    auto ldb_ = [&](long k0) { return BK ? load_kmajor(g.B, g.ldb, n0, g.N, k0, k_hi, g.b_shift, g.K, tid) : load_rowmajor(g.B, g.ldb, n0, g.N, k0, k_hi, tid); };
+    if (k_lo < k_hi) {
+        Pieces pa = lda_(k_lo), pb = ldb_(k_lo);
+        for (long k0 = k_lo; k0 < k_hi; k0 += GK) {
+            __syncthreads();
+            if (AK) store_kmajor(As, pa, tid); else store_rowmajor(As, pa, tid);
+            if (BK) store_kmajor(Bs, pb, tid); else store_rowmajor(Bs, pb, tid);
+            if (k0 + GK < k_hi) { pa = lda_(k0 + GK); pb = ldb_(k0 + GK); }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < GK / 16; ++ks) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = AK ? frag_kmajor(As, 64 * wm + 32 * i, ks, lane) : frag_rowmajor(As, 64 * wm + 32 * i, ks, lane);
+                    b[i] = BK ? frag_kmajor(Bs, 64 * wn + 32 * i, ks, lane) : frag_rowmajor(Bs, 64 * wn + 32 * i, ks, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int mb = m0 + 64 * wm + 32 * i, nb = n0 + 64 * wn + 32 * j;
+            const int n = nb + (lane & 31);
+            if (EPI == GEMM_EPI_TILE_BF16) {
+                if (mb + 32 <= g.M && nb + 32 <= g.N) {            // whole tiles only (M, N multiples of 32 on this route)
+                    unsigned w[8];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float b0 = g.bias ? g.bias[mb + mfma32_row(r, lane)] : 0.f;
+                        const float b1 = g.bias ? g.bias[mb + mfma32_row(r + 1, lane)] : 0.f;
+                        w[r >> 1] = pack_bf16x2(acc[i][j][r] + b0, acc[i][j][r + 1] + b1);
+                    }
+                    bf16_t *dst = reinterpret_cast<bf16_t *>(g.C) + (((long)(nb >> 5) * (g.M >> 5) + (mb >> 5)) * 64 + lane) * 16;
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{w[0], w[1], w[2], w[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 8) = u32x4{w[4], w[5], w[6], w[7]};
+                }
+            } else {
+                if (n >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + mfma32_row(r, lane);
+                    if (m >= g.M) continue;
+                    if (EPI == GEMM_EPI_F32)
+                        (reinterpret_cast<float *>(g.C) + (long)blockIdx.z * g.M * g.ldc)[(long)m * g.ldc + n] = acc[i][j][r];
+                    else
+                        reinterpret_cast<bf16_t *>(g.C)[(long)m * g.ldc + n] = (bf16_t)acc[i][j][r];
+                }
+            }
+        }
+}
+
+template <bool AK, bool BK>
+int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
+    switch (g.epi) {
+    case GEMM_EPI_F32: hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK, GEMM_EPI_F32>), grid, dim3(256), 0, st, g); break;
+    case GEMM_EPI_BF16: hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK, GEMM_EPI_BF16>), grid, dim3(256), 0, st, g); break;
+    case GEMM_EPI_TILE_BF16: hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK, GEMM_EPI_TILE_BF16>), grid, dim3(256), 0, st, g); break;
+    default: nsd_set_error("gemm_bf16: unknown epilogue %d", g.epi); return NSD_E_INVALID;
+    }
+    NSD_CHECK_LAUNCH("gemm_bf16_kernel");
+    return NSD_OK;
+}
+
+}  // namespace
+
+int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
+    if (!g.A || !g.B || !g.C || g.M < 1 || g.N < 1 || g.K < 1) { nsd_set_error("gemm_bf16: null pointer or empty problem"); return NSD_E_INVALID; }
+    // 16-byte pieces along the contiguous dimension of each operand
+    if ((g.a_kmajor ? g.M % 8 : g.K % 8) || (g.b_kmajor ? g.N % 8 : g.K % 8) || g.lda % 8 || g.ldb % 8) {
+        nsd_set_error("gemm_bf16: contiguous dimensions and leading dimensions must be multiples of 8 (M=%d N=%d K=%ld lda=%ld ldb=%ld)",
+                      g.M, g.N, g.K, g.lda, g.ldb);
+        return NSD_E_INVALID;
+    }
+    if (g.epi == GEMM_EPI_TILE_BF16 && (g.M % 32 || g.N % 32)) { nsd_set_error("gemm_bf16: tile output needs M, N multiples of 32"); return NSD_E_INVALID; }
+    const int splits = (g.epi == GEMM_EPI_F32 && g.splits > 1) ? g.splits : 1;
+    if (g.b_shift != 0 && !g.b_kmajor) { nsd_set_error("gemm_bf16: b_shift needs a k-major B"); return NSD_E_INVALID; }
+    GemmArgs a = g;
+    a.splits = splits;
+    const dim3 grid((g.N + GN - 1) / GN, (g.M + GM - 1) / GM, splits);
+    if (g.a_kmajor) return g.b_kmajor ? launch_epi<true, true>(a, grid, st) : launch_epi<true, false>(a, grid, st);
+    return g.b_kmajor ? launch_epi<false, true>(a, grid, st) : launch_epi<false, false>(a, grid, st);
+}

@@ -319,3 +319,30 @@ def rrelu_noise(seed: int, stream_id: int, shape, device) -> torch.Tensor:
     out = torch.empty(shape, dtype=torch.float32, device=device)
     _call("nsd_rrelu_noise", out.device, seed & 0xFFFFFFFFFFFFFFFF, stream_id, out.numel(), _dev_f32(out, "out"), STREAM)
     return out
+
+
+# ---- sequence-batched path (large hidden sizes): building blocks ---------------------------------------------------------
+def gemm_bf16(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = False, b_kmajor: bool = False, b_shift: int = 0,
+              epilogue: int = 0, bias: Optional[torch.Tensor] = None, splits: int = 1) -> torch.Tensor:
+    """C[M,N] = A . B on the matrix pipe (nsd_gemm_bf16): bf16 device tensors, fp32 accumulate.
+    a: [M,K] (or [K,M] when a_kmajor), b: [N,K] (or [K,N] when b_kmajor).  epilogue 0 -> fp32 [splits,M,N] summed here when
+    splits > 1; 1 -> bf16 [M,N]; 2 -> bf16 accumulator tiles [N/32, M/32, 64, 16] (+ bias[m])."""
+    for t, n in ((a, "a"), (b, "b")):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise NsdError(f"gemm_bf16: {n} must be a contiguous bf16 tensor on the MI355X")
+    K, M = (a.shape[0], a.shape[1]) if a_kmajor else (a.shape[1], a.shape[0])
+    Kb, N = (b.shape[0], b.shape[1]) if b_kmajor else (b.shape[1], b.shape[0])
+    if K != Kb:
+        raise NsdError(f"gemm_bf16: K mismatch {K} vs {Kb}")
+    dev = a.device
+    if epilogue == 0:
+        c = torch.empty((max(splits, 1), M, N), dtype=torch.float32, device=dev)
+    elif epilogue == 1:
+        c = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    else:
+        c = torch.empty((N // 32, M // 32, 64, 16), dtype=torch.bfloat16, device=dev)
+    _call("nsd_gemm_bf16", dev, a.data_ptr(), a.shape[1], int(a_kmajor), b.data_ptr(), b.shape[1], int(b_kmajor), int(b_shift),
+          c.data_ptr(), N, int(epilogue), _dev_f32(bias, "bias", (M,)), M, N, K, int(splits), STREAM)
+    if epilogue == 0:
+        return c[0] if splits <= 1 else c.sum(0)
+    return c
