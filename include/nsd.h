@@ -50,6 +50,8 @@ extern "C" {
 /* flags */
 #define NSD_FLAG_RESIDUAL   1u   /* extension (not in the reference): out_l = LSTM_l(in_l) + in_l, l>=1 */
 #define NSD_FLAG_TRAIN      2u   /* keep activations in the workspace for nsd_*_bwd */
+#define NSD_FLAG_BIDIR      8u   /* nsd_seq_* entry points only: bidirectional LSTM (torch.nn.LSTM(bidirectional=True)); the
+                                    sequence fed to the attention pooling and the head is 2H wide */
 #define NSD_FLAG_BF16       4u   /* large-H batched path only (H % 16 == 0, H >= 64, B >= 16; ignored elsewhere): GEMM operands
                                     rounded to bf16 at the matrix pipe (fp32 accumulate, fp32 storage and cell arithmetic) --
                                     BASELINE cfg3's precision; results differ from fp32 at the 1e-2 level */
@@ -239,6 +241,39 @@ int nsd_adam_step_dev(int64_t n, float *p, const float *g, float *m, float *v, f
 int nsd_gemm_bf16(const void *A, int64_t lda, int32_t a_kmajor, const void *B, int64_t ldb, int32_t b_kmajor, int64_t b_shift,
                   void *C, int64_t ldc, int32_t epilogue, const float *bias, int32_t M, int32_t N, int64_t K, int32_t splits,
                   void *stream);
+
+/*
+ * The path itself.  Same model as above -- EEG_LSTM, lstm_eeg_model.py:13-39, with the ctor kwargs of :14 -- for hidden sizes
+ * 64, 128, 256, 512 (L <= 8, F, K <= 64), optionally bidirectional (NSD_FLAG_BIDIR; where lstm_eeg_model.py:16-22 would take
+ * torch's `bidirectional=True`), computed with bf16 GEMM operands, bf16 saved activations, fp32 accumulation and fp32 cell
+ * state / gate arithmetic (BASELINE cfg3 / cfg5 precision; differs from an fp32 run at the 1e-2 level on logits).
+ * Per layer: input projection over the whole sequence (one GEMM) -> persistent scan (recurrent weights resident in
+ * registers, groups of H/32 workgroups exchanging h_t through the saved sequence) ; backward: persistent scan -> weight /
+ * input gradient GEMMs.  x is the same [B,T,C] fp32 tensor as everywhere else; everything in between lives in `workspace`.
+ *
+ * Flat parameter vector: torch's state_dict order, i.e. per layer the four tensors of the forward direction, then (D = 2)
+ * the four `_reverse` tensors; layer l > 0 has input width D*H; ln / attn / fc.0 act on D*H columns.
+ *   nsd_seq_param_layout: offsets[4*L*D + 8]
+ * Train-mode randomness: counter streams of `rng` as in nsd_lstm_head_train_rng (inter-layer dropout index
+ * ((l*B + b)*T + t)*D*H + column, RReLU / head dropout index b*F + f); rng == NULL: no dropout, eval RReLU slope.
+ *   nsd_seq_train_fwd   forward + head + mean CE (scale = 1/B_global) + head backward; logits[B,K] written
+ *   nsd_seq_train_bwd   BPTT + all parameter gradients -> grads[P] (overwritten), same rng as the forward call
+ *   nsd_seq_loss_sum    sum of the per-trial CE losses of the last nsd_seq_train_fwd -> out[0] (device)
+ *   nsd_seq_status      BLOCKING (the only entry point that synchronises): 0 ok; 1 / 2 a forward / backward scan group
+ *                       timed out waiting for one of its workgroups (results are then invalid)
+ */
+int64_t nsd_seq_param_count(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int32_t D);
+int     nsd_seq_param_layout(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int32_t D, int64_t *offsets);
+int     nsd_seq_supported(const nsd_dims *d, uint32_t flags);
+int64_t nsd_seq_workspace_bytes(const nsd_dims *d, uint32_t flags);
+int nsd_seq_infer(const nsd_dims *d, const float *params, const float *x, uint32_t flags, float *logits, float *probs,
+                  void *workspace, int64_t workspace_bytes, void *stream);
+int nsd_seq_train_fwd(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, const int32_t *labels,
+                      float scale, uint32_t flags, void *workspace, int64_t workspace_bytes, float *logits, void *stream);
+int nsd_seq_train_bwd(const nsd_dims *d, const float *params, const nsd_rng *rng, uint32_t flags, void *workspace,
+                      int64_t workspace_bytes, float *grads, void *stream);
+int nsd_seq_loss_sum(const nsd_dims *d, uint32_t flags, const void *workspace, int64_t workspace_bytes, float *out, void *stream);
+int nsd_seq_status(const void *workspace, int32_t *status_out, void *stream);
 
 #ifdef __cplusplus
 }

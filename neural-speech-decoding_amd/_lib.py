@@ -16,6 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 NSD_FLAG_RESIDUAL = 1
 NSD_FLAG_TRAIN = 2
 NSD_FLAG_BF16 = 4
+NSD_FLAG_BIDIR = 8
 
 
 class Rng(C.Structure):
@@ -69,6 +70,15 @@ SYMBOLS = {
     "nsd_adam_step_dev": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp] + [C.c_float] * 6 + [_vp, _vp]),
     "nsd_gemm_bf16": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int64, C.c_int32, C.c_int64, _vp, C.c_int64, C.c_int32, _fp,
                                 C.c_int32, C.c_int32, C.c_int64, C.c_int32, _vp]),
+    "nsd_seq_param_count": (C.c_int64, [C.c_int32] * 6),
+    "nsd_seq_param_layout": (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int64)]),
+    "nsd_seq_supported": (C.c_int, [_dp, C.c_uint32]),
+    "nsd_seq_workspace_bytes": (C.c_int64, [_dp, C.c_uint32]),
+    "nsd_seq_infer": (C.c_int, [_dp, _fp, _fp, C.c_uint32, _fp, _fp, _vp, C.c_int64, _vp]),
+    "nsd_seq_train_fwd": (C.c_int, [_dp, _fp, _fp, _vp, _ip, C.c_float, C.c_uint32, _vp, C.c_int64, _fp, _vp]),
+    "nsd_seq_train_bwd": (C.c_int, [_dp, _fp, _vp, C.c_uint32, _vp, C.c_int64, _fp, _vp]),
+    "nsd_seq_loss_sum": (C.c_int, [_dp, C.c_uint32, _vp, C.c_int64, _fp, _vp]),
+    "nsd_seq_status": (C.c_int, [_vp, C.POINTER(C.c_int32), _vp]),
     "nsd_train_masks": (C.c_int, [C.c_uint64, C.c_uint32, C.c_float, C.c_float, C.c_int64, _fp, C.c_int64, _fp, _fp, _vp]),
 }
 

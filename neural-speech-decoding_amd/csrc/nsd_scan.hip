@@ -1,0 +1,496 @@
+// nsd_scan.hip -- the serial part of the sequence-batched LSTM path: persistent recurrence kernels with the recurrent
+// weights resident in registers for the whole sequence (self.lstm(x), Neuro-Alpha-App/Utilities/lstm_eeg_model.py:16-22,34:
+// torch.nn.LSTM semantics -- gate order i,f,g,o, zero initial state, one direction per scan -- and BPTT through it).
+//
+// Decomposition.  The input projection of a layer is hoisted out of the recurrence (one GEMM over the whole sequence,
+// nsd_gemm_bf16.hip); what is left per step is gates[4H, trials] = W_hh[4H, H] . h_{t-1}[H, trials] + xproj_t.  A GROUP of
+// P = H/32 workgroups advances one batch tile of MG trials through all T steps; workgroup p owns 32 hidden units: its 4 waves
+// hold the 4 x 32 matching rows of W_hh (bf16, 16-byte A fragments of v_mfma_f32_32x32x16_bf16) in VGPRs for the whole
+// launch -- 16 KB per wave at H = 256, 32 KB at H = 512 -- so the weights never move again.  The gate rows of a wave's tile
+// are ordered so that accumulator registers 4j..4j+3 of a lane are the gates i,f,g,o of ONE unit for ONE trial (the lane's
+// column): the LSTM cell runs entirely in the lane's registers, the cell state never leaves them, and the 4 units a lane
+// owns are adjacent in memory (8-byte stores).
+//
+// Exchange.  Each step every workgroup needs h_{t-1} of ALL H units of its batch tile: the members of a group exchange their
+// 32-unit slices through the saved sequence itself (hs[t] is written anyway for the backward pass): write-through (sc1)
+// stores, every storing wave drains vmcnt, workgroup barrier, ONE lane publishes the step count in the member's flag;
+// consumers poll the P flags of the group with sc1 loads (one wave, one word per lane), workgroup barrier, then sc1 loads of
+// the tile (guide: Guideline 16 R1 with sc1 loads in place of the acquire fence; every handed-off byte is stored and
+// loaded sc1).  Groups are independent of each other: no grid-wide barrier exists.  Every spin is bounded: a member that
+// does not see its group for ~1 s sets the status word and leaves (the others of the group then time out the same way).
+//
+// Backward.  Same grouping; per step the group exchanges da_t [trials, 4H] (written for the weight-gradient GEMMs anyway),
+// workgroup p computes dh_rec for its 32 units as W_hh^T[32, 4H] . da_t^T with the contraction split over its 4 waves (B
+// fragments straight from global memory -- each 16-byte piece is needed by exactly one wave), partial tiles meet in LDS.
+#include "nsd_seq.h"
+
+namespace {
+
+constexpr unsigned SPIN_LIMIT = 1u << 20;          // polls (each >= ~1 us with the sleep): ~1-2 s, then give up
+constexpr int ST_FWD_TIMEOUT = 1, ST_BWD_TIMEOUT = 2;
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// operand preparation
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row order of a 32-row accumulator tile: row n = 8j + 4hh + g  <->  unit 4hh + j of the tile's 8 units, gate g
+__device__ __forceinline__ int tile_row_to_param_row(const int tile, const int n, const int H) {
+    const int j = n >> 3, hh = (n >> 2) & 1, g = n & 3;
+    return g * H + 8 * tile + 4 * hh + j;
+}
+
+__global__ __launch_bounds__(256) void seq_prep_kernel(const PrepArgs a) {
+    const int H = a.H, G = 4 * H, I = a.I, Ip = a.Ipad;
+    const long n_wf = (long)G * H, n_wb = (long)H * G, n_wx = (long)G * Ip, n_wxt = a.wxt ? (long)I * G : 0, n_b = G;
+    const long total = n_wf + n_wb + n_wx + n_wxt + n_b;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        long i = e;
+        if (i < n_wf) {                                        // wf[row'][k] = W_hh[row(row')][k]
+            const int rp = (int)(i / H), k = (int)(i - (long)rp * H);
+            a.wf[i] = (bf16_t)a.w_hh[(long)tile_row_to_param_row(rp >> 5, rp & 31, H) * H + k];
+            continue;
+        }
+        i -= n_wf;
+        if (i < n_wb) {                                        // wb[j][c = 4u + g] = W_hh[g*H + u][j]
+            const int j = (int)(i / G), c = (int)(i - (long)j * G), u = c >> 2, g = c & 3;
+            a.wb[i] = (bf16_t)a.w_hh[(long)(g * H + u) * H + j];
+            continue;
+        }
+        i -= n_wb;
+        if (i < n_wx) {                                        // wx[row'][i] = W_ih[row(row')][i], zero padded to Ipad
+            const int rp = (int)(i / Ip), c = (int)(i - (long)rp * Ip);
+            a.wx[i] = c < I ? (bf16_t)a.w_ih[(long)tile_row_to_param_row(rp >> 5, rp & 31, H) * I + c] : (bf16_t)0.f;
+            continue;
+        }
+        i -= n_wx;
+        if (i < n_wxt) {                                       // wxt[i][off + c] = W_ih[g*H + u][i]
+            const int ii = (int)(i / G), c = (int)(i - (long)ii * G), u = c >> 2, g = c & 3;
+            a.wxt[(long)ii * a.wxt_ld + a.wxt_off + c] = (bf16_t)a.w_ih[(long)(g * H + u) * I + ii];
+            continue;
+        }
+        i -= n_wxt;
+        {
+            const int rp = (int)i, row = tile_row_to_param_row(rp >> 5, rp & 31, H);
+            a.bsum[rp] = a.b_ih[row] + a.b_hh[row];
+        }
+    }
+}
+
+// x [B][T][C] fp32 -> xbf [T][Bp][CP] bf16, zero padded
+__global__ __launch_bounds__(256) void seq_xbf_kernel(const float *x, bf16_t *xbf, int B, int Bp, int T, int C, int CP) {
+    const long total = (long)T * Bp * CP;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % CP);
+        const long r = e / CP;
+        const int b = (int)(r % Bp), t = (int)(r / Bp);
+        xbf[e] = (b < B && c < C) ? (bf16_t)x[((long)b * T + t) * C + c] : (bf16_t)0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// group geometry shared by both scans
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Member { int dir, group, p; };
+// Members of a group get block ids that are equal mod 8 where the grid allows it: those blocks are observed to share an XCD,
+// so the exchange stays inside one L2.  Speed only -- the protocol does not depend on placement.
+__device__ __forceinline__ Member member_of(const int bid, const int groups, const int P) {
+    Member m;
+    const int nper = groups * P;
+    m.dir = bid / nper;
+    const int rem = bid - m.dir * nper;
+    if ((nper & 7) == 0 && ((nper >> 3) % P) == 0) {
+        const int x = rem & 7, slot = rem >> 3;
+        m.group = x * ((nper >> 3) / P) + slot / P;
+        m.p = slot % P;
+    } else {
+        m.group = rem / P;
+        m.p = rem % P;
+    }
+    return m;
+}
+
+// wave 0: wait until every member of the group has published `need` steps.  Returns false on timeout.
+template <int P>
+__device__ __forceinline__ bool wait_group(const unsigned *gflags, const unsigned need, const int lane) {
+    for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        const unsigned v = lane < P ? ld_sc1_u32(gflags + lane) : 0xffffffffu;
+        if (__all(v >= need)) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+__device__ __forceinline__ f32x16 unpack_tile(const u32x4 lo, const u32x4 hi) {
+    f32x16 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = bf16_lo(lo[i]); v[2 * i + 1] = bf16_hi(lo[i]);
+        v[8 + 2 * i] = bf16_lo(hi[i]); v[8 + 2 * i + 1] = bf16_hi(hi[i]);
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// forward scan
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int H, int NT>
+__global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
+    constexpr int KS = H / 16, P = H / 32, MG = 32 * NT, LDB = H + 8, G = 4 * H;
+    __shared__ __align__(16) bf16_t Bt[MG * LDB];              // h_{t-1} of the batch tile, [trial][unit]
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Member me = member_of(blockIdx.x, a.groups, P);
+    const int dir = me.dir;
+    const int gt = 4 * me.p + wave;                            // this wave's accumulator tile = units 8gt .. 8gt+7
+    const int b0 = (a.group0 + me.group) * MG;
+    const int col = lane & 31, hh = lane >> 5;                 // MFMA column (trial of the tile) / k half
+
+    // recurrent weights -> registers for the whole sequence (A operand: lane holds row `col` of the tile, k = 16ks + 8hh ..)
+    bf16x8 w[KS];
+    {
+        const bf16_t *wrow = a.wf[dir] + (long)(32 * gt + col) * H + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[ks] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ks);
+    }
+    float c[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[nt][j] = 0.f;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+
+    unsigned *gflags = a.flags + (long)(dir * a.groups + me.group) * 16;
+    const long ld = a.ld, Bp = a.Bp;
+    const int u0 = 8 * gt + 4 * hh;                            // first of this lane's 4 units
+    const bool train = a.cs[0] != nullptr;
+
+    for (int s = 0; s < a.T; ++s) {
+        const int t = dir == 0 ? s : a.T - 1 - s;
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        // input projection of this step (independent of the recurrence: its latency runs under the wait below)
+        u32x4 xp[NT][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16_t *src = a.xproj[dir] + ((((long)t * (Bp >> 5) + (b0 >> 5) + nt) * (G >> 5) + gt) * 64 + lane) * 16;
+            xp[nt][0] = *reinterpret_cast<const u32x4 *>(src);
+            xp[nt][1] = *reinterpret_cast<const u32x4 *>(src + 8);
+        }
+        f32x16 acc[NT];
+        if (s > 0) {
+            if (wave == 0 && !wait_group<P>(gflags, (unsigned)s, lane) && lane == 0) {
+                s_abort = 1;
+                atomicExch(a.status, ST_FWD_TIMEOUT);
+            }
+            __syncthreads();
+            if (s_abort) break;                                 // uniform: every thread reads the same word after the barrier
+            // gather h_{t-1} of the whole tile (all H units): sc1 loads, 16 bytes each
+            const nsd_rsrc rh = make_rsrc(a.hs + ((long)tp * Bp + b0) * ld + dir * H, (unsigned)((long)MG * ld * 2));
+            constexpr int PIECES = MG * (H / 8) / 256;
+            u32x4 pv[PIECES];
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int e = tid + 256 * i, row = e / (H / 8), pc = e % (H / 8);
+                pv[i] = ld_sc1_b128(rh, (unsigned)((row * ld + 8 * pc) * 2));
+            }
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int e = tid + 256 * i, row = e / (H / 8), pc = e % (H / 8);
+                *reinterpret_cast<u32x4 *>(Bt + row * LDB + 8 * pc) = pv[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(Bt + (32 * nt + col) * LDB + 16 * ks + 8 * hh);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], b, acc[nt], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
+        }
+        // ---- LSTM cell in registers: registers 4j..4j+3 = gates i,f,g,o of unit u0 + j for trial b0 + 32nt + col
+        float hv[NT][4], gi[NT][4], gf[NT][4], gg[NT][4], go[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gi[nt][j] = fast_sigmoid(acc[nt][4 * j]);
+                gf[nt][j] = fast_sigmoid(acc[nt][4 * j + 1]);
+                gg[nt][j] = fast_tanh(acc[nt][4 * j + 2]);
+                go[nt][j] = fast_sigmoid(acc[nt][4 * j + 3]);
+                c[nt][j] = fmaf(gf[nt][j], c[nt][j], gi[nt][j] * gg[nt][j]);
+                hv[nt][j] = go[nt][j] * fast_tanh(c[nt][j]);
+            }
+        // ---- publish h_t: write-through stores, drain, barrier, flag
+        unsigned hw[NT][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            hw[nt][0] = pack_bf16x2(hv[nt][0], hv[nt][1]);
+            hw[nt][1] = pack_bf16x2(hv[nt][2], hv[nt][3]);
+            const long row = (long)t * Bp + b0 + 32 * nt + col;
+            st_sc1_u64(a.hs + row * ld + dir * H + u0, ((unsigned long long)hw[nt][1] << 32) | hw[nt][0]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) st_sc1_u32(gflags + me.p, (unsigned)(s + 1));
+        // ---- everything else of the step leaves behind the flag (nobody waits for it inside this launch)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int b = b0 + 32 * nt + col;
+            const long row = (long)t * Bp + b;
+            if (a.lk) {
+                float m[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.rng.on && b < a.B) {
+                    const uint64_t base = (((uint64_t)a.layer * a.B + b) * a.T + t) * (uint64_t)ld + (uint64_t)(dir * H + u0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[j] = nsd_rand_u32(a.rng.seed, a.rng.base, base + j) >= a.rng.thr_lstm ? a.rng.keep_lstm : 0.f;
+                }
+                // the multiplier acts on the value the next layer really reads: the bf16 h
+                const float h0 = bf16_lo(hw[nt][0]), h1 = bf16_hi(hw[nt][0]), h2 = bf16_lo(hw[nt][1]), h3 = bf16_hi(hw[nt][1]);
+                u32x2 v = {pack_bf16x2(h0 * m[0], h1 * m[1]), pack_bf16x2(h2 * m[2], h3 * m[3])};
+                *reinterpret_cast<u32x2 *>(a.lk + row * ld + dir * H + u0) = v;
+            }
+            if (train) {
+                u32x2 cv = {pack_bf16x2(c[nt][0], c[nt][1]), pack_bf16x2(c[nt][2], c[nt][3])};
+                *reinterpret_cast<u32x2 *>(a.cs[dir] + row * H + u0) = cv;
+                unsigned gw[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gw[2 * j] = pack_bf16x2(gi[nt][j], gf[nt][j]);
+                    gw[2 * j + 1] = pack_bf16x2(gg[nt][j], go[nt][j]);
+                }
+                bf16_t *gd = a.ga[dir] + row * G + 4 * u0;
+                *reinterpret_cast<u32x4 *>(gd) = u32x4{gw[0], gw[1], gw[2], gw[3]};
+                *reinterpret_cast<u32x4 *>(gd + 8) = u32x4{gw[4], gw[5], gw[6], gw[7]};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// backward scan
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int H, int NT>
+__global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
+    constexpr int P = H / 32, MG = 32 * NT, G = 4 * H, KQ = G / 16 / 4;       // k steps of one wave's quarter of the contraction
+    __shared__ __align__(16) float red[4][NT][32][32];        // partial dh_rec tiles of the 4 waves, [unit of the workgroup][trial]
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Member me = member_of(blockIdx.x, a.groups, P);
+    const int dir = me.dir;
+    const int b0 = (a.group0 + me.group) * MG;
+    const int col = lane & 31, hh = lane >> 5;
+
+    // W_hh^T rows = this workgroup's 32 units, k = this wave's quarter of the 4H gate columns
+    bf16x8 w[KQ];
+    {
+        const bf16_t *wrow = a.wb[dir] + (long)(32 * me.p + col) * G + wave * (G / 4) + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KQ; ++ks) w[ks] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ks);
+    }
+    float dc[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dc[nt][j] = 0.f;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+
+    unsigned *gflags = a.flags + (long)(dir * a.groups + me.group) * 16;
+    const long ld = a.ld, Bp = a.Bp, ldda = (long)a.D * G;
+    const int u0 = 32 * me.p + 8 * wave + 4 * hh;              // this lane's 4 units (same ownership as the forward scan)
+    // loop invariants of the top layer: d out_t = alpha_t * dpooled + dscore_t * attn_w
+    float dpl[NT][4], aw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aw[j] = a.din ? 0.f : a.attn_w[dir * H + u0 + j];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dpl[nt][j] = a.din ? 0.f : a.dpooled[(long)(b0 + 32 * nt + col) * ld + dir * H + u0 + j];
+
+    for (int s = 0; s < a.T; ++s) {
+        const int t = dir == 0 ? a.T - 1 - s : s;              // reverse of the forward order
+        const int tn = dir == 0 ? t + 1 : t - 1;               // the step processed just before (later in forward time)
+        const int tprev = dir == 0 ? t - 1 : t + 1;            // earlier in forward time: c_{t-1}
+        // saved activations and upstream gradient of this step: independent of the recurrence
+        u32x4 gq[NT][2];
+        u32x2 cq[NT], cpq[NT];
+        float dup[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int b = b0 + 32 * nt + col;
+            const long row = (long)t * Bp + b;
+            const bf16_t *gs = a.ga[dir] + row * G + 4 * u0;
+            gq[nt][0] = *reinterpret_cast<const u32x4 *>(gs);
+            gq[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 8);
+            cq[nt] = *reinterpret_cast<const u32x2 *>(a.cs[dir] + row * H + u0);
+            const bool first = dir == 0 ? t == 0 : t == a.T - 1;
+            cpq[nt] = first ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs[dir] + ((long)tprev * Bp + b) * H + u0);
+            if (a.din) {
+                const f32x4 dv = *reinterpret_cast<const f32x4 *>(a.din + row * ld + dir * H + u0);
+                float m[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.rng.on && b < a.B) {
+                    const uint64_t base = (((uint64_t)a.layer * a.B + b) * a.T + t) * (uint64_t)ld + (uint64_t)(dir * H + u0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[j] = nsd_rand_u32(a.rng.seed, a.rng.base, base + j) >= a.rng.thr_lstm ? a.rng.keep_lstm : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dup[nt][j] = dv[j] * m[j];
+            } else {
+                const float al = a.alpha[row], ds = a.dscore[row];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dup[nt][j] = fmaf(al, dpl[nt][j], ds * aw[j]);
+            }
+        }
+        float drec[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) drec[nt][j] = 0.f;
+        if (s > 0) {
+            if (wave == 0 && !wait_group<P>(gflags, (unsigned)s, lane) && lane == 0) {
+                s_abort = 1;
+                atomicExch(a.status, ST_BWD_TIMEOUT);
+            }
+            __syncthreads();
+            if (s_abort) break;
+            // dh_rec partial: rows = this workgroup's 32 units, columns = trials, k = this wave's quarter of da_{t+1}'s columns;
+            // B fragments straight from the exchanged tensor (sc1), 16 bytes per lane and k step
+            f32x16 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+            const nsd_rsrc rd = make_rsrc(a.da + ((long)tn * Bp + b0) * ldda + dir * G + wave * (G / 4), (unsigned)((long)MG * ldda * 2));
+            constexpr int CH = KQ < 8 ? KQ : 8;                  // fragments in flight per batch
+#pragma unroll
+            for (int k0 = 0; k0 < KQ; k0 += CH) {
+                u32x4 bv[NT][CH];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        bv[nt][k] = ld_sc1_b128(rd, (unsigned)(((32 * nt + col) * ldda + 16 * (k0 + k) + 8 * hh) * 2));
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[k0 + k], __builtin_bit_cast(bf16x8, bv[nt][k]), acc[nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave][nt][mfma32_row(r, lane)][col] = acc[nt][r];
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = 8 * wave + 4 * hh + j;
+                    drec[nt][j] = (red[0][nt][n][col] + red[1][nt][n][col]) + (red[2][nt][n][col] + red[3][nt][n][col]);
+                }
+        }
+        // ---- cell backward for (trial, 4 units); da_t -> exchange + saved for the weight-gradient GEMMs
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            unsigned dw[8];
+            const float cv[4] = {bf16_lo(cq[nt][0]), bf16_hi(cq[nt][0]), bf16_lo(cq[nt][1]), bf16_hi(cq[nt][1])};
+            const float cp[4] = {bf16_lo(cpq[nt][0]), bf16_hi(cpq[nt][0]), bf16_lo(cpq[nt][1]), bf16_hi(cpq[nt][1])};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned w0 = gq[nt][j >> 1][2 * (j & 1)], w1 = gq[nt][j >> 1][2 * (j & 1) + 1];
+                const float ig = bf16_lo(w0), fg = bf16_hi(w0), gg = bf16_lo(w1), og = bf16_hi(w1);
+                const float tc = fast_tanh(cv[j]);
+                const float dh = dup[nt][j] + drec[nt][j];
+                const float dct = fmaf(dh * og, 1.f - tc * tc, dc[nt][j]);
+                dc[nt][j] = dct * fg;
+                const float dai = dct * gg * ig * (1.f - ig);
+                const float daf = dct * cp[j] * fg * (1.f - fg);
+                const float dag = dct * ig * (1.f - gg * gg);
+                const float dao = dh * tc * og * (1.f - og);
+                dw[2 * j] = pack_bf16x2(dai, daf);
+                dw[2 * j + 1] = pack_bf16x2(dag, dao);
+            }
+            // (descriptor base wave-uniform, the lane's position in the offset)
+            const nsd_rsrc rs = make_rsrc(a.da + ((long)t * Bp + b0) * ldda + dir * G, (unsigned)((long)MG * ldda * 2));
+            const unsigned off = (unsigned)(((32 * nt + col) * ldda + 4 * u0) * 2);
+            st_sc1_b128(rs, off, u32x4{dw[0], dw[1], dw[2], dw[3]});
+            st_sc1_b128(rs, off + 16u, u32x4{dw[4], dw[5], dw[6], dw[7]});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // (also orders this step's reads of `red` before the next step's writes)
+        if (tid == 0) st_sc1_u32(gflags + me.p, (unsigned)(s + 1));
+    }
+}
+
+template <int H>
+int launch_fwd_h(const ScanFwdArgs &a, int MG, const dim3 grid, hipStream_t st) {
+    if (MG == 32) hipLaunchKernelGGL((scan_fwd_kernel<H, 1>), grid, dim3(256), 0, st, a);
+    else          hipLaunchKernelGGL((scan_fwd_kernel<H, 2>), grid, dim3(256), 0, st, a);
+    NSD_CHECK_LAUNCH("scan_fwd_kernel");
+    return NSD_OK;
+}
+template <int H>
+int launch_bwd_h(const ScanBwdArgs &a, int MG, const dim3 grid, hipStream_t st) {
+    if (MG == 32) hipLaunchKernelGGL((scan_bwd_kernel<H, 1>), grid, dim3(256), 0, st, a);
+    else          hipLaunchKernelGGL((scan_bwd_kernel<H, 2>), grid, dim3(256), 0, st, a);
+    NSD_CHECK_LAUNCH("scan_bwd_kernel");
+    return NSD_OK;
+}
+
+}  // namespace
+
+bool nsd_scan_supported(int H) { return H == 64 || H == 128 || H == 256 || H == 512; }
+
+static int check_grid(const char *who, int H, int MG, int groups, int D) {
+    if (!nsd_scan_supported(H) || (MG != 32 && MG != 64) || groups < 1 || D < 1 || D > NSD_SEQ_MAX_DIRS) {
+        nsd_set_error("%s: unsupported geometry H=%d MG=%d groups=%d D=%d", who, H, MG, groups, D);
+        return NSD_E_INVALID;
+    }
+    // every member of every group must be resident at the same time: one workgroup per CU
+    const int need = D * groups * (H / 32);
+    if (need > nsd_num_cus()) {
+        nsd_set_error("%s: %d workgroups needed but only %d CUs: split the batch (internal error of the caller)", who, need, nsd_num_cus());
+        return NSD_E_INVALID;
+    }
+    return NSD_OK;
+}
+
+int nsd_scan_fwd_launch(const ScanFwdArgs &a, int H, int MG, hipStream_t st) {
+    if (const int rc = check_grid("scan_fwd", H, MG, a.groups, a.D)) return rc;
+    const dim3 grid(a.D * a.groups * (H / 32));
+    switch (H) {
+    case 64: return launch_fwd_h<64>(a, MG, grid, st);
+    case 128: return launch_fwd_h<128>(a, MG, grid, st);
+    case 256: return launch_fwd_h<256>(a, MG, grid, st);
+    default: return launch_fwd_h<512>(a, MG, grid, st);
+    }
+}
+int nsd_scan_bwd_launch(const ScanBwdArgs &a, int H, int MG, hipStream_t st) {
+    if (const int rc = check_grid("scan_bwd", H, MG, a.groups, a.D)) return rc;
+    const dim3 grid(a.D * a.groups * (H / 32));
+    switch (H) {
+    case 64: return launch_bwd_h<64>(a, MG, grid, st);
+    case 128: return launch_bwd_h<128>(a, MG, grid, st);
+    case 256: return launch_bwd_h<256>(a, MG, grid, st);
+    default: return launch_bwd_h<512>(a, MG, grid, st);
+    }
+}
+
+int nsd_seq_prep_launch(const PrepArgs &a, hipStream_t st) {
+    const long total = 2L * 4 * a.H * a.H + 4L * a.H * a.Ipad + (a.wxt ? 4L * a.H * a.I : 0) + 4L * a.H;
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(seq_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    NSD_CHECK_LAUNCH("seq_prep_kernel");
+    return NSD_OK;
+}
+int nsd_seq_xbf_launch(const float *x, bf16_t *xbf, int B, int Bp, int T, int C, int CP, hipStream_t st) {
+    const long total = (long)T * Bp * CP;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(seq_xbf_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, xbf, B, Bp, T, C, CP);
+    NSD_CHECK_LAUNCH("seq_xbf_kernel");
+    return NSD_OK;
+}

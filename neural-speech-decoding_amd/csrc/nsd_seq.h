@@ -1,0 +1,113 @@
+// nsd_seq.h -- the sequence-batched path for large hidden sizes (BASELINE cfg3: H=256, K=5, B=1024, bf16; cfg5: C=64, T=1000,
+// H=512, bidirectional).  Shared declarations of nsd_scan.hip (persistent recurrence kernels), nsd_head_tm.hip (attention
+// pooling / LayerNorm / dense head on the time-major bf16 sequence) and the orchestration in nsd_seq.hip.
+//
+// Same model as the other paths -- EEG_LSTM of Neuro-Alpha-App/Utilities/lstm_eeg_model.py:13-39 with the ctor kwargs of
+// :14 (and `bidirectional=True` where :16-22 would take it) -- computed with bf16 GEMM operands and bf16 saved activations,
+// fp32 accumulation, fp32 cell state and gate arithmetic.
+//
+// Layout of the path, all time-major so that one time step of a batch tile is one contiguous block:
+//   rows r = t * Bp + b, Bp = B rounded up to the batch tile (padding trials carry zeros and produce zero gradients)
+//   xbf   [T*Bp][CP]        the EEG windows as bf16 (CP = C rounded up to 16)
+//   hs[l] [T*Bp][D*H]       h_t of layer l, direction d in columns d*H..        (recurrent exchange, dW_hh operand)
+//   lk[l] [T*Bp][D*H]       what layer l+1 and the head read: h * dropout multiplier (== hs[l] without dropout)
+//   cs    [T*Bp][H], ga [T*Bp][4H] per (l, d): cell state and activated gates (unit-major quads) for the backward pass
+//   xproj [T*Bp/32][4H/32][64][16] per d: input projection + bias as MFMA accumulator tiles (the scan's lanes load 32 bytes)
+//   da    [T*Bp][D*4H]      gate pre-activation gradients of the layer in flight (unit-major columns c = 4u + g)
+//   din   [T*Bp][D*H] fp32  gradient w.r.t. the layer's output coming from the layer above
+#pragma once
+#include "nsd_bf16.h"
+
+#define NSD_SEQ_MAX_DIRS 2
+#define NSD_SEQ_STATUS_WORDS 16
+
+struct SeqDims {
+    int B, T, C, H, L, K, F, D;
+    int Bp, MG, CP, P, groups;      // derived: padded batch, trials per group (32 or 64), padded channels, workgroups per group, groups per direction
+};
+
+struct SeqParamLayout {
+    int64_t w_ih[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS], w_hh[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS];
+    int64_t b_ih[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS], b_hh[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS];
+    int64_t ln_w, ln_b, attn_w, attn_b, fc0_w, fc0_b, fc3_w, fc3_b, total, lstm_total;
+};
+SeqParamLayout nsd_seq_make_layout(int C, int H, int L, int K, int F, int D);
+
+// byte offsets inside the caller's workspace
+struct SeqWs {
+    int64_t status, flags;                                       // int32[16]; uint32 [L][D][groups][16] + backward copy
+    int64_t xbf;
+    int64_t wf[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS], wb[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS], wx[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS];
+    int64_t wxt[NSD_MAX_LAYERS], bsum[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS];
+    int64_t hs[NSD_MAX_LAYERS], lk[NSD_MAX_LAYERS];
+    int64_t cs[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS], ga[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS];
+    int64_t xproj[NSD_SEQ_MAX_DIRS];
+    int64_t da, din[2];
+    int64_t alpha, dscore, pooled, dpooled, loss, hb, parts;
+    int64_t total;
+    int64_t flags_bytes, hb_stride;
+};
+
+// ---- recurrence kernels (nsd_scan.hip) ----------------------------------------------------------------------------------
+struct ScanFwdArgs {
+    const bf16_t *wf[NSD_SEQ_MAX_DIRS];      // [4H][H] recurrent weights, rows in accumulator-tile order
+    const bf16_t *xproj[NSD_SEQ_MAX_DIRS];   // accumulator tiles, bias included
+    bf16_t *hs;                              // [T*Bp][ld]
+    bf16_t *lk;                              // [T*Bp][ld] or null (no multiplier: readers use hs)
+    bf16_t *cs[NSD_SEQ_MAX_DIRS];            // [T*Bp][H] or null (inference)
+    bf16_t *ga[NSD_SEQ_MAX_DIRS];            // [T*Bp][4H] or null
+    unsigned *flags;                         // [D][groups][16], zeroed before the launch
+    int *status;
+    int B, Bp, T, D, ld, groups, group0, layer;  // groups of THIS launch, the first of them being batch tile group0
+    RngArgs rng;                             // rng.on: multiplier of stream rng.base on this layer's output
+};
+struct ScanBwdArgs {
+    const bf16_t *wb[NSD_SEQ_MAX_DIRS];      // [H][4H] recurrent weights transposed, k = unit-major gate column
+    const bf16_t *cs[NSD_SEQ_MAX_DIRS], *ga[NSD_SEQ_MAX_DIRS];
+    bf16_t *da;                              // [T*Bp][D*4H]
+    const float *din;                        // [T*Bp][ld] gradient w.r.t. this layer's (multiplied) output, or null (top layer)
+    const float *alpha, *dscore;             // [T*Bp] (top layer)
+    const float *dpooled;                    // [Bp][ld]
+    const float *attn_w;                     // [ld]
+    unsigned *flags;
+    int *status;
+    int B, Bp, T, D, ld, groups, group0, layer;
+    RngArgs rng;
+};
+int nsd_scan_fwd_launch(const ScanFwdArgs &a, int H, int MG, hipStream_t st);
+int nsd_scan_bwd_launch(const ScanBwdArgs &a, int H, int MG, hipStream_t st);
+bool nsd_scan_supported(int H);
+
+struct PrepArgs {
+    const float *w_ih, *w_hh, *b_ih, *b_hh;
+    bf16_t *wf, *wb, *wx, *wxt;              // wxt may be null (layer 0)
+    float *bsum;
+    int H, I, Ipad, wxt_ld, wxt_off;
+};
+int nsd_seq_prep_launch(const PrepArgs &a, hipStream_t st);
+int nsd_seq_xbf_launch(const float *x, bf16_t *xbf, int B, int Bp, int T, int C, int CP, hipStream_t st);
+
+// ---- head on the time-major sequence (nsd_head_tm.hip) -------------------------------------------------------------------
+struct HeadTmArgs {
+    const bf16_t *top;                       // [T*Bp][DH]
+    const float *ln_w, *ln_b, *attn_w, *attn_b, *fc0_w, *fc0_b, *fc3_w, *fc3_b;
+    float eval_slope;
+    float *logits, *probs;                   // [B][K]
+    // training
+    const int32_t *labels;
+    float scale;
+    RngArgs rng;                             // rng.on: RReLU slopes (stream base+1) and head dropout (base+2) drawn here
+    const float *rrelu_slope, *drop_head;    // explicit [B][F] tensors instead (tests); null with rng.on
+    float *alpha, *dscore;                   // [T*Bp]
+    float *pooled, *dpooled;                 // [Bp][DH]
+    float *loss;                             // [Bp]
+    float *hb;                               // per-trial rows for the parameter-gradient reductions, stride hb_stride
+    long hb_stride;
+    int B, Bp, T, DH, F, K, train;
+};
+int nsd_head_tm_launch(const HeadTmArgs &a, hipStream_t st);
+// head parameter gradients from the per-trial rows: grads_head points at ln.weight inside the flat gradient vector
+int nsd_head_tm_grads_launch(const float *hb, long hb_stride, int B, int DH, int F, int K, float *g_ln_w, float *g_ln_b, float *g_attn_w,
+                             float *g_attn_b, float *g_fc0_w, float *g_fc0_b, float *g_fc3_w, float *g_fc3_b, hipStream_t st);
+// per-trial row layout (floats): ln_out[DH] | dy_xhat[DH] | dy[DH] | dattn[DH] | dpre[F] | act[F] | dlogits[K] | dscore_sum[1]
+static inline long nsd_head_tm_row_floats(int DH, int F, int K) { return 4L * DH + 2L * F + K + 1; }

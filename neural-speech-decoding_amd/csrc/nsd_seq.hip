@@ -1,0 +1,430 @@
+// nsd_seq.hip -- orchestration and C ABI of the sequence-batched path (declared in include/nsd.h, "nsd_seq_*"):
+// parameter / workspace layout, the per-layer sequence  input-projection GEMM -> persistent scan  (forward) and
+// persistent scan -> weight-gradient / input-gradient GEMMs  (backward), head on the time-major sequence.
+// Model: EEG_LSTM of Neuro-Alpha-App/Utilities/lstm_eeg_model.py:13-39 (+ bidirectional nn.LSTM where :16-22 would take the
+// kwarg); parameter order = torch's state_dict order (…_l{k}, then …_l{k}_reverse per layer).
+#include <string.h>
+#include "nsd_seq.h"
+#include "nsd_args.h"
+
+namespace {
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+int derive(const nsd_dims *d, uint32_t flags, SeqDims *o) {
+    if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    SeqDims s;
+    s.B = d->B; s.T = d->T; s.C = d->C; s.H = d->H; s.L = d->L; s.K = d->K; s.F = d->F;
+    s.D = (flags & NSD_FLAG_BIDIR) ? 2 : 1;
+    if (!nsd_scan_supported(s.H)) { nsd_set_error("seq path: hidden size %d not covered (64, 128, 256, 512)", s.H); return NSD_E_INVALID; }
+    if (s.F > 64 || s.K > 64) { nsd_set_error("seq path: F=%d K=%d exceed 64", s.F, s.K); return NSD_E_INVALID; }
+    if (flags & NSD_FLAG_RESIDUAL) { nsd_set_error("seq path: the residual extension is not available on this path"); return NSD_E_INVALID; }
+    s.P = s.H / 32;
+    s.CP = (int)align_up(s.C, 16);
+    const int cus = nsd_num_cus();
+    const int cap = cus / (s.P * s.D);                          // groups that can be resident at once
+    if (cap < 1) { nsd_set_error("seq path: H=%d D=%d needs %d workgroups per group, device has %d CUs", s.H, s.D, s.P * s.D, cus); return NSD_E_INVALID; }
+    const int g32 = (s.B + 31) / 32;
+    s.MG = (g32 <= cap) ? 32 : 64;
+    s.Bp = (int)align_up(s.B > 0 ? s.B : 1, s.MG);
+    s.groups = s.Bp / s.MG;
+    *o = s;
+    return NSD_OK;
+}
+
+SeqWs make_ws(const SeqDims &s) {
+    SeqWs w;
+    memset(&w, 0, sizeof(w));
+    const int64_t R = (int64_t)s.T * s.Bp, H = s.H, G = 4 * H, DH = (int64_t)s.D * H;
+    int64_t p = 0;
+    auto take = [&](int64_t bytes) { const int64_t at = p; p = align_up(p + bytes, 256); return at; };
+    w.status = take(NSD_SEQ_STATUS_WORDS * 4);
+    w.flags_bytes = 2LL * s.L * s.D * s.groups * 16 * 4;        // forward + backward flag sets of every layer
+    w.flags = take(w.flags_bytes);
+    w.xbf = take(R * s.CP * 2);
+    for (int l = 0; l < s.L; ++l) {
+        const int64_t I = l == 0 ? s.C : DH, Ip = l == 0 ? s.CP : DH;
+        (void)I;
+        for (int d = 0; d < s.D; ++d) {
+            w.wf[l][d] = take(G * H * 2);
+            w.wb[l][d] = take(H * G * 2);
+            w.wx[l][d] = take(G * Ip * 2);
+            w.bsum[l][d] = take(G * 4);
+        }
+        w.wxt[l] = l > 0 ? take(DH * s.D * G * 2) : 0;
+        w.hs[l] = take(R * DH * 2);
+        w.lk[l] = l < s.L - 1 ? take(R * DH * 2) : 0;
+        for (int d = 0; d < s.D; ++d) {
+            w.cs[l][d] = take(R * H * 2);
+            w.ga[l][d] = take(R * G * 2);
+        }
+    }
+    for (int d = 0; d < s.D; ++d) w.xproj[d] = take(R * G * 2);
+    w.da = take(R * s.D * G * 2);
+    w.din[0] = take(R * DH * 4);
+    w.alpha = take(R * 4);
+    w.dscore = take(R * 4);
+    w.pooled = take((int64_t)s.Bp * DH * 4);
+    w.dpooled = take((int64_t)s.Bp * DH * 4);
+    w.loss = take((int64_t)s.Bp * 4);
+    w.hb_stride = align_up(nsd_head_tm_row_floats((int)DH, s.F, s.K), 4);
+    w.hb = take((int64_t)s.Bp * w.hb_stride * 4);
+    w.parts = take(64LL * 1024 * 1024);                          // split-K partials of the weight-gradient GEMMs (<= 16 M floats)
+    w.total = p;
+    return w;
+}
+
+template <class T>
+T *at(void *ws, int64_t off) { return reinterpret_cast<T *>(reinterpret_cast<char *>(ws) + off); }
+
+int make_rng_args(const nsd_rng *r, RngArgs *out) {
+    memset(out, 0, sizeof(*out));
+    if (!r) return NSD_OK;
+    if (!(r->p_lstm >= 0.f && r->p_lstm < 1.f) || !(r->p_head >= 0.f && r->p_head < 1.f)) { nsd_set_error("rng: p out of [0,1)"); return NSD_E_INVALID; }
+    out->seed = r->seed; out->base = r->base_stream;
+    out->thr_lstm = nsd_drop_threshold(r->p_lstm); out->thr_head = nsd_drop_threshold(r->p_head);
+    out->keep_lstm = 1.0f / (1.0f - r->p_lstm); out->keep_head = 1.0f / (1.0f - r->p_head);
+    out->on = 1;
+    return NSD_OK;
+}
+
+// ---- small reduction kernels of the backward pass -----------------------------------------------------------------------------
+// grads rows are torch's (g*H + u); the GEMM's rows are unit-major c = 4u + g.  out[(g*H+u)*I + i] = sum_z part[z][c][i], i < I
+__global__ __launch_bounds__(256) void seq_reduce_dw_kernel(const float *part, int nparts, int H, int N, int I, float *out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = 4L * H * I;
+    if (e >= total) return;
+    const int c = (int)(e / I), i = (int)(e - (long)c * I), u = c >> 2, g = c & 3;
+    const long MN = 4L * H * N;
+    float s = 0.f;
+    for (int z = 0; z < nparts; ++z) s += part[(long)z * MN + (long)c * N + i];
+    out[(long)(g * H + u) * I + i] = s;
+}
+// bias gradients: part[z][c] = sum of da[r][c] over the rows of split z  (256 threads = 64 columns x 4 row lanes)
+__global__ __launch_bounds__(256) void seq_colsum_part_kernel(const bf16_t *A, long lda, int M, long rows, float *part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r_lo = (long)blockIdx.y * per, r_hi = (r_lo + per < rows) ? r_lo + per : rows;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < M) {
+        long r = r_lo + g;
+        for (; r + 4 < r_hi; r += 8) { s0 += (float)A[r * lda + c]; s1 += (float)A[(r + 4) * lda + c]; }
+        for (; r < r_hi; r += 4) s0 += (float)A[r * lda + c];
+    }
+    red[g][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && c < M) part[(long)blockIdx.y * M + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void seq_reduce_db_kernel(const float *part, int nparts, int H, float *b_ih, float *b_hh) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 4 * H) return;
+    float s = 0.f;
+    for (int z = 0; z < nparts; ++z) s += part[(long)z * 4 * H + c];
+    const int u = c >> 2, g = c & 3;
+    b_ih[g * H + u] = s; b_hh[g * H + u] = s;
+}
+
+struct Ctx {
+    SeqDims s;
+    SeqParamLayout pl;
+    SeqWs w;
+    void *ws;
+    const float *params;
+    hipStream_t st;
+    int cap;                                                     // groups per scan launch
+};
+
+int split_count(int M, int N, long K) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int S = 512 / (tiles > 0 ? tiles : 1);
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    while (S > 1 && K / S < 256) --S;
+    while ((long)S * M * N > 16L * 1024 * 1024 && S > 1) --S;
+    return S;
+}
+
+int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
+    const SeqDims &s = c.s;
+    const int H = s.H, G = 4 * H, DH = s.D * H;
+    const long R = (long)s.T * s.Bp;
+    if (hipMemsetAsync(at<char>(c.ws, c.w.status), 0, (size_t)(c.w.flags + c.w.flags_bytes - c.w.status), c.st) != hipSuccess) {
+        nsd_set_error("seq: memset failed"); return NSD_E_LAUNCH;
+    }
+    if (const int rc = nsd_seq_xbf_launch(x, at<bf16_t>(c.ws, c.w.xbf), s.B, s.Bp, s.T, s.C, s.CP, c.st)) return rc;
+    for (int l = 0; l < s.L; ++l)
+        for (int d = 0; d < s.D; ++d) {
+            PrepArgs p;
+            memset(&p, 0, sizeof(p));
+            p.w_ih = c.params + c.pl.w_ih[l][d]; p.w_hh = c.params + c.pl.w_hh[l][d];
+            p.b_ih = c.params + c.pl.b_ih[l][d]; p.b_hh = c.params + c.pl.b_hh[l][d];
+            p.wf = at<bf16_t>(c.ws, c.w.wf[l][d]); p.wb = at<bf16_t>(c.ws, c.w.wb[l][d]); p.wx = at<bf16_t>(c.ws, c.w.wx[l][d]);
+            p.wxt = l > 0 ? at<bf16_t>(c.ws, c.w.wxt[l]) : nullptr;
+            p.bsum = at<float>(c.ws, c.w.bsum[l][d]);
+            p.H = H; p.I = l == 0 ? s.C : DH; p.Ipad = l == 0 ? s.CP : DH; p.wxt_ld = s.D * G; p.wxt_off = d * G;
+            if (const int rc = nsd_seq_prep_launch(p, c.st)) return rc;
+        }
+    for (int l = 0; l < s.L; ++l) {
+        // inter-layer dropout active: layer l < L-1 writes its multiplied output to lk[l], which layer l+1 then reads
+        const bool lstm_drop = train && rng.on && rng.thr_lstm != 0;
+        const bool masked = lstm_drop && l < s.L - 1;
+        const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : at<bf16_t>(c.ws, lstm_drop ? c.w.lk[l - 1] : c.w.hs[l - 1]);
+        const int Kin = l == 0 ? s.CP : DH;
+        for (int d = 0; d < s.D; ++d) {
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A = at<bf16_t>(c.ws, c.w.wx[l][d]); g.lda = Kin; g.B = in; g.ldb = Kin;
+            g.C = at<bf16_t>(c.ws, c.w.xproj[d]); g.bias = at<float>(c.ws, c.w.bsum[l][d]);
+            g.M = G; g.N = (int)R; g.K = Kin; g.splits = 1; g.epi = GEMM_EPI_TILE_BF16;
+            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+        }
+        for (int g0 = 0; g0 < s.groups; g0 += c.cap) {
+            ScanFwdArgs a;
+            memset(&a, 0, sizeof(a));
+            const int ng = s.groups - g0 < c.cap ? s.groups - g0 : c.cap;
+            for (int d = 0; d < s.D; ++d) {
+                a.wf[d] = at<bf16_t>(c.ws, c.w.wf[l][d]);
+                a.xproj[d] = at<bf16_t>(c.ws, c.w.xproj[d]);
+                a.cs[d] = train ? at<bf16_t>(c.ws, c.w.cs[l][d]) : nullptr;
+                a.ga[d] = train ? at<bf16_t>(c.ws, c.w.ga[l][d]) : nullptr;
+            }
+            a.hs = at<bf16_t>(c.ws, c.w.hs[l]);
+            a.lk = masked ? at<bf16_t>(c.ws, c.w.lk[l]) : nullptr;
+            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)l * s.D * s.groups + (long)g0 * s.D) * 16;   // disjoint per chunk
+            a.status = at<int>(c.ws, c.w.status);
+            a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
+            a.rng = rng;
+            a.rng.on = masked ? 1 : 0;
+            if (const int rc = nsd_scan_fwd_launch(a, H, s.MG, c.st)) return rc;
+        }
+    }
+    return NSD_OK;
+}
+
+HeadTmArgs head_args(Ctx &c, float *logits, float *probs) {
+    const SeqDims &s = c.s;
+    HeadTmArgs h;
+    memset(&h, 0, sizeof(h));
+    h.top = at<bf16_t>(c.ws, c.w.hs[s.L - 1]);
+    h.ln_w = c.params + c.pl.ln_w; h.ln_b = c.params + c.pl.ln_b; h.attn_w = c.params + c.pl.attn_w; h.attn_b = c.params + c.pl.attn_b;
+    h.fc0_w = c.params + c.pl.fc0_w; h.fc0_b = c.params + c.pl.fc0_b; h.fc3_w = c.params + c.pl.fc3_w; h.fc3_b = c.params + c.pl.fc3_b;
+    h.eval_slope = (float)((0.125 + 1.0 / 3.0) / 2.0);           // nn.RReLU eval slope, lstm_eeg_model.py:27
+    h.logits = logits; h.probs = probs;
+    h.B = s.B; h.Bp = s.Bp; h.T = s.T; h.DH = s.D * s.H; h.F = s.F; h.K = s.K;
+    return h;
+}
+
+int backward(Ctx &c, const RngArgs &rng, float *grads) {
+    const SeqDims &s = c.s;
+    const int H = s.H, G = 4 * H, DH = s.D * H;
+    const long R = (long)s.T * s.Bp;
+    float *parts = at<float>(c.ws, c.w.parts);
+    for (int l = s.L - 1; l >= 0; --l) {
+        const bool masked = rng.on && l < s.L - 1 && rng.thr_lstm != 0;
+        for (int g0 = 0; g0 < s.groups; g0 += c.cap) {
+            ScanBwdArgs a;
+            memset(&a, 0, sizeof(a));
+            const int ng = s.groups - g0 < c.cap ? s.groups - g0 : c.cap;
+            for (int d = 0; d < s.D; ++d) {
+                a.wb[d] = at<bf16_t>(c.ws, c.w.wb[l][d]);
+                a.cs[d] = at<bf16_t>(c.ws, c.w.cs[l][d]);
+                a.ga[d] = at<bf16_t>(c.ws, c.w.ga[l][d]);
+            }
+            a.da = at<bf16_t>(c.ws, c.w.da);
+            a.din = l == s.L - 1 ? nullptr : at<float>(c.ws, c.w.din[0]);
+            a.alpha = at<float>(c.ws, c.w.alpha); a.dscore = at<float>(c.ws, c.w.dscore); a.dpooled = at<float>(c.ws, c.w.dpooled);
+            a.attn_w = c.params + c.pl.attn_w;
+            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)(s.L + l) * s.D * s.groups + (long)g0 * s.D) * 16;
+            a.status = at<int>(c.ws, c.w.status);
+            a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
+            a.rng = rng;
+            a.rng.on = masked ? 1 : 0;
+            if (const int rc = nsd_scan_bwd_launch(a, H, s.MG, c.st)) return rc;
+        }
+        // ---- contractions over the whole sequence
+        const bf16_t *da = at<bf16_t>(c.ws, c.w.da);
+        const bool in_masked = rng.on && rng.thr_lstm != 0 && l > 0;
+        const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : at<bf16_t>(c.ws, in_masked ? c.w.lk[l - 1] : c.w.hs[l - 1]);
+        const int Kin = l == 0 ? s.CP : DH, I = l == 0 ? s.C : DH;
+        for (int d = 0; d < s.D; ++d) {
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A = da + (long)d * G; g.lda = (long)s.D * G; g.a_kmajor = 1; g.b_kmajor = 1;
+            g.C = parts; g.M = G; g.K = R; g.epi = GEMM_EPI_F32;
+            // recurrent weights: operand h_{t-1} of the direction (one time step = Bp rows away)
+            g.B = at<bf16_t>(c.ws, c.w.hs[l]) + (long)d * H; g.ldb = DH; g.N = H; g.ldc = H;
+            g.b_shift = d == 0 ? -(long)s.Bp : (long)s.Bp;
+            g.splits = split_count(G, H, R);
+            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+            hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * H + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, H, H,
+                               grads + c.pl.w_hh[l][d]);
+            // input weights
+            g.B = in; g.ldb = Kin; g.N = Kin; g.ldc = Kin; g.b_shift = 0;
+            g.splits = split_count(G, Kin, R);
+            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+            hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * I + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, Kin, I,
+                               grads + c.pl.w_ih[l][d]);
+            // biases
+            const int RS = 64;
+            hipLaunchKernelGGL(seq_colsum_part_kernel, dim3((G + 63) / 64, RS), dim3(256), 0, c.st, da + (long)d * G, (long)s.D * G, G, R, parts);
+            hipLaunchKernelGGL(seq_reduce_db_kernel, dim3((G + 255) / 256), dim3(256), 0, c.st, parts, RS, H, grads + c.pl.b_ih[l][d],
+                               grads + c.pl.b_hh[l][d]);
+            NSD_CHECK_LAUNCH("seq weight gradients");
+        }
+        if (l > 0) {                                             // gradient w.r.t. the layer's input, both directions in one contraction
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A = da; g.lda = (long)s.D * G; g.B = at<bf16_t>(c.ws, c.w.wxt[l]); g.ldb = (long)s.D * G;
+            g.C = at<float>(c.ws, c.w.din[0]); g.ldc = DH; g.M = (int)R; g.N = DH; g.K = (long)s.D * G; g.splits = 1; g.epi = GEMM_EPI_F32;
+            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+        }
+    }
+    const long hbs = c.w.hb_stride;
+    return nsd_head_tm_grads_launch(at<float>(c.ws, c.w.hb), hbs, s.B, DH, s.F, s.K, grads + c.pl.ln_w, grads + c.pl.ln_b, grads + c.pl.attn_w,
+                                    grads + c.pl.attn_b, grads + c.pl.fc0_w, grads + c.pl.fc0_b, grads + c.pl.fc3_w, grads + c.pl.fc3_b, c.st);
+}
+
+int make_ctx(const nsd_dims *d, uint32_t flags, const float *params, void *ws, int64_t ws_bytes, void *stream, const char *who, Ctx *c) {
+    if (const int rc = derive(d, flags, &c->s)) return rc;
+    c->pl = nsd_seq_make_layout(c->s.C, c->s.H, c->s.L, c->s.K, c->s.F, c->s.D);
+    c->w = make_ws(c->s);
+    if (!ws || !params) { nsd_set_error("%s: null pointer", who); return NSD_E_INVALID; }
+    if (ws_bytes < c->w.total) {
+        nsd_set_error("%s: workspace of %lld bytes is smaller than nsd_seq_workspace_bytes() = %lld", who, (long long)ws_bytes, (long long)c->w.total);
+        return NSD_E_WORKSPACE;
+    }
+    c->ws = ws; c->params = params; c->st = (hipStream_t)stream;
+    c->cap = nsd_num_cus() / (c->s.P * c->s.D);
+    return NSD_OK;
+}
+
+}  // namespace
+
+SeqParamLayout nsd_seq_make_layout(int C, int H, int L, int K, int F, int D) {
+    SeqParamLayout o;
+    memset(&o, 0, sizeof(o));
+    int64_t p = 0;
+    const int DH = D * H;
+    for (int l = 0; l < L; ++l) {
+        const int I = l == 0 ? C : DH;
+        for (int d = 0; d < D; ++d) {                            // torch: all four tensors of a direction, then the _reverse ones
+            o.w_ih[l][d] = p; p += 4LL * H * I;
+            o.w_hh[l][d] = p; p += 4LL * H * H;
+            o.b_ih[l][d] = p; p += 4LL * H;
+            o.b_hh[l][d] = p; p += 4LL * H;
+        }
+    }
+    o.lstm_total = p;
+    o.ln_w = p; p += DH;   o.ln_b = p; p += DH;
+    o.attn_w = p; p += DH; o.attn_b = p; p += 1;
+    o.fc0_w = p; p += (int64_t)F * DH; o.fc0_b = p; p += F;
+    o.fc3_w = p; p += (int64_t)K * F; o.fc3_b = p; p += K;
+    o.total = p;
+    return o;
+}
+
+extern "C" {
+
+int64_t nsd_seq_param_count(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int32_t D) {
+    if (C < 1 || H < 1 || L < 1 || L > NSD_MAX_LAYERS || K < 1 || F < 1 || D < 1 || D > NSD_SEQ_MAX_DIRS) {
+        nsd_set_error("bad model dims C=%d H=%d L=%d K=%d F=%d D=%d", C, H, L, K, F, D);
+        return NSD_E_INVALID;
+    }
+    return nsd_seq_make_layout(C, H, L, K, F, D).total;
+}
+
+int nsd_seq_param_layout(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int32_t D, int64_t *offsets) {
+    if (nsd_seq_param_count(C, H, L, K, F, D) < 0 || !offsets) return NSD_E_INVALID;
+    const SeqParamLayout o = nsd_seq_make_layout(C, H, L, K, F, D);
+    int64_t *q = offsets;
+    for (int l = 0; l < L; ++l)
+        for (int d = 0; d < D; ++d) { *q++ = o.w_ih[l][d]; *q++ = o.w_hh[l][d]; *q++ = o.b_ih[l][d]; *q++ = o.b_hh[l][d]; }
+    q[0] = o.ln_w; q[1] = o.ln_b; q[2] = o.attn_w; q[3] = o.attn_b; q[4] = o.fc0_w; q[5] = o.fc0_b; q[6] = o.fc3_w; q[7] = o.fc3_b;
+    return NSD_OK;
+}
+
+int nsd_seq_supported(const nsd_dims *d, uint32_t flags) {
+    SeqDims s;
+    return derive(d, flags, &s) == NSD_OK ? 1 : 0;
+}
+
+int64_t nsd_seq_workspace_bytes(const nsd_dims *d, uint32_t flags) {
+    SeqDims s;
+    if (const int rc = derive(d, flags, &s)) return rc;
+    return make_ws(s).total;
+}
+
+int nsd_seq_infer(const nsd_dims *d, const float *params, const float *x, uint32_t flags, float *logits, float *probs, void *workspace,
+                  int64_t workspace_bytes, void *stream) {
+    Ctx c;
+    if (const int rc = make_ctx(d, flags, params, workspace, workspace_bytes, stream, "seq_infer", &c)) return rc;
+    if (!x || !logits) { nsd_set_error("seq_infer: null pointer"); return NSD_E_INVALID; }
+    if (d->B == 0) return NSD_OK;
+    RngArgs off;
+    memset(&off, 0, sizeof(off));
+    if (const int rc = forward(c, x, off, false)) return rc;
+    HeadTmArgs h = head_args(c, logits, probs);
+    return nsd_head_tm_launch(h, c.st);
+}
+
+int nsd_seq_train_fwd(const nsd_dims *d, const float *params, const float *x, const nsd_rng *rng, const int32_t *labels, float scale,
+                      uint32_t flags, void *workspace, int64_t workspace_bytes, float *logits, void *stream) {
+    Ctx c;
+    if (const int rc = make_ctx(d, flags, params, workspace, workspace_bytes, stream, "seq_train_fwd", &c)) return rc;
+    if (!x || !logits || !labels) { nsd_set_error("seq_train_fwd: null pointer"); return NSD_E_INVALID; }
+    if (d->B == 0) return NSD_OK;
+    RngArgs r;
+    if (const int rc = make_rng_args(rng, &r)) return rc;
+    if (const int rc = forward(c, x, r, true)) return rc;
+    HeadTmArgs h = head_args(c, logits, nullptr);
+    h.train = 1; h.labels = labels; h.scale = scale; h.rng = r;
+    h.alpha = at<float>(c.ws, c.w.alpha); h.dscore = at<float>(c.ws, c.w.dscore);
+    h.pooled = at<float>(c.ws, c.w.pooled); h.dpooled = at<float>(c.ws, c.w.dpooled); h.loss = at<float>(c.ws, c.w.loss);
+    h.hb = at<float>(c.ws, c.w.hb); h.hb_stride = c.w.hb_stride;
+    // padding trials: their dpooled / dscore must be zero so that they contribute nothing to any gradient
+    const int DH = c.s.D * c.s.H;
+    if (c.s.Bp > c.s.B) {
+        if (hipMemsetAsync(h.dpooled + (long)c.s.B * DH, 0, (size_t)(c.s.Bp - c.s.B) * DH * 4, c.st) != hipSuccess ||
+            hipMemsetAsync(h.alpha, 0, (size_t)c.s.T * c.s.Bp * 4, c.st) != hipSuccess ||
+            hipMemsetAsync(h.dscore, 0, (size_t)c.s.T * c.s.Bp * 4, c.st) != hipSuccess) {
+            nsd_set_error("seq_train_fwd: memset failed");
+            return NSD_E_LAUNCH;
+        }
+    }
+    return nsd_head_tm_launch(h, c.st);
+}
+
+int nsd_seq_train_bwd(const nsd_dims *d, const float *params, const nsd_rng *rng, uint32_t flags, void *workspace, int64_t workspace_bytes,
+                      float *grads, void *stream) {
+    Ctx c;
+    if (const int rc = make_ctx(d, flags, params, workspace, workspace_bytes, stream, "seq_train_bwd", &c)) return rc;
+    if (!grads) { nsd_set_error("seq_train_bwd: null pointer"); return NSD_E_INVALID; }
+    if (d->B == 0) return NSD_OK;
+    RngArgs r;
+    if (const int rc = make_rng_args(rng, &r)) return rc;
+    return backward(c, r, grads);
+}
+
+int nsd_seq_loss_sum(const nsd_dims *d, uint32_t flags, const void *workspace, int64_t workspace_bytes, float *out, void *stream) {
+    SeqDims s;
+    if (const int rc = derive(d, flags, &s)) return rc;
+    const SeqWs w = make_ws(s);
+    if (!workspace || !out) { nsd_set_error("seq_loss_sum: null pointer"); return NSD_E_INVALID; }
+    if (workspace_bytes < w.total) { nsd_set_error("seq_loss_sum: workspace too small"); return NSD_E_WORKSPACE; }
+    return nsd_loss_sum_launch(reinterpret_cast<const float *>(reinterpret_cast<const char *>(workspace) + w.loss), s.B, out, (hipStream_t)stream);
+}
+
+// Blocking read of the path's status word: 0 = ok, 1 / 2 = a forward / backward scan group gave up waiting for a member
+// (a workgroup of the group was not resident, or the device was lost).  The only entry point that synchronises.
+int nsd_seq_status(const void *workspace, int32_t *status_out, void *stream) {
+    if (!workspace || !status_out) { nsd_set_error("seq_status: null pointer"); return NSD_E_INVALID; }
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+        hipMemcpy(status_out, workspace, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        nsd_set_error("seq_status: %s", hipGetErrorString(hipGetLastError()));
+        return NSD_E_LAUNCH;
+    }
+    return NSD_OK;
+}
+
+}  // extern "C"

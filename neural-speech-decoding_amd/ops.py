@@ -25,13 +25,17 @@ class ModelSpec:
     L: int = 2
     K: int = 3
     F: int = FC_HIDDEN
+    D: int = 1          # directions: 2 = bidirectional (torch's nn.LSTM(bidirectional=True)); sequence-batched path only
 
     def dims(self, B: int, T: int) -> Dims:
         return Dims(B, T, self.C, self.H, self.L, self.K, self.F)
 
     @property
     def param_count(self) -> int:
-        n = _lib.lib().nsd_param_count(self.C, self.H, self.L, self.K, self.F)
+        if self.D == 1:
+            n = _lib.lib().nsd_param_count(self.C, self.H, self.L, self.K, self.F)
+        else:
+            n = _lib.lib().nsd_seq_param_count(self.C, self.H, self.L, self.K, self.F, self.D)
         if n < 0:
             raise NsdError(f"bad model dims {self}")
         return int(n)
@@ -39,28 +43,43 @@ class ModelSpec:
     def names(self) -> List[str]:
         out = []
         for l in range(self.L):
-            out += [f"lstm.weight_ih_l{l}", f"lstm.weight_hh_l{l}", f"lstm.bias_ih_l{l}", f"lstm.bias_hh_l{l}"]
+            for sfx in (("",) if self.D == 1 else ("", "_reverse")):      # torch's state_dict order
+                out += [f"lstm.weight_ih_l{l}{sfx}", f"lstm.weight_hh_l{l}{sfx}", f"lstm.bias_ih_l{l}{sfx}", f"lstm.bias_hh_l{l}{sfx}"]
         return out + ["ln.weight", "ln.bias", "attn.weight", "attn.bias",
                       "fc.0.weight", "fc.0.bias", "fc.3.weight", "fc.3.bias"]
 
     def shapes(self) -> Dict[str, Tuple[int, ...]]:
         s = {}
+        DH = self.D * self.H
         for l in range(self.L):
-            I = self.C if l == 0 else self.H
-            s[f"lstm.weight_ih_l{l}"] = (4 * self.H, I)
-            s[f"lstm.weight_hh_l{l}"] = (4 * self.H, self.H)
-            s[f"lstm.bias_ih_l{l}"] = (4 * self.H,)
-            s[f"lstm.bias_hh_l{l}"] = (4 * self.H,)
-        s.update({"ln.weight": (self.H,), "ln.bias": (self.H,), "attn.weight": (1, self.H), "attn.bias": (1,),
-                  "fc.0.weight": (self.F, self.H), "fc.0.bias": (self.F,),
+            I = self.C if l == 0 else DH
+            for sfx in (("",) if self.D == 1 else ("", "_reverse")):
+                s[f"lstm.weight_ih_l{l}{sfx}"] = (4 * self.H, I)
+                s[f"lstm.weight_hh_l{l}{sfx}"] = (4 * self.H, self.H)
+                s[f"lstm.bias_ih_l{l}{sfx}"] = (4 * self.H,)
+                s[f"lstm.bias_hh_l{l}{sfx}"] = (4 * self.H,)
+        s.update({"ln.weight": (DH,), "ln.bias": (DH,), "attn.weight": (1, DH), "attn.bias": (1,),
+                  "fc.0.weight": (self.F, DH), "fc.0.bias": (self.F,),
                   "fc.3.weight": (self.K, self.F), "fc.3.bias": (self.K,)})
         return s
 
     def offsets(self) -> Dict[str, int]:
-        n = 4 * self.L + 8
+        n = 4 * self.L * self.D + 8
         offs = (C.c_int64 * n)()
-        _call("nsd_param_layout", None, self.C, self.H, self.L, self.K, self.F, offs)
+        if self.D == 1:
+            _call("nsd_param_layout", None, self.C, self.H, self.L, self.K, self.F, offs)
+        else:
+            _call("nsd_seq_param_layout", None, self.C, self.H, self.L, self.K, self.F, self.D, offs)
         return dict(zip(self.names(), [int(o) for o in offs]))
+
+    @property
+    def seq_flags(self) -> int:
+        return _lib.NSD_FLAG_BIDIR if self.D == 2 else 0
+
+    def seq_path(self, B: int = 32, T: int = 1) -> bool:
+        """True where the sequence-batched bf16 path (nsd_seq_*) covers this model (H in 64/128/256/512, F, K <= 64)."""
+        d = self.dims(B, T)
+        return bool(_lib.lib().nsd_seq_supported(C.byref(d), self.seq_flags))
 
     def fast_path(self) -> bool:
         d = self.dims(1, 1)
@@ -346,3 +365,73 @@ def gemm_bf16(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = False, b_kma
     if epilogue == 0:
         return c[0] if splits <= 1 else c.sum(0)
     return c
+
+
+# ---- sequence-batched path (nsd_seq_*): large hidden sizes, optional bidirectional, bf16 operands -------------------------
+def seq_workspace(spec: ModelSpec, B: int, T: int, device) -> torch.Tensor:
+    d = spec.dims(B, T)
+    n = _lib.lib().nsd_seq_workspace_bytes(C.byref(d), spec.seq_flags)
+    if n < 0:
+        check(int(n), "nsd_seq_workspace_bytes")
+    return torch.empty(int(n), dtype=torch.uint8, device=device)
+
+
+def _seq_rng(rng: Optional[dict]):
+    if rng is None:
+        return None
+    return C.byref(_lib.Rng(int(rng["seed"]) & 0xFFFFFFFFFFFFFFFF, int(rng["base_stream"]) & 0xFFFFFFFF, float(rng["p_lstm"]),
+                            float(rng["p_head"])))
+
+
+def seq_status(ws: torch.Tensor) -> int:
+    """0 = ok; 1 / 2 = a forward / backward scan group timed out (results invalid).  Synchronises."""
+    out = C.c_int32(-1)
+    _call("nsd_seq_status", ws.device, ws.data_ptr(), C.byref(out), STREAM)
+    return int(out.value)
+
+
+def seq_infer(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: Optional[torch.Tensor] = None, *,
+              want_probs: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    B, T, Cc = x.shape
+    if Cc != spec.C:
+        raise NsdError(f"x has {Cc} channels, model expects {spec.C}")
+    d = spec.dims(B, T)
+    logits = torch.empty((B, spec.K), dtype=torch.float32, device=x.device)
+    probs = torch.empty_like(logits) if want_probs else None
+    if B == 0:
+        return logits, probs
+    ws = seq_workspace(spec, B, T, x.device) if ws is None else ws
+    _call("nsd_seq_infer", x.device, C.byref(d), _dev_f32(flat, "params", (spec.param_count,)), _dev_f32(x, "x"), spec.seq_flags,
+          _dev_f32(logits, "logits"), _dev_f32(probs, "probs"), ws.data_ptr(), _nbytes(ws), STREAM)
+    return logits, probs
+
+
+def seq_train_fwd(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, labels: torch.Tensor, ws: torch.Tensor, *,
+                  rng: Optional[dict] = None, scale: Optional[float] = None, logits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Forward + head + mean CE + head backward of one training evaluation; activations stay in `ws` for seq_train_bwd."""
+    B, T, _ = x.shape
+    d = spec.dims(B, T)
+    if labels.dtype != torch.int32 or not labels.is_cuda or not labels.is_contiguous():
+        raise NsdError("labels must be a contiguous int32 tensor on the device")
+    logits = torch.empty((B, spec.K), dtype=torch.float32, device=x.device) if logits is None else logits
+    scale = (1.0 / max(B, 1)) if scale is None else float(scale)
+    _call("nsd_seq_train_fwd", x.device, C.byref(d), _dev_f32(flat, "params", (spec.param_count,)), _dev_f32(x, "x", (B, T, spec.C)),
+          _seq_rng(rng), labels.data_ptr(), scale, spec.seq_flags, ws.data_ptr(), _nbytes(ws), _dev_f32(logits, "logits", (B, spec.K)), STREAM)
+    return logits
+
+
+def seq_train_bwd(spec: ModelSpec, flat: torch.Tensor, ws: torch.Tensor, B: int, T: int, *, rng: Optional[dict] = None,
+                  grads: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """BPTT + every parameter gradient of the evaluation seq_train_fwd left in `ws` -> flat gradient vector (overwritten)."""
+    d = spec.dims(B, T)
+    grads = torch.empty(spec.param_count, dtype=torch.float32, device=flat.device) if grads is None else grads
+    _call("nsd_seq_train_bwd", flat.device, C.byref(d), _dev_f32(flat, "params", (spec.param_count,)), _seq_rng(rng), spec.seq_flags,
+          ws.data_ptr(), _nbytes(ws), _dev_f32(grads, "grads", (spec.param_count,)), STREAM)
+    return grads
+
+
+def seq_loss_sum(spec: ModelSpec, ws: torch.Tensor, B: int, T: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d = spec.dims(B, T)
+    out = torch.empty(1, dtype=torch.float32, device=ws.device) if out is None else out
+    _call("nsd_seq_loss_sum", ws.device, C.byref(d), spec.seq_flags, ws.data_ptr(), _nbytes(ws), out.data_ptr(), STREAM)
+    return out

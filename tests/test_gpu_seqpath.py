@@ -90,3 +90,109 @@ def test_gemm_bf16_split_k_shift_and_tile_epilogue(nsd, dev):
         for mt in range(M // 32):
             want = ref[32 * mt + rows, 32 * nt + cols]
             assert np.abs(tiles[nt, mt] - want).max() <= 2 ** -8 * np.abs(want).max() + 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# the path itself against the fp32 oracle (unidirectional): inference, training gradients, dropout streams
+# ---------------------------------------------------------------------------------------------------
+from oracle import nsd_oracle as orc                      # noqa: E402  (test infrastructure: the checker)
+from tests.golden.make_goldens import synth_labels, synth_params, synth_x      # noqa: E402
+
+# bf16 operands / bf16 saved activations, fp32 accumulation: measured agreement with the fp32 oracle is ~1e-2 on logits
+# of magnitude ~1 and a few percent of each gradient tensor's largest element; the bounds below are ~3x that.
+SEQ_LOGIT_TOL = 4e-2
+SEQ_GRAD_RTOL = 6e-2
+
+
+def _flat(state, d, dev):
+    return torch.from_numpy(orc.flatten_state(state, d)).to(dev)
+
+
+def _grad_check(got, ref, d, rtol=SEQ_GRAD_RTOL):
+    g, r = orc.unflatten(got, d), orc.unflatten(ref, d)
+    worst = {}
+    for k in orc.param_names(d):
+        scale = max(np.abs(r[k]).max(), 1e-6)
+        err = np.abs(g[k] - r[k]).max()
+        worst[k] = err / scale
+        if k == "attn.bias":
+            assert err < 1e-4, (k, err)                 # analytically zero
+        else:
+            assert err <= rtol * scale + 1e-6, (k, err, scale)
+    return worst
+
+
+@pytest.mark.parametrize("H,L,K,B,T", [(64, 2, 5, 40, 24), (128, 1, 3, 33, 17), (256, 2, 5, 48, 30), (64, 3, 3, 70, 9)])
+def test_seq_infer_matches_oracle(nsd, dev, H, L, K, B, T):
+    from nsd_amd import ops
+    d = orc.Dims(C=8, H=H, L=L, K=K)
+    spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+    assert spec.seq_path(B, T)
+    st = synth_params(8, H, L, K, seed=H + L)
+    x = synth_x(B, T, seed=B)
+    ref = orc.forward(orc.flatten_state(st, d), x, d)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    logits, probs = ops.seq_infer(spec, _flat(st, d, dev), torch.from_numpy(x).to(dev), ws)
+    assert ops.seq_status(ws) == 0
+    lg, pr = logits.cpu().numpy(), probs.cpu().numpy()
+    assert np.isfinite(lg).all()
+    assert np.abs(lg - ref["logits"]).max() < SEQ_LOGIT_TOL, np.abs(lg - ref["logits"]).max()
+    assert np.abs(pr - ref["probs"]).max() < SEQ_LOGIT_TOL
+    # argmax agrees wherever the oracle's margin exceeds the tolerance
+    srt = np.sort(ref["logits"], axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2 * SEQ_LOGIT_TOL
+    assert clear.sum() >= B // 2 and np.array_equal(lg.argmax(1)[clear], ref["logits"].argmax(1)[clear])
+    # batch invariance: the same trials in a different batch composition give the same logits (bitwise: per-trial arithmetic
+    # does not depend on the neighbours in the tile)
+    sub = torch.from_numpy(x[5:29]).to(dev)
+    lg2, _ = ops.seq_infer(spec, _flat(st, d, dev), sub)
+    assert torch.equal(lg2, logits[5:29])
+
+
+@pytest.mark.parametrize("H,L,K,B,T", [(64, 2, 5, 40, 24), (256, 2, 5, 36, 20), (128, 1, 3, 33, 12)])
+def test_seq_train_gradients_match_oracle(nsd, dev, H, L, K, B, T):
+    from nsd_amd import ops
+    d = orc.Dims(C=8, H=H, L=L, K=K)
+    spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+    st = synth_params(8, H, L, K, seed=3 * H + L)
+    x, y = synth_x(B, T, seed=B + 1), synth_labels(B, K, seed=B)
+    flat_np = orc.flatten_state(st, d)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, d)            # eval-mode RReLU, no dropout (rng=None)
+    flat = torch.from_numpy(flat_np).to(dev)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    logits = ops.seq_train_fwd(spec, flat, xt, yt, ws)
+    g = ops.seq_train_bwd(spec, flat, ws, B, T)
+    loss = float(ops.seq_loss_sum(spec, ws, B, T).item()) / B
+    assert ops.seq_status(ws) == 0
+    assert np.abs(logits.cpu().numpy() - fw["logits"]).max() < SEQ_LOGIT_TOL
+    assert abs(loss - loss_ref) < 2e-2
+    worst = _grad_check(g.cpu().numpy(), g_ref, d)
+    print("worst relative gradient errors:", {k: round(float(v), 4) for k, v in worst.items()})
+    # deterministic: a second evaluation is bit-identical
+    ops.seq_train_fwd(spec, flat, xt, yt, ws)
+    assert torch.equal(ops.seq_train_bwd(spec, flat, ws, B, T), g)
+
+
+def test_seq_train_with_counter_streams_matches_oracle_with_the_same_masks(nsd, dev):
+    """Dropout multipliers / RReLU slopes drawn inside the kernels == the oracle fed the tensors of the same counter streams."""
+    from nsd_amd import ops
+    H, L, K, B, T, F = 64, 2, 3, 37, 15, 32
+    d = orc.Dims(C=8, H=H, L=L, K=K)
+    spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+    st = synth_params(8, H, L, K, seed=77)
+    x, y = synth_x(B, T, seed=9), synth_labels(B, K, seed=9)
+    seed, base, p = 0xC0FFEE1234, 40, 0.5
+    dl = orc.dropout_mask(seed, base, p, (L - 1, B, T, H))
+    sl = orc.rrelu_noise(seed, base + 1, (B, F))
+    dh = orc.dropout_mask(seed, base + 2, p, (B, F))
+    flat_np = orc.flatten_state(st, d)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, d, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    flat = torch.from_numpy(flat_np).to(dev)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    rng = dict(seed=seed, base_stream=base, p_lstm=p, p_head=p)
+    logits = ops.seq_train_fwd(spec, flat, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), ws, rng=rng)
+    g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng)
+    assert ops.seq_status(ws) == 0
+    assert np.abs(logits.cpu().numpy() - fw["logits"]).max() < SEQ_LOGIT_TOL
+    _grad_check(g.cpu().numpy(), g_ref, d)
