@@ -52,6 +52,8 @@ extern "C" {
 #define NSD_FLAG_TRAIN      2u   /* keep activations in the workspace for nsd_*_bwd */
 #define NSD_FLAG_BIDIR      8u   /* nsd_seq_* entry points only: bidirectional LSTM (torch.nn.LSTM(bidirectional=True)); the
                                     sequence fed to the attention pooling and the head is 2H wide */
+#define NSD_FLAG_NO_L2_EXCHANGE 16u /* nsd_seq_* only, diagnostics: scan groups always use the write-through exchange, also when
+                                    all their workgroups report the same XCD (results are identical either way) */
 #define NSD_FLAG_BF16       4u   /* large-H batched path only (H % 16 == 0, H >= 64, B >= 16; ignored elsewhere): GEMM operands
                                     rounded to bf16 at the matrix pipe (fp32 accumulate, fp32 storage and cell arithmetic) --
                                     BASELINE cfg3's precision; results differ from fp32 at the 1e-2 level */

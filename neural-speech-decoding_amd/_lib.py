@@ -17,6 +17,7 @@ NSD_FLAG_RESIDUAL = 1
 NSD_FLAG_TRAIN = 2
 NSD_FLAG_BF16 = 4
 NSD_FLAG_BIDIR = 8
+NSD_FLAG_NO_L2_EXCHANGE = 16
 
 
 class Rng(C.Structure):

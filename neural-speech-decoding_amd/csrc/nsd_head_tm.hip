@@ -217,59 +217,60 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
     if (lane == 0) row[4 * DH + 2 * F + K] = dsum;
 }
 
-// Head parameter gradients: one thread per gradient element, trials summed in index order.
-__global__ __launch_bounds__(256) void head_tm_grads_kernel(const float *hb, long stride, int B, int DH, int F, int K, float *g_ln_w,
-                                                            float *g_ln_b, float *g_attn_w, float *g_attn_b, float *g_fc0_w, float *g_fc0_b,
-                                                            float *g_fc3_w, float *g_fc3_b) {
-    const long n_vec = 3L * DH, n_fc0 = (long)F * DH, n_fc3 = (long)K * F;
-    const long total = n_vec + n_fc0 + F + n_fc3 + K + 1;
+// Head parameter gradients, two stages (fixed order -> deterministic): stage 1, one thread per (gradient element, slice of the
+// batch): partial sums over the slice's trials; stage 2 adds the slices and scatters into the flat gradient vector.
+// Element order: d ln.weight[DH] | d ln.bias[DH] | d attn.weight[DH] | d fc.0.weight[F*DH] | d fc.0.bias[F] | d fc.3.weight[K*F] |
+// d fc.3.bias[K] | d attn.bias[1]
+__device__ __forceinline__ long head_grad_count(int DH, int F, int K) { return 3L * DH + (long)F * DH + F + (long)K * F + K + 1; }
+
+__global__ __launch_bounds__(256) void head_tm_grads_part_kernel(const float *hb, long stride, int B, int DH, int F, int K, float *part) {
+    const long total = head_grad_count(DH, F, K);
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
+    const int per = (B + gridDim.y - 1) / gridDim.y;
+    const int b_lo = blockIdx.y * per, b_hi = b_lo + per < B ? b_lo + per : B;
     const long o_dpre = 4L * DH, o_act = o_dpre + F, o_dlog = o_act + F, o_ds = o_dlog + K;
-    float s0 = 0.f, s1 = 0.f;
+    const long n_vec = 3L * DH, n_fc0 = (long)F * DH, n_fc3 = (long)K * F;
+    long oa, ob = -1;                                           // element = sum_b hb[b][oa] (* hb[b][ob])
     long i = e;
-    if (i < n_vec) {                                            // d ln.weight, d ln.bias, d attn.weight: column sums
-        const int which = (int)(i / DH), c = (int)(i - (long)which * DH);
-        const long off = (which == 0 ? 1L : which == 1 ? 2L : 3L) * DH + c;
-        int b = 0;
-        for (; b + 1 < B; b += 2) { s0 += hb[(long)b * stride + off]; s1 += hb[(long)(b + 1) * stride + off]; }
-        if (b < B) s0 += hb[(long)b * stride + off];
-        (which == 0 ? g_ln_w : which == 1 ? g_ln_b : g_attn_w)[c] = s0 + s1;
-        return;
-    }
-    i -= n_vec;
-    if (i < n_fc0) {                                            // d fc.0.weight[f][c] = sum_b dpre[b][f] * ln_out[b][c]
-        const int f = (int)(i / DH), c = (int)(i - (long)f * DH);
-        int b = 0;
-        for (; b + 1 < B; b += 2) {
-            s0 = fmaf(hb[(long)b * stride + o_dpre + f], hb[(long)b * stride + c], s0);
-            s1 = fmaf(hb[(long)(b + 1) * stride + o_dpre + f], hb[(long)(b + 1) * stride + c], s1);
+    if (i < n_vec) { const int which = (int)(i / DH); oa = (which + 1L) * DH + (i - (long)which * DH); }
+    else if ((i -= n_vec) < n_fc0) { const int f = (int)(i / DH); oa = o_dpre + f; ob = i - (long)f * DH; }
+    else if ((i -= n_fc0) < F) { oa = o_dpre + i; }
+    else if ((i -= F) < n_fc3) { const int k = (int)(i / F); oa = o_dlog + k; ob = o_act + (i - (long)k * F); }
+    else if ((i -= n_fc3) < K) { oa = o_dlog + i; }
+    else { oa = o_ds; }
+    float s0 = 0.f, s1 = 0.f;
+    int b = b_lo;
+    if (ob < 0) {
+        for (; b + 1 < b_hi; b += 2) { s0 += hb[(long)b * stride + oa]; s1 += hb[(long)(b + 1) * stride + oa]; }
+        if (b < b_hi) s0 += hb[(long)b * stride + oa];
+    } else {
+        for (; b + 1 < b_hi; b += 2) {
+            s0 = fmaf(hb[(long)b * stride + oa], hb[(long)b * stride + ob], s0);
+            s1 = fmaf(hb[(long)(b + 1) * stride + oa], hb[(long)(b + 1) * stride + ob], s1);
         }
-        if (b < B) s0 = fmaf(hb[(long)b * stride + o_dpre + f], hb[(long)b * stride + c], s0);
-        g_fc0_w[i] = s0 + s1;
-        return;
+        if (b < b_hi) s0 = fmaf(hb[(long)b * stride + oa], hb[(long)b * stride + ob], s0);
     }
-    i -= n_fc0;
-    if (i < F) {
-        for (int b = 0; b < B; ++b) s0 += hb[(long)b * stride + o_dpre + i];
-        g_fc0_b[i] = s0;
-        return;
-    }
-    i -= F;
-    if (i < n_fc3) {                                            // d fc.3.weight[k][f] = sum_b dlogits[b][k] * act[b][f]
-        const int k = (int)(i / F), f = (int)(i - (long)k * F);
-        for (int b = 0; b < B; ++b) s0 = fmaf(hb[(long)b * stride + o_dlog + k], hb[(long)b * stride + o_act + f], s0);
-        g_fc3_w[i] = s0;
-        return;
-    }
-    i -= n_fc3;
-    if (i < K) {
-        for (int b = 0; b < B; ++b) s0 += hb[(long)b * stride + o_dlog + i];
-        g_fc3_b[i] = s0;
-        return;
-    }
-    for (int b = 0; b < B; ++b) s0 += hb[(long)b * stride + o_ds];
-    g_attn_b[0] = s0;
+    part[(long)blockIdx.y * total + e] = s0 + s1;
+}
+__global__ __launch_bounds__(256) void head_tm_grads_sum_kernel(const float *part, int nparts, int DH, int F, int K, float *g_ln_w, float *g_ln_b,
+                                                                float *g_attn_w, float *g_attn_b, float *g_fc0_w, float *g_fc0_b, float *g_fc3_w,
+                                                                float *g_fc3_b) {
+    const long total = head_grad_count(DH, F, K);
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+    for (int z = 0; z < nparts; ++z) s += part[(long)z * total + e];
+    const long n_fc0 = (long)F * DH, n_fc3 = (long)K * F;
+    long i = e;
+    if (i < DH) { g_ln_w[i] = s; return; }
+    if ((i -= DH) < DH) { g_ln_b[i] = s; return; }
+    if ((i -= DH) < DH) { g_attn_w[i] = s; return; }
+    if ((i -= DH) < n_fc0) { g_fc0_w[i] = s; return; }
+    if ((i -= n_fc0) < F) { g_fc0_b[i] = s; return; }
+    if ((i -= F) < n_fc3) { g_fc3_w[i] = s; return; }
+    if ((i -= n_fc3) < K) { g_fc3_b[i] = s; return; }
+    g_attn_b[0] = s;
 }
 
 template <int VPL>
@@ -296,11 +297,14 @@ int nsd_head_tm_launch(const HeadTmArgs &a, hipStream_t st) {
     }
 }
 
-int nsd_head_tm_grads_launch(const float *hb, long hb_stride, int B, int DH, int F, int K, float *g_ln_w, float *g_ln_b, float *g_attn_w,
-                             float *g_attn_b, float *g_fc0_w, float *g_fc0_b, float *g_fc3_w, float *g_fc3_b, hipStream_t st) {
+int nsd_head_tm_grads_launch(const float *hb, long hb_stride, int B, int DH, int F, int K, float *scratch, float *g_ln_w, float *g_ln_b,
+                             float *g_attn_w, float *g_attn_b, float *g_fc0_w, float *g_fc0_b, float *g_fc3_w, float *g_fc3_b, hipStream_t st) {
     const long total = 3L * DH + (long)F * DH + F + (long)K * F + K + 1;
-    hipLaunchKernelGGL(head_tm_grads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, hb, hb_stride, B, DH, F, K, g_ln_w,
-                       g_ln_b, g_attn_w, g_attn_b, g_fc0_w, g_fc0_b, g_fc3_w, g_fc3_b);
-    NSD_CHECK_LAUNCH("head_tm_grads_kernel");
+    const int NB = B >= 512 ? 16 : (B >= 64 ? 4 : 1);           // scratch: NB * total floats
+    const unsigned gx = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(head_tm_grads_part_kernel, dim3(gx, NB), dim3(256), 0, st, hb, hb_stride, B, DH, F, K, scratch);
+    hipLaunchKernelGGL(head_tm_grads_sum_kernel, dim3(gx), dim3(256), 0, st, scratch, NB, DH, F, K, g_ln_w, g_ln_b, g_attn_w, g_attn_b, g_fc0_w,
+                       g_fc0_b, g_fc3_w, g_fc3_b);
+    NSD_CHECK_LAUNCH("head_tm_grads");
     return NSD_OK;
 }

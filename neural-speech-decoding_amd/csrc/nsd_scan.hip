@@ -13,10 +13,17 @@
 //
 // Exchange.  Each step every workgroup needs h_{t-1} of ALL H units of its batch tile: the members of a group exchange their
 // 32-unit slices through the saved sequence itself (hs[t] is written anyway for the backward pass): write-through (sc1)
-// stores, every storing wave drains vmcnt, workgroup barrier, ONE lane publishes the step count in the member's flag;
-// consumers poll the P flags of the group with sc1 loads (one wave, one word per lane), workgroup barrier, then sc1 loads of
-// the tile (guide: Guideline 16 R1 with sc1 loads in place of the acquire fence; every handed-off byte is stored and
-// loaded sc1).  Groups are independent of each other: no grid-wide barrier exists.  Every spin is bounded: a member that
+// stores, the storing wave drains vmcnt and publishes the step count in ITS OWN flag word (4 words per workgroup, no
+// workgroup barrier on the publishing side); every consuming wave polls all 4P words of its group with sc1 loads (one
+// word per lane) and only then issues its sc1 loads of the tile -- a tile row is complete before anybody reads any part
+// of it (guide: Guideline 16 R1 with sc1 loads in place of the acquire fence; every handed-off byte is stored and loaded
+// sc1, every flag follows the drain of the stores it stands for).
+// Same-XCD shortcut: before the first step the members of a group exchange their XCC ids (HW_REG_XCC_ID) through the slow
+// protocol -- which doubles as a start barrier: nobody enters the time loop before every member is resident.  When all ids
+// are equal the group shares ONE L2, and the exchange switches to plain stores (kept in that L2; vmcnt is acknowledged by
+// the L2) read by the same L1-bypassing loads: an L2 round trip per hop instead of a memory round trip.  Which mode a
+// group runs in is decided from what the hardware reports at run time, identically by all its members; a group spread
+// over XCDs simply keeps the write-through protocol.  Results are the same in both modes.  Groups are independent of each other: no grid-wide barrier exists.  Every spin is bounded: a member that
 // does not see its group for ~1 s sets the status word and leaves (the others of the group then time out the same way).
 //
 // Backward.  Same grouping; per step the group exchanges da_t [trials, 4H] (written for the weight-gradient GEMMs anyway),
@@ -24,10 +31,17 @@
 // fragments straight from global memory -- each 16-byte piece is needed by exactly one wave), partial tiles meet in LDS.
 #include "nsd_seq.h"
 
+// timing experiments only (make ABL=n -> libnsd_hip_abl.so, never shipped): bit 0 skip the flag wait, bit 1 skip the tile
+// gather, bit 2 skip the drain of the published stores -- results are wrong by construction, only the time is of interest
+#ifndef NSD_SCAN_ABLATE
+#define NSD_SCAN_ABLATE 0
+#endif
+
 namespace {
 
 constexpr unsigned SPIN_LIMIT = 1u << 20;          // polls (each >= ~1 us with the sleep): ~1-2 s, then give up
 constexpr int ST_FWD_TIMEOUT = 1, ST_BWD_TIMEOUT = 2;
+constexpr int GROUP_WORDS = 128;                   // flag words per group: [0,64) one per wave of every member, [64,80) XCC ids
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // operand preparation
@@ -108,15 +122,37 @@ __device__ __forceinline__ Member member_of(const int bid, const int groups, con
     return m;
 }
 
-// wave 0: wait until every member of the group has published `need` steps.  Returns false on timeout.
-template <int P>
+// one wave: wait until every wave of every member of the group has published `need` steps (NW = 4P flag words, one per
+// lane).  Returns false on timeout.
+template <int NW>
 __device__ __forceinline__ bool wait_group(const unsigned *gflags, const unsigned need, const int lane) {
     for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
-        const unsigned v = lane < P ? ld_sc1_u32(gflags + lane) : 0xffffffffu;
+        const unsigned v = lane < NW ? ld_sc1_u32(gflags + lane) : 0xffffffffu;
         if (__all(v >= need)) return true;
         __builtin_amdgcn_s_sleep(1);
     }
     return false;
+}
+
+// Start of a scan: publish this workgroup's XCC id, wait for the whole group (every wave polls; bounded), report whether the
+// group sits on one XCD.  Returns -1 on timeout, else 0 / 1.
+template <int P>
+__device__ __forceinline__ int group_rendezvous(unsigned *gwords, const int p, const int wave, const int lane) {
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;       // HW_REG_XCC_ID[3:0]
+    if (wave == 0 && lane == 0) st_sc1_u32(gwords + 64 + p, xcc + 1u);
+    for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        const unsigned v = lane < P ? ld_sc1_u32(gwords + 64 + lane) : xcc + 1u;
+        if (__all(v != 0u)) return __all(v == xcc + 1u) ? 1 : 0;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return -1;
+}
+// exchange stores: plain when the group shares an L2, write-through otherwise
+__device__ __forceinline__ void st_xchg_u64(const bool same_l2, void *p, const unsigned long long v) {
+    if (same_l2) *reinterpret_cast<unsigned long long *>(p) = v; else st_sc1_u64(p, v);
+}
+__device__ __forceinline__ void st_xchg_u32(const bool same_l2, void *p, const unsigned v) {
+    if (same_l2) *reinterpret_cast<unsigned *>(p) = v; else st_sc1_u32(p, v);
 }
 
 __device__ __forceinline__ f32x16 unpack_tile(const u32x4 lo, const u32x4 hi) {
@@ -135,7 +171,9 @@ __device__ __forceinline__ f32x16 unpack_tile(const u32x4 lo, const u32x4 hi) {
 template <int H, int NT>
 __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     constexpr int KS = H / 16, P = H / 32, MG = 32 * NT, LDB = H + 8, G = 4 * H;
-    __shared__ __align__(16) bf16_t Bt[MG * LDB];              // h_{t-1} of the batch tile, [trial][unit]
+    // h_{t-1} of the batch tile, [trial][unit]; two buffers alternate by step so that ONE barrier per step is enough (a wave
+    // refills buffer s&1 only after it passed the barrier of step s-1, i.e. after every wave finished reading it at step s-2)
+    __shared__ __align__(16) bf16_t Bt2[2][MG * LDB];
     __shared__ int s_abort;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Member me = member_of(blockIdx.x, a.groups, P);
@@ -159,7 +197,12 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     if (tid == 0) s_abort = 0;
     __syncthreads();
 
-    unsigned *gflags = a.flags + (long)(dir * a.groups + me.group) * 16;
+    unsigned *gflags = a.flags + (long)(dir * a.groups + me.group) * GROUP_WORDS;
+    const int rv = group_rendezvous<P>(gflags, me.p, wave, lane);
+    if (rv < 0 && lane == 0) { s_abort = 1; atomicExch(a.status, ST_FWD_TIMEOUT); }
+    __syncthreads();
+    if (s_abort) return;
+    const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
     const long ld = a.ld, Bp = a.Bp;
     const int u0 = 8 * gt + 4 * hh;                            // first of this lane's 4 units
     const bool train = a.cs[0] != nullptr;
@@ -177,12 +220,11 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
         }
         f32x16 acc[NT];
         if (s > 0) {
-            if (wave == 0 && !wait_group<P>(gflags, (unsigned)s, lane) && lane == 0) {
-                s_abort = 1;
+            bf16_t *Bt = Bt2[s & 1];
+            if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
+                s_abort = 1;                                    // (the wave still walks to the barrier below: the exit is uniform)
                 atomicExch(a.status, ST_FWD_TIMEOUT);
             }
-            __syncthreads();
-            if (s_abort) break;                                 // uniform: every thread reads the same word after the barrier
             // gather h_{t-1} of the whole tile (all H units): sc1 loads, 16 bytes each
             const nsd_rsrc rh = make_rsrc(a.hs + ((long)tp * Bp + b0) * ld + dir * H, (unsigned)((long)MG * ld * 2));
             constexpr int PIECES = MG * (H / 8) / 256;
@@ -190,7 +232,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
                 const int e = tid + 256 * i, row = e / (H / 8), pc = e % (H / 8);
-                pv[i] = ld_sc1_b128(rh, (unsigned)((row * ld + 8 * pc) * 2));
+                pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u} : ld_sc1_b128(rh, (unsigned)((row * ld + 8 * pc) * 2));
             }
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
@@ -198,6 +240,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 *reinterpret_cast<u32x4 *>(Bt + row * LDB + 8 * pc) = pv[i];
             }
             __syncthreads();
+            if (s_abort) break;                                 // uniform: every thread reads the same word after the barrier
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
 #pragma unroll
@@ -224,18 +267,17 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 c[nt][j] = fmaf(gf[nt][j], c[nt][j], gi[nt][j] * gg[nt][j]);
                 hv[nt][j] = go[nt][j] * fast_tanh(c[nt][j]);
             }
-        // ---- publish h_t: write-through stores, drain, barrier, flag
+        // ---- publish h_t: write-through stores, drain, this wave's flag
         unsigned hw[NT][2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             hw[nt][0] = pack_bf16x2(hv[nt][0], hv[nt][1]);
             hw[nt][1] = pack_bf16x2(hv[nt][2], hv[nt][3]);
             const long row = (long)t * Bp + b0 + 32 * nt + col;
-            st_sc1_u64(a.hs + row * ld + dir * H + u0, ((unsigned long long)hw[nt][1] << 32) | hw[nt][0]);
+            st_xchg_u64(same_l2, a.hs + row * ld + dir * H + u0, ((unsigned long long)hw[nt][1] << 32) | hw[nt][0]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) st_sc1_u32(gflags + me.p, (unsigned)(s + 1));
+        if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
         // ---- everything else of the step leaves behind the flag (nobody waits for it inside this launch)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -276,7 +318,11 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 template <int H, int NT>
 __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     constexpr int P = H / 32, MG = 32 * NT, G = 4 * H, KQ = G / 16 / 4;       // k steps of one wave's quarter of the contraction
-    __shared__ __align__(16) float red[4][NT][32][32];        // partial dh_rec tiles of the 4 waves, [unit of the workgroup][trial]
+    // partial dh_rec tiles of the 4 waves, [unit of the workgroup][trial]; two sets alternate by step (one barrier per step)
+    __shared__ __align__(16) float red2[2][4][NT][32][32];
+    constexpr int CW = (G / 4) < 128 ? (G / 4) : 128;          // columns per staged chunk of a wave's quarter
+    constexpr int NCH = (G / 4) / CW, LDS_ = CW + 8;
+    __shared__ __align__(16) bf16_t stg[4][MG * LDS_];         // one private strip per wave
     __shared__ int s_abort;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Member me = member_of(blockIdx.x, a.groups, P);
@@ -299,8 +345,16 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     if (tid == 0) s_abort = 0;
     __syncthreads();
 
-    unsigned *gflags = a.flags + (long)(dir * a.groups + me.group) * 16;
+    unsigned *gflags = a.flags + (long)(dir * a.groups + me.group) * GROUP_WORDS;
+    const int rv = group_rendezvous<P>(gflags, me.p, wave, lane);
+    if (rv < 0 && lane == 0) { s_abort = 1; atomicExch(a.status, ST_BWD_TIMEOUT); }
+    __syncthreads();
+    if (s_abort) return;
+    const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
     const long ld = a.ld, Bp = a.Bp, ldda = (long)a.D * G;
+    float dbs[16];                                             // bias gradient of this lane's 16 gate columns, summed over time and tiles
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dbs[k] = 0.f;
     const int u0 = 32 * me.p + 8 * wave + 4 * hh;              // this lane's 4 units (same ownership as the forward scan)
     // loop invariants of the top layer: d out_t = alpha_t * dpooled + dscore_t * attn_w
     float dpl[NT][4], aw[4];
@@ -351,38 +405,54 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) drec[nt][j] = 0.f;
         if (s > 0) {
-            if (wave == 0 && !wait_group<P>(gflags, (unsigned)s, lane) && lane == 0) {
+            float (*red)[NT][32][32] = red2[s & 1];
+            if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
                 s_abort = 1;
                 atomicExch(a.status, ST_BWD_TIMEOUT);
             }
-            __syncthreads();
-            if (s_abort) break;
-            // dh_rec partial: rows = this workgroup's 32 units, columns = trials, k = this wave's quarter of da_{t+1}'s columns;
-            // B fragments straight from the exchanged tensor (sc1), 16 bytes per lane and k step
+            // dh_rec partial: rows = this workgroup's 32 units, columns = trials, k = this wave's quarter of da_{t+1}'s columns.
+            // The wave stages its quarter of the tile through its PRIVATE LDS strip in chunks of CW columns: the global loads
+            // are whole 128-byte lines (16 lanes per row) instead of 32-byte fragments -- 4x fewer L2 requests, which is what
+            // bounds this kernel -- and no other wave touches the strip, so only the wave's own counters order it.
             f32x16 acc[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
             const nsd_rsrc rd = make_rsrc(a.da + ((long)tn * Bp + b0) * ldda + dir * G + wave * (G / 4), (unsigned)((long)MG * ldda * 2));
-            constexpr int CH = KQ < 8 ? KQ : 8;                  // fragments in flight per batch
+            bf16_t *strip = stg[wave];
+            constexpr int LPI = CW / 8;                          // lanes per row of a chunk (16-byte pieces)
+            constexpr int RPI = 64 / LPI;                        // rows per load instruction
+            constexpr int NLD = MG / RPI;                        // load instructions per chunk
+            const int lrow = lane / LPI, lpc = lane % LPI;
+            u32x4 pv[NLD];
 #pragma unroll
-            for (int k0 = 0; k0 < KQ; k0 += CH) {
-                u32x4 bv[NT][CH];
+            for (int i = 0; i < NLD; ++i)
+                pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}
+                                              : ld_sc1_b128(rd, (unsigned)(((lrow + RPI * i) * ldda + 8 * lpc) * 2));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+            for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        bv[nt][k] = ld_sc1_b128(rd, (unsigned)(((32 * nt + col) * ldda + 16 * (k0 + k) + 8 * hh) * 2));
+                for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4 *>(strip + (lrow + RPI * i) * LDS_ + 8 * lpc) = pv[i];
+                if (ch + 1 < NCH) {
 #pragma unroll
-                for (int k = 0; k < CH; ++k)
+                    for (int i = 0; i < NLD; ++i)
+                        pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}
+                                                      : ld_sc1_b128(rd, (unsigned)(((lrow + RPI * i) * ldda + CW * (ch + 1) + 8 * lpc) * 2));
+                }
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[k0 + k], __builtin_bit_cast(bf16x8, bv[nt][k]), acc[nt], 0, 0, 0);
+                for (int k = 0; k < CW / 16; ++k)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(strip + (32 * nt + col) * LDS_ + 16 * k + 8 * hh);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ch * (CW / 16) + k], b, acc[nt], 0, 0, 0);
+                    }
+                // (the compiler orders the next chunk's ds_write behind these ds_reads: same wave, same LDS object)
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) red[wave][nt][mfma32_row(r, lane)][col] = acc[nt][r];
             __syncthreads();
+            if (s_abort) break;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -411,16 +481,34 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                 const float dao = dh * tc * og * (1.f - og);
                 dw[2 * j] = pack_bf16x2(dai, daf);
                 dw[2 * j + 1] = pack_bf16x2(dag, dao);
+                dbs[4 * j] += dai; dbs[4 * j + 1] += daf; dbs[4 * j + 2] += dag; dbs[4 * j + 3] += dao;
             }
             // (descriptor base wave-uniform, the lane's position in the offset)
             const nsd_rsrc rs = make_rsrc(a.da + ((long)t * Bp + b0) * ldda + dir * G, (unsigned)((long)MG * ldda * 2));
             const unsigned off = (unsigned)(((32 * nt + col) * ldda + 4 * u0) * 2);
-            st_sc1_b128(rs, off, u32x4{dw[0], dw[1], dw[2], dw[3]});
-            st_sc1_b128(rs, off + 16u, u32x4{dw[4], dw[5], dw[6], dw[7]});
+            if (same_l2) {
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[0], dw[1], dw[2], dw[3]}, rs, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[4], dw[5], dw[6], dw[7]}, rs, (int)off + 16, 0, 0);
+            } else {
+                st_sc1_b128(rs, off, u32x4{dw[0], dw[1], dw[2], dw[3]});
+                st_sc1_b128(rs, off + 16u, u32x4{dw[4], dw[5], dw[6], dw[7]});
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                        // (also orders this step's reads of `red` before the next step's writes)
-        if (tid == 0) st_sc1_u32(gflags + me.p, (unsigned)(s + 1));
+        if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
+    }
+    // ---- bias gradients of this batch tile: sum over the 32 trials of each half-wave, one row of dbp per (direction, tile)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float v = dbs[k];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+        dbs[k] = v;
+    }
+    if (col == 0) {
+        float *dst = a.dbp + ((long)dir * a.groups_total + a.group0 + me.group) * G + 4 * u0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) *reinterpret_cast<f32x4 *>(dst + k) = f32x4{dbs[k], dbs[k + 1], dbs[k + 2], dbs[k + 3]};
     }
 }
 

@@ -43,7 +43,7 @@ struct SeqWs {
     int64_t cs[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS], ga[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS];
     int64_t xproj[NSD_SEQ_MAX_DIRS];
     int64_t da, din[2];
-    int64_t alpha, dscore, pooled, dpooled, loss, hb, parts;
+    int64_t alpha, dscore, pooled, dpooled, loss, hb, parts, dbp;
     int64_t total;
     int64_t flags_bytes, hb_stride;
 };
@@ -56,22 +56,25 @@ struct ScanFwdArgs {
     bf16_t *lk;                              // [T*Bp][ld] or null (no multiplier: readers use hs)
     bf16_t *cs[NSD_SEQ_MAX_DIRS];            // [T*Bp][H] or null (inference)
     bf16_t *ga[NSD_SEQ_MAX_DIRS];            // [T*Bp][4H] or null
-    unsigned *flags;                         // [D][groups][16], zeroed before the launch
+    unsigned *flags;                         // [D][groups][128] (one word per wave of every member + XCC ids), zeroed before the launch
     int *status;
     int B, Bp, T, D, ld, groups, group0, layer;  // groups of THIS launch, the first of them being batch tile group0
+    int allow_l2_mode;                       // 0: always the write-through exchange (tests: both modes must agree)
     RngArgs rng;                             // rng.on: multiplier of stream rng.base on this layer's output
 };
 struct ScanBwdArgs {
     const bf16_t *wb[NSD_SEQ_MAX_DIRS];      // [H][4H] recurrent weights transposed, k = unit-major gate column
     const bf16_t *cs[NSD_SEQ_MAX_DIRS], *ga[NSD_SEQ_MAX_DIRS];
     bf16_t *da;                              // [T*Bp][D*4H]
+    float *dbp;                              // [D][groups_total][4H] bias-gradient partials, one row per batch tile (unit-major columns)
     const float *din;                        // [T*Bp][ld] gradient w.r.t. this layer's (multiplied) output, or null (top layer)
     const float *alpha, *dscore;             // [T*Bp] (top layer)
     const float *dpooled;                    // [Bp][ld]
     const float *attn_w;                     // [ld]
     unsigned *flags;
     int *status;
-    int B, Bp, T, D, ld, groups, group0, layer;
+    int B, Bp, T, D, ld, groups, group0, groups_total, layer;
+    int allow_l2_mode;
     RngArgs rng;
 };
 int nsd_scan_fwd_launch(const ScanFwdArgs &a, int H, int MG, hipStream_t st);
@@ -107,7 +110,8 @@ struct HeadTmArgs {
 };
 int nsd_head_tm_launch(const HeadTmArgs &a, hipStream_t st);
 // head parameter gradients from the per-trial rows: grads_head points at ln.weight inside the flat gradient vector
-int nsd_head_tm_grads_launch(const float *hb, long hb_stride, int B, int DH, int F, int K, float *g_ln_w, float *g_ln_b, float *g_attn_w,
-                             float *g_attn_b, float *g_fc0_w, float *g_fc0_b, float *g_fc3_w, float *g_fc3_b, hipStream_t st);
+// (scratch: 16 * (3 DH + F DH + F + K F + K + 1) floats)
+int nsd_head_tm_grads_launch(const float *hb, long hb_stride, int B, int DH, int F, int K, float *scratch, float *g_ln_w, float *g_ln_b,
+                             float *g_attn_w, float *g_attn_b, float *g_fc0_w, float *g_fc0_b, float *g_fc3_w, float *g_fc3_b, hipStream_t st);
 // per-trial row layout (floats): ln_out[DH] | dy_xhat[DH] | dy[DH] | dattn[DH] | dpre[F] | act[F] | dlogits[K] | dscore_sum[1]
 static inline long nsd_head_tm_row_floats(int DH, int F, int K) { return 4L * DH + 2L * F + K + 1; }

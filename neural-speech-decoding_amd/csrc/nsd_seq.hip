@@ -39,7 +39,7 @@ SeqWs make_ws(const SeqDims &s) {
     int64_t p = 0;
     auto take = [&](int64_t bytes) { const int64_t at = p; p = align_up(p + bytes, 256); return at; };
     w.status = take(NSD_SEQ_STATUS_WORDS * 4);
-    w.flags_bytes = 2LL * s.L * s.D * s.groups * 16 * 4;        // forward + backward flag sets of every layer
+    w.flags_bytes = 2LL * s.L * s.D * s.groups * 128 * 4;        // forward + backward flag sets of every layer (one word per wave)
     w.flags = take(w.flags_bytes);
     w.xbf = take(R * s.CP * 2);
     for (int l = 0; l < s.L; ++l) {
@@ -69,6 +69,7 @@ SeqWs make_ws(const SeqDims &s) {
     w.loss = take((int64_t)s.Bp * 4);
     w.hb_stride = align_up(nsd_head_tm_row_floats((int)DH, s.F, s.K), 4);
     w.hb = take((int64_t)s.Bp * w.hb_stride * 4);
+    w.dbp = take((int64_t)s.D * s.groups * G * 4);
     w.parts = take(64LL * 1024 * 1024);                          // split-K partials of the weight-gradient GEMMs (<= 16 M floats)
     w.total = p;
     return w;
@@ -100,22 +101,7 @@ __global__ __launch_bounds__(256) void seq_reduce_dw_kernel(const float *part, i
     for (int z = 0; z < nparts; ++z) s += part[(long)z * MN + (long)c * N + i];
     out[(long)(g * H + u) * I + i] = s;
 }
-// bias gradients: part[z][c] = sum of da[r][c] over the rows of split z  (256 threads = 64 columns x 4 row lanes)
-__global__ __launch_bounds__(256) void seq_colsum_part_kernel(const bf16_t *A, long lda, int M, long rows, float *part) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    const long per = (rows + gridDim.y - 1) / gridDim.y;
-    const long r_lo = (long)blockIdx.y * per, r_hi = (r_lo + per < rows) ? r_lo + per : rows;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < M) {
-        long r = r_lo + g;
-        for (; r + 4 < r_hi; r += 8) { s0 += (float)A[r * lda + c]; s1 += (float)A[(r + 4) * lda + c]; }
-        for (; r < r_hi; r += 4) s0 += (float)A[r * lda + c];
-    }
-    red[g][threadIdx.x & 63] = s0 + s1;
-    __syncthreads();
-    if (g == 0 && c < M) part[(long)blockIdx.y * M + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
+// bias gradients: sum of the per-tile rows the backward scan left
 __global__ __launch_bounds__(256) void seq_reduce_db_kernel(const float *part, int nparts, int H, float *b_ih, float *b_hh) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= 4 * H) return;
@@ -133,6 +119,7 @@ struct Ctx {
     const float *params;
     hipStream_t st;
     int cap;                                                     // groups per scan launch
+    int l2_mode;                                                 // same-XCD exchange shortcut allowed (NSD_FLAG_NO_L2_EXCHANGE clears it)
 };
 
 int split_count(int M, int N, long K) {
@@ -191,11 +178,12 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             }
             a.hs = at<bf16_t>(c.ws, c.w.hs[l]);
             a.lk = masked ? at<bf16_t>(c.ws, c.w.lk[l]) : nullptr;
-            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)l * s.D * s.groups + (long)g0 * s.D) * 16;   // disjoint per chunk
+            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)l * s.D * s.groups + (long)g0 * s.D) * 128;   // disjoint per chunk
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
             a.rng = rng;
             a.rng.on = masked ? 1 : 0;
+            a.allow_l2_mode = c.l2_mode;
             if (const int rc = nsd_scan_fwd_launch(a, H, s.MG, c.st)) return rc;
         }
     }
@@ -235,11 +223,13 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             a.din = l == s.L - 1 ? nullptr : at<float>(c.ws, c.w.din[0]);
             a.alpha = at<float>(c.ws, c.w.alpha); a.dscore = at<float>(c.ws, c.w.dscore); a.dpooled = at<float>(c.ws, c.w.dpooled);
             a.attn_w = c.params + c.pl.attn_w;
-            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)(s.L + l) * s.D * s.groups + (long)g0 * s.D) * 16;
+            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)(s.L + l) * s.D * s.groups + (long)g0 * s.D) * 128;
+            a.dbp = at<float>(c.ws, c.w.dbp); a.groups_total = s.groups;
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
             a.rng = rng;
             a.rng.on = masked ? 1 : 0;
+            a.allow_l2_mode = c.l2_mode;
             if (const int rc = nsd_scan_bwd_launch(a, H, s.MG, c.st)) return rc;
         }
         // ---- contractions over the whole sequence
@@ -265,11 +255,9 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
             hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * I + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, Kin, I,
                                grads + c.pl.w_ih[l][d]);
-            // biases
-            const int RS = 64;
-            hipLaunchKernelGGL(seq_colsum_part_kernel, dim3((G + 63) / 64, RS), dim3(256), 0, c.st, da + (long)d * G, (long)s.D * G, G, R, parts);
-            hipLaunchKernelGGL(seq_reduce_db_kernel, dim3((G + 255) / 256), dim3(256), 0, c.st, parts, RS, H, grads + c.pl.b_ih[l][d],
-                               grads + c.pl.b_hh[l][d]);
+            // biases: the backward scan summed da over time per batch tile
+            hipLaunchKernelGGL(seq_reduce_db_kernel, dim3((G + 255) / 256), dim3(256), 0, c.st, at<float>(c.ws, c.w.dbp) + (long)d * s.groups * G,
+                               s.groups, H, grads + c.pl.b_ih[l][d], grads + c.pl.b_hh[l][d]);
             NSD_CHECK_LAUNCH("seq weight gradients");
         }
         if (l > 0) {                                             // gradient w.r.t. the layer's input, both directions in one contraction
@@ -281,7 +269,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
         }
     }
     const long hbs = c.w.hb_stride;
-    return nsd_head_tm_grads_launch(at<float>(c.ws, c.w.hb), hbs, s.B, DH, s.F, s.K, grads + c.pl.ln_w, grads + c.pl.ln_b, grads + c.pl.attn_w,
+    return nsd_head_tm_grads_launch(at<float>(c.ws, c.w.hb), hbs, s.B, DH, s.F, s.K, parts, grads + c.pl.ln_w, grads + c.pl.ln_b, grads + c.pl.attn_w,
                                     grads + c.pl.attn_b, grads + c.pl.fc0_w, grads + c.pl.fc0_b, grads + c.pl.fc3_w, grads + c.pl.fc3_b, c.st);
 }
 
@@ -296,6 +284,7 @@ int make_ctx(const nsd_dims *d, uint32_t flags, const float *params, void *ws, i
     }
     c->ws = ws; c->params = params; c->st = (hipStream_t)stream;
     c->cap = nsd_num_cus() / (c->s.P * c->s.D);
+    c->l2_mode = (flags & NSD_FLAG_NO_L2_EXCHANGE) ? 0 : 1;
     return NSD_OK;
 }
 

@@ -74,7 +74,7 @@ class ModelSpec:
 
     @property
     def seq_flags(self) -> int:
-        return _lib.NSD_FLAG_BIDIR if self.D == 2 else 0
+        return (_lib.NSD_FLAG_BIDIR if self.D == 2 else 0) | _seq_extra_flags
 
     def seq_path(self, B: int = 32, T: int = 1) -> bool:
         """True where the sequence-batched bf16 path (nsd_seq_*) covers this model (H in 64/128/256/512, F, K <= 64)."""
@@ -110,6 +110,13 @@ _launch_hook = None
 
 
 _extra_flags = 0
+_seq_extra_flags = 0
+
+
+def set_seq_l2_exchange(on: bool) -> None:
+    """Sequence-batched path, diagnostics: off = scan groups always use the write-through exchange (NSD_FLAG_NO_L2_EXCHANGE)."""
+    global _seq_extra_flags
+    _seq_extra_flags = 0 if on else _lib.NSD_FLAG_NO_L2_EXCHANGE
 
 
 def set_gemm_bf16(on: bool) -> None:

@@ -196,3 +196,28 @@ def test_seq_train_with_counter_streams_matches_oracle_with_the_same_masks(nsd, 
     assert ops.seq_status(ws) == 0
     assert np.abs(logits.cpu().numpy() - fw["logits"]).max() < SEQ_LOGIT_TOL
     _grad_check(g.cpu().numpy(), g_ref, d)
+
+
+def test_seq_exchange_modes_agree(nsd, dev):
+    """Scan groups whose workgroups report one XCD exchange through that L2 (plain stores), other groups write through; the
+    diagnostic flag NSD_FLAG_NO_L2_EXCHANGE forces the write-through protocol everywhere.  Both must give the same bits."""
+    from nsd_amd import ops
+    H, L, K, B, T = 256, 2, 5, 96, 40
+    d = orc.Dims(C=8, H=H, L=L, K=K)
+    spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+    st = synth_params(8, H, L, K, seed=5)
+    x, y = synth_x(B, T, seed=2), synth_labels(B, K, seed=2)
+    flat = _flat(st, d, dev)
+    xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    out = []
+    for on in (True, False):
+        ops.set_seq_l2_exchange(on)
+        try:
+            ws = ops.seq_workspace(spec, B, T, dev)
+            lg = ops.seq_train_fwd(spec, flat, xt, yt, ws).clone()
+            g = ops.seq_train_bwd(spec, flat, ws, B, T).clone()
+            assert ops.seq_status(ws) == 0
+            out.append((lg, g))
+        finally:
+            ops.set_seq_l2_exchange(True)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
