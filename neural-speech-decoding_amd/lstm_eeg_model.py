@@ -29,18 +29,22 @@ CLASS_NAMES = ["Food", "Water", "BG-Noise"]   # verbatim from lstm_eeg_model.py:
 class _StackedLSTMParams(nn.Module):
     """Parameter container with torch.nn.LSTM's parameter names, shapes and default init."""
 
-    def __init__(self, input_size: int, hidden_size: int, num_layers: int):
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int, bidirectional: bool = False):
         super().__init__()
         self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.bidirectional = bool(bidirectional)
         k = 1.0 / math.sqrt(hidden_size)
+        D = 2 if bidirectional else 1
         for l in range(num_layers):
-            I = input_size if l == 0 else hidden_size
-            for name, shape in ((f"weight_ih_l{l}", (4 * hidden_size, I)), (f"weight_hh_l{l}", (4 * hidden_size, hidden_size)),
-                                (f"bias_ih_l{l}", (4 * hidden_size,)), (f"bias_hh_l{l}", (4 * hidden_size,))):
-                self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+            I = input_size if l == 0 else D * hidden_size
+            for sfx in (("", "_reverse") if bidirectional else ("",)):         # torch.nn.LSTM's registration order
+                for name, shape in ((f"weight_ih_l{l}{sfx}", (4 * hidden_size, I)), (f"weight_hh_l{l}{sfx}", (4 * hidden_size, hidden_size)),
+                                    (f"bias_ih_l{l}{sfx}", (4 * hidden_size,)), (f"bias_hh_l{l}{sfx}", (4 * hidden_size,))):
+                    self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
 
     def extra_repr(self) -> str:
-        return f"{self.input_size}, {self.hidden_size}, num_layers={self.num_layers}, batch_first=True"
+        return (f"{self.input_size}, {self.hidden_size}, num_layers={self.num_layers}, batch_first=True"
+                + (", bidirectional=True" if self.bidirectional else ""))
 
 
 class _EEGFunction(torch.autograd.Function):
@@ -74,27 +78,70 @@ class _EEGFunction(torch.autograd.Function):
         return (None, None, None) + grads
 
 
+class _EEGSeqFunction(torch.autograd.Function):
+    """Whole-model autograd node on the sequence-batched bf16 path (nsd_seq_*): x, parameters -> logits; backward needs
+    d loss / d logits of a mean cross-entropy, which that path fuses into the forward -- so the node takes the labels
+    and returns (logits, loss) with loss the mean CE the kernels computed, and only `loss.backward()` (times a scalar) is
+    supported.  The Trainer calls the ops directly; this node exists so that the nn.Module surface works too."""
+
+    @staticmethod
+    def forward(ctx, module: "EEG_LSTM", x: torch.Tensor, labels: torch.Tensor, rng, *params):
+        spec, flat = module.spec, module._flat
+        B, T, _ = x.shape
+        ws = ops.seq_workspace(spec, B, T, x.device)
+        logits = ops.seq_train_fwd(spec, flat, x, labels, ws, rng=rng)
+        loss = ops.seq_loss_sum(spec, ws, B, T) / B
+        ctx.module, ctx.ws, ctx.rng, ctx.shape = module, ws, rng, (B, T)
+        ctx.mark_non_differentiable(logits)
+        return logits, loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, _dlogits, dloss):
+        module = ctx.module
+        spec = module.spec
+        B, T = ctx.shape
+        g = ops.seq_train_bwd(spec, module._flat, ctx.ws, B, T, rng=ctx.rng) * dloss
+        offs, shapes = spec.offsets(), spec.shapes()
+        grads = tuple(g[offs[n]:offs[n] + math.prod(shapes[n])].view(shapes[n]) for n in spec.names())
+        ctx.ws = None
+        return (None, None, None, None) + grads
+
+
 class EEG_LSTM(nn.Module):
     """2-layer LSTM -> attention pooling over time -> LayerNorm -> Linear/RReLU/Dropout/Linear.
 
     Signature and defaults of the reference (lstm_eeg_model.py:14).  Keyword-only extensions, all
     default OFF so that reference checkpoints reproduce reference logits:
-      residual   add the layer input to the output of every LSTM layer l>=1 (README's "residual stack")
-      normalize  per-channel z-score of the window before the LSTM (Frontend/app.py:166-170 semantics)
+      residual       add the layer input to the output of every LSTM layer l>=1 (README's "residual stack")
+      normalize      per-channel z-score of the window before the LSTM (Frontend/app.py:166-170 semantics)
+      bidirectional  torch.nn.LSTM(bidirectional=True) where lstm_eeg_model.py:16-22 builds the LSTM: `_reverse`
+                     parameters in torch's order, the attention pooling / LayerNorm / fc.0 act on 2H columns (BASELINE cfg5)
+      precision      "fp32" (default) or "bf16": the sequence-batched path for hidden sizes 64/128/256/512 (BASELINE cfg3 /
+                     cfg5) -- bf16 GEMM operands and saved activations, fp32 accumulation and cell state; logits differ
+                     from an fp32 run at the 1e-2 level.  bidirectional needs "bf16".
     """
 
     def __init__(self, input_size=8, hidden_size=48, num_layers=2, num_classes=3, dropout=0.60, *,
-                 residual: bool = False, normalize: bool = False):
+                 residual: bool = False, normalize: bool = False, bidirectional: bool = False, precision: str = "fp32"):
         super().__init__()
-        self.spec = ops.ModelSpec(C=input_size, H=hidden_size, L=num_layers, K=num_classes, F=ops.FC_HIDDEN)
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision={precision!r}: expected 'fp32' or 'bf16'")
+        self.spec = ops.ModelSpec(C=input_size, H=hidden_size, L=num_layers, K=num_classes, F=ops.FC_HIDDEN,
+                                  D=2 if bidirectional else 1)
+        self.precision = precision
+        if bidirectional and precision != "bf16":
+            raise ValueError("bidirectional=True is built on the sequence-batched path only: pass precision='bf16'")
+        if precision == "bf16" and residual:
+            raise ValueError("the residual extension is not available with precision='bf16'")
         self.dropout_p = float(dropout) if num_layers > 1 else 0.0   # nn.LSTM drops only between layers (:21)
         self.head_dropout_p = float(dropout)
         self.residual, self.normalize = bool(residual), bool(normalize)
-        self.lstm = _StackedLSTMParams(input_size, hidden_size, num_layers)
-        self.ln = nn.LayerNorm(hidden_size)
-        self.attn = nn.Linear(hidden_size, 1)
+        self.lstm = _StackedLSTMParams(input_size, hidden_size, num_layers, bidirectional)
+        DH = self.spec.D * hidden_size
+        self.ln = nn.LayerNorm(DH)
+        self.attn = nn.Linear(DH, 1)
         self.fc = nn.Sequential(
-            nn.Linear(hidden_size, ops.FC_HIDDEN),
+            nn.Linear(DH, ops.FC_HIDDEN),
             nn.RReLU(),
             nn.Dropout(dropout),
             nn.Linear(ops.FC_HIDDEN, num_classes),
@@ -167,6 +214,15 @@ class EEG_LSTM(nn.Module):
         if self.normalize:
             x = ops.zscore(x)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self.precision == "bf16":
+            if not self.spec.seq_path(max(x.shape[0], 1), x.shape[1]):
+                raise NsdError(f"precision='bf16': model shape {self.spec} is not covered by the sequence-batched path "
+                               "(hidden size 64/128/256/512, fc width and classes <= 64)")
+            if self.training or need_grad:
+                raise NsdError("precision='bf16': training goes through EEG_LSTM.loss(x, labels) or nsd_amd.trainer.Trainer "
+                               "(the path fuses the cross-entropy into the forward); forward() serves eval mode")
+            logits, _ = ops.seq_infer(self.spec, flat, x, want_probs=False)
+            return logits
         if not self.training and not need_grad:
             logits, _ = ops.infer(self.spec, flat, x, residual=self.residual, want_probs=False)
             return logits
@@ -174,12 +230,32 @@ class EEG_LSTM(nn.Module):
         params = [p for _, p in self._named_in_order()]
         return _EEGFunction.apply(self, x, masks, *params)
 
+    def loss(self, x: torch.Tensor, labels: torch.Tensor):
+        """precision='bf16' training surface: (logits, mean cross-entropy) with the loss differentiable w.r.t. the
+        parameters -- `model.loss(x, y)[1].backward()` fills `.grad` of all tensors.  Train mode draws the dropout / RReLU
+        streams inside the kernels."""
+        if self.precision != "bf16":
+            raise NsdError("EEG_LSTM.loss is the bf16 path's training surface; with precision='fp32' use "
+                           "torch.nn.functional.cross_entropy(model(x), y)")
+        flat = self.flat_parameters()
+        x = x.contiguous().float()
+        if self.normalize:
+            x = ops.zscore(x)
+        rng = None
+        if self.training:
+            self._step += 1
+            rng = dict(seed=self._seed, base_stream=4 * self._step, p_lstm=self.dropout_p, p_head=self.head_dropout_p)
+        params = [p for _, p in self._named_in_order()]
+        return _EEGSeqFunction.apply(self, x, labels.to(torch.int32).contiguous(), rng, *params)
+
     @torch.no_grad()
     def predict_proba(self, x: torch.Tensor) -> torch.Tensor:
         """Eval-mode class probabilities with the softmax fused into the head kernel (lstm_eeg_model.py:97)."""
         x = x.contiguous().float()
         if self.normalize:
             x = ops.zscore(x)
+        if self.precision == "bf16":
+            return ops.seq_infer(self.spec, self.flat_parameters(), x, want_probs=True)[1]
         _, probs = ops.infer(self.spec, self.flat_parameters(), x, residual=self.residual, want_probs=True)
         return probs
 

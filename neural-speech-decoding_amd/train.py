@@ -50,6 +50,9 @@ def main(argv=None) -> int:
     ap.add_argument("--weight-decay", type=float, default=0.0)
     ap.add_argument("--hidden", type=int, default=48)
     ap.add_argument("--dropout", type=float, default=0.60)
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"),
+                    help="bf16: the sequence-batched path (hidden 64/128/256/512; BASELINE cfg3 = --hidden 256 --classes 5 --precision bf16)")
+    ap.add_argument("--bidirectional", action="store_true", help="bidirectional LSTM (needs --precision bf16)")
     ap.add_argument("--val-fraction", type=float, default=0.2)
     ap.add_argument("--normalize", action="store_true", help="per-channel z-score of each window (app.py:166-170)")
     ap.add_argument("--seed", type=int, default=0)
@@ -84,7 +87,8 @@ def main(argv=None) -> int:
     y_all = torch.from_numpy(y_np).to(dev)
 
     torch.manual_seed(args.seed)          # (Trainer also broadcasts rank 0's parameters when world > 1)
-    model = EEG_LSTM(8, args.hidden, 2, args.classes, args.dropout, normalize=args.normalize).to(dev).train()
+    model = EEG_LSTM(8, args.hidden, 2, args.classes, args.dropout, normalize=args.normalize, precision=args.precision,
+                     bidirectional=args.bidirectional).to(dev).train()
     trainer = Trainer(model, lr=args.lr, weight_decay=args.weight_decay, seed=args.seed + 1)
     tr_dev = torch.from_numpy(tr_idx).to(dev)
 

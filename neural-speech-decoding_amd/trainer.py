@@ -165,6 +165,22 @@ class Trainer:
         from . import _lib
         sp = self.spec
         B, T, _ = x.shape
+        if self.model.precision == "bf16":
+            # sequence-batched path: forward (+ head, CE, head backward), backward (+ all parameter gradients), Adam
+            key = ("seq", B, T)
+            if key not in self._bufs:
+                self._bufs = {key: {"ws": ops.seq_workspace(sp, B, T, self.flat.device),
+                                    "logits": torch.empty((B, sp.K), dtype=torch.float32, device=self.flat.device)}}
+            buf = self._bufs[key]
+            rng = None
+            if self.stochastic:
+                rng = dict(seed=self.seed, base_stream=(self.step_count & 0x3FFFFFFF) * 4, p_lstm=self.model.dropout_p,
+                           p_head=self.model.head_dropout_p)
+            ops.seq_train_fwd(sp, self.flat, x, y, buf["ws"], rng=rng, scale=scale, logits=buf["logits"])
+            ops.seq_train_bwd(sp, self.flat, buf["ws"], B, T, rng=rng, grads=self.grads)
+            if fuse_adam:
+                self._adam()
+            return
         buf = self._buffers(B, T)
         L = _lib.lib()
         st = torch.cuda.current_stream().cuda_stream
@@ -265,10 +281,22 @@ class Trainer:
         self._last_B, self._last_T = B, T
 
     @_on_own_device
+    def scan_status(self) -> int:
+        """precision='bf16' only: 0 unless a scan group of the last step timed out (see nsd_seq_status).  Synchronises."""
+        for key, buf in self._bufs.items():
+            if key[0] == "seq":
+                return ops.seq_status(buf["ws"])
+        return 0
+
+    @_on_own_device
     def last_loss(self) -> float:
         """Mean CE loss of this rank's shard in the most recent step (synchronises)."""
         if not self._last_B:
             return float("nan")
+        if self.model.precision == "bf16":
+            ws = self._bufs[("seq", self._last_B, self._last_T)]["ws"]
+            ops.seq_loss_sum(self.spec, ws, self._last_B, self._last_T, out=self._loss)
+            return float(self._loss.item()) / self._last_B
         ws = self._buffers(self._last_B, self._last_T)["ws"]
         ops.loss_sum(self.spec, ws, self._last_B, self._last_T, out=self._loss)
         return float(self._loss.item()) / self._last_B

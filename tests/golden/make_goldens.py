@@ -38,6 +38,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 
 SYNTH_SHAPES = [(32, 250), (256, 250), (1, 625), (7, 33)]
 CFG3_STRIDE = 97
+# bidirectional goldens (extension, oracle = torch): tag -> (C, H, L, K, B, T)
+BIDIR_CASES = {"bi64": (8, 64, 2, 3, 6, 20), "bi128c64": (64, 128, 2, 5, 5, 12), "bi64L1": (8, 64, 1, 3, 4, 9)}
 X_STD = 2.7  # dataset global std is 2.73
 
 
@@ -52,17 +54,21 @@ def synth_labels(B, K=3, seed=1234):
     return np.random.RandomState(seed + 7919).randint(0, K, size=B).astype(np.int32)
 
 
-def synth_params(C, H, L, K, F=32, seed=99):
-    """torch-default-like init U(-1/sqrt(fan), 1/sqrt(fan)); LayerNorm (1,0).  name -> array."""
+def synth_params(C, H, L, K, F=32, seed=99, D=1):
+    """torch-default-like init U(-1/sqrt(fan), 1/sqrt(fan)); LayerNorm (1,0).  name -> array, in torch's state_dict order
+    (D = 2: bidirectional, `_reverse` tensors after the forward ones of each layer; layers > 0 and the head see D*H columns)."""
     rs = np.random.RandomState(seed)
     st = {}
     k = 1.0 / np.sqrt(H)
+    DH = D * H
     for l in range(L):
-        I = C if l == 0 else H
-        st[f"lstm.weight_ih_l{l}"] = rs.uniform(-k, k, (4 * H, I)).astype(np.float32)
-        st[f"lstm.weight_hh_l{l}"] = rs.uniform(-k, k, (4 * H, H)).astype(np.float32)
-        st[f"lstm.bias_ih_l{l}"] = rs.uniform(-k, k, (4 * H,)).astype(np.float32)
-        st[f"lstm.bias_hh_l{l}"] = rs.uniform(-k, k, (4 * H,)).astype(np.float32)
+        I = C if l == 0 else DH
+        for sfx in (("",) if D == 1 else ("", "_reverse")):
+            st[f"lstm.weight_ih_l{l}{sfx}"] = rs.uniform(-k, k, (4 * H, I)).astype(np.float32)
+            st[f"lstm.weight_hh_l{l}{sfx}"] = rs.uniform(-k, k, (4 * H, H)).astype(np.float32)
+            st[f"lstm.bias_ih_l{l}{sfx}"] = rs.uniform(-k, k, (4 * H,)).astype(np.float32)
+            st[f"lstm.bias_hh_l{l}{sfx}"] = rs.uniform(-k, k, (4 * H,)).astype(np.float32)
+    H = DH
     st["ln.weight"] = (1.0 + 0.1 * rs.standard_normal(H)).astype(np.float32)
     st["ln.bias"] = (0.1 * rs.standard_normal(H)).astype(np.float32)
     st["attn.weight"] = rs.uniform(-k, k, (1, H)).astype(np.float32)
@@ -214,6 +220,54 @@ def main():
             ext["cfg3.gradnorm." + k] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
         else:
             ext["cfg3.grad." + k] = g.copy()
+    # the same cfg3 model at B=16 (a whole MFMA batch tile is exercised from B >= 16 on): logits, loss, all gradients of
+    # the small tensors, strided samples + norms of the big ones
+    x16 = torch.from_numpy(synth_x(16, 250, seed=4))
+    y16 = torch.from_numpy(synth_labels(16, K=5, seed=4).astype(np.int64))
+    m3.zero_grad()
+    lg16 = m3(x16)
+    loss16 = Fnn.cross_entropy(lg16, y16)
+    loss16.backward()
+    ext["cfg3b16.logits"] = lg16.detach().numpy()
+    ext["cfg3b16.loss"] = np.array(loss16.item(), np.float32)
+    for k, p in m3.named_parameters():
+        g = p.grad.numpy()
+        if g.size > 20000:
+            ext["cfg3b16.gradsample." + k] = g.ravel()[::CFG3_STRIDE].copy()
+            ext["cfg3b16.gradnorm." + k] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        else:
+            ext["cfg3b16.grad." + k] = g.copy()
+    # bidirectional (BASELINE cfg5's structure at a small size): the reference class cannot express it; oracle = stock torch
+    # nn.LSTM(bidirectional=True) + the reference's own head on the 2H-wide sequence ("extension, oracle = torch").
+    # Parameters come from synth_params(..., D=2) (numpy, regenerated in the tests): only outputs are stored.
+    for tag, (Cb, Hb, Lb, Kb, Bb, Tb) in BIDIR_CASES.items():
+        stb = synth_params(Cb, Hb, Lb, Kb, seed=70 + Hb, D=2)
+        lstm = torch.nn.LSTM(Cb, Hb, Lb, batch_first=True, bidirectional=True)
+        lstm.load_state_dict({k[len("lstm."):]: torch.from_numpy(v) for k, v in stb.items() if k.startswith("lstm.")}, strict=True)
+        t = {k: torch.from_numpy(v).requires_grad_(True) for k, v in stb.items() if not k.startswith("lstm.")}
+        xb = torch.from_numpy(synth_x(Bb, Tb, C=Cb, seed=60))
+        yb = torch.from_numpy(synth_labels(Bb, K=Kb, seed=60).astype(np.int64))
+        out, _ = lstm(xb)
+        w = torch.softmax((out @ t["attn.weight"].t()).squeeze(-1) + t["attn.bias"], dim=1)
+        pooled = (out * w.unsqueeze(-1)).sum(dim=1)
+        z = Fnn.layer_norm(pooled, (2 * Hb,), t["ln.weight"], t["ln.bias"], 1e-5) @ t["fc.0.weight"].t() + t["fc.0.bias"]
+        slope = (0.125 + 1.0 / 3.0) / 2.0
+        lgb = torch.where(z >= 0, z, z * slope) @ t["fc.3.weight"].t() + t["fc.3.bias"]      # eval-mode RReLU, no dropout
+        lossb = Fnn.cross_entropy(lgb, yb)
+        lossb.backward()
+        ext[f"{tag}.logits"] = lgb.detach().numpy()
+        ext[f"{tag}.loss"] = np.array(lossb.item(), np.float32)
+        ext[f"{tag}.alpha"] = w.detach().numpy()
+        ext[f"{tag}.out_t0_tlast"] = out.detach().numpy()[:, [0, Tb - 1], :]
+        grads = {"lstm." + k: v.grad.numpy() for k, v in lstm.named_parameters()}
+        grads.update({k: v.grad.numpy() for k, v in t.items()})
+        assert list(grads) == list(stb), (list(grads), list(stb))             # torch's state_dict order == synth_params order
+        for k, g in grads.items():
+            if g.size > 5000:
+                ext[f"{tag}.gradsample.{k}"] = g.ravel()[::CFG3_STRIDE].copy()
+                ext[f"{tag}.gradnorm.{k}"] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            else:
+                ext[f"{tag}.grad.{k}"] = g.copy()
     # one-layer and three-layer variants of the reference class (num_layers is a ctor kwarg)
     for Lx in (1, 3):
         stl = synth_params(8, 48, Lx, 3, seed=20 + Lx)
