@@ -1,28 +1,40 @@
 #!/usr/bin/env python3
 """EEG-trials/sec of the train step (fwd + bwd + Adam [+ gradient all-reduce]) on N MI355X.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 50 --warmup 10                      # BASELINE configs[1] ("cfg2"), the default
+    python bench.py --config cfg3                                        # K=5, H=256, B=1024, bf16 (sequence-batched path)
+    python bench.py --config cfg5 --steps 5 --warmup 2                   # C=64, T=1000, H=512 bidirectional, B=512 per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload at N=1 = BASELINE.json configs[1] ("cfg2"): the reference's 3-class model (C=8, H=48, L=2, K=3,
-fp32, the reference checkpoint's weights when tests/golden/weights_3class.npz is present), synthetic
-windows x = 2.7*N(0,1) of 8 ch x 250 steps, batch 256 per GPU, dropout 0.6 + RReLU noise ON (they are
-part of the reference's train() step).  For N>1 every rank keeps 256 trials (weak scaling) and the flat
-gradient (127 KB) is summed with one RCCL all-reduce per step.
+Workloads (synthetic windows x = 2.7*N(0,1), labels uniform; dropout 0.6 + RReLU noise ON: they are part of the reference's
+train() step; inputs resident in HBM before the timed region; every rank keeps the per-GPU batch = weak scaling; the flat
+gradient is summed with ONE RCCL all-reduce per step):
+  cfg2  the reference's 3-class model (C=8, H=48, L=2, K=3, fp32, reference checkpoint weights), 250-step windows, 256 trials/GPU
+  cfg4  the same model at 1024 trials/GPU (BASELINE configs[3]'s per-GPU share of a global batch of 8192)
+  cfg3  5-class model, H=256, 1024 trials/GPU, bf16 operands / fp32 accumulation (BASELINE configs[2])
+  cfg5  64 channels x 1000 steps, 2-layer bidirectional LSTM, H=512, 512 trials/GPU, bf16 (BASELINE configs[4] per GPU)
 
-One JSON line on rank 0.  Besides the driver's contract it carries
-  roofline      for the dominant kernel (longest average launch): algorithmic FLOP per launch / measured
-                launch time against the fp32 peak (157.3 TFLOP/s; vector == f32-MFMA rate on gfx950), with
-                the HBM view next to it (algorithmic bytes per launch / time against 8 TB/s)
-  cpu_baseline  the same train step on PyTorch-CPU (oneDNN LSTM, all host cores), bounded to ~15 s
+ONE JSON line on rank 0.  Besides the driver's contract it carries
+  preheat_steps untimed steps run before the W warm-up steps (GPU clock ramp)
+  step_ms_events    median / min of the per-step duration measured with HIP events on the launch stream (second loop)
+  roofline      dominant kernel (longest average launch): algorithmic FLOP per launch / its launch time measured live with
+                HIP events on the launch stream, against the peak of the arithmetic it runs on; HBM view beside it;
+                `traffic` from the committed rocprofv3 PMC passes IF they were taken on the kernel sources of this tree
+  cpu_baseline  the same train step on PyTorch-CPU (the reference module's structure on stock nn.LSTM / oneDNN), all host
+                cores, bounded; `one_thread` row beside it
+  inference / T625   (cfg2, one GPU) inference trials/s at B=256,T=250, single-window latency at the real 625-sample shape,
+                and the train step at T=625
 """
 from __future__ import annotations
 
 import argparse
 import contextlib
+import glob
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,28 +46,73 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: fp32 vector == fp32 matrix rate; dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+CONFIGS = {
+    "cfg2": dict(C=8, H=48, L=2, K=3, T=250, B=256, precision="fp32", bidirectional=False, dtype="f32",
+                 text="cfg2: 3-class EEG_LSTM train step (dropout 0.6 + RReLU noise, CE, Adam), 8ch x 250-step windows, H=48 L=2 fp32"),
+    "cfg4": dict(C=8, H=48, L=2, K=3, T=250, B=1024, precision="fp32", bidirectional=False, dtype="f32",
+                 text="cfg4 per-GPU share: the cfg2 model at 1024 trials per GPU (global batch 8192 on 8 GPUs)"),
+    "cfg3": dict(C=8, H=256, L=2, K=5, T=250, B=1024, precision="bf16", bidirectional=False, dtype="bf16",
+                 text="cfg3: 5-class EEG_LSTM train step (dropout 0.6 + RReLU noise, CE, Adam), 8ch x 250-step windows, H=256 L=2, "
+                      "bf16 GEMM operands and saved activations, fp32 accumulation / cell state"),
+    "cfg5": dict(C=64, H=512, L=2, K=5, T=1000, B=512, precision="bf16", bidirectional=True, dtype="bf16",
+                 text="cfg5 per-GPU share: 64ch x 1000-step windows, 2-layer bidirectional LSTM H=512 (global batch 4096 on 8 GPUs), "
+                      "bf16 GEMM operands and saved activations, fp32 accumulation / cell state"),
+}
+# sources whose hash ties a recorded PMC traffic file to the kernels it was measured on
+KERNEL_SOURCES = {
+    "fp32": ["nsd_lstm2_fwd48.hip", "nsd_lstm2_bwd48.hip", "nsd_common.h", "nsd_args.h", "nsd_prof.h"],
+    "bf16": ["nsd_scan.hip", "nsd_gemm_bf16.hip", "nsd_head_tm.hip", "nsd_seq.hip", "nsd_seq.h", "nsd_bf16.h", "nsd_common.h"],
+}
 
 
-TRAFFIC_FILE = "r01_v10_hbm_traffic.json"      # written by tools/pmc_run.sh + tools/pmc_summarize.py for the current kernels
+def kernel_source_hash(precision: str) -> str:
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES[precision]:
+        h.update(open(os.path.join(ROOT, "neural-speech-decoding_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
-def algorithmic_per_trial(T, C, H, L=2, K=3):
-    """SURVEY 8(d) contract figures for the fp32 H=48 path (per trial)."""
-    macs_step = 0
-    for l in range(L):
-        I = C if l == 0 else H
-        macs_step += 4 * H * (I + H)
-    fwd_flop = 2 * T * macs_step + 2 * T * H * 2
+def recorded_traffic(config: str, precision: str, kernel: str, B: int, T: int):
+    """HBM bytes per launch of `kernel` from the newest profiles/*_hbm_traffic.json taken for this config, batch and on
+    exactly these kernel sources; (None, reason) otherwise -- a stale file is never quoted."""
+    want = kernel_source_hash(precision)
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        try:
+            j = json.load(open(p))
+        except Exception:
+            continue
+        if j.get("config") != config or j.get("B") != B or j.get("T") != T:
+            continue
+        if j.get("source_sha256") != want:
+            best = best or (None, f"{os.path.basename(p)} was measured on other kernel sources: not quoted")
+            continue
+        e = j.get("kernels", {}).get(kernel)
+        if e:
+            best = (e["hbm_bytes_per_launch_corrected"], f"profiles/{os.path.basename(p)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                                                         f"separate passes; kernel sources sha256 {want[:12]})")
+    return best or (None, "no recorded PMC pass for this config / batch")
+
+
+def algorithmic(cfg, B, T):
+    """SURVEY 8(d) contract figures, per launch of the forward / backward recurrence kernel and per train step."""
+    C, H, L, K = cfg["C"], cfg["H"], cfg["L"], cfg["K"]
+    D = 2 if cfg["bidirectional"] else 1
+    s_a = 2 if cfg["precision"] == "bf16" else 4
+    macs_step = sum(D * 4 * H * ((C if l == 0 else D * H) + H) for l in range(L))
+    fwd_flop = 2 * T * macs_step + 2 * T * D * H * 2
     x_bytes = T * C * 4
-    hc_bytes = L * T * 2 * H * 4            # h and c per layer-step
-    return {
-        "flop_fwd": fwd_flop, "flop_bwd": 2 * fwd_flop, "flop_train": 3 * fwd_flop,
-        "bytes_fwd_kernel": x_bytes + hc_bytes,            # x read, h/c written once
-        "bytes_bwd_kernel": x_bytes + hc_bytes,            # x read again (dW_ih), h/c read once
-        "bytes_train": 2 * x_bytes + 2 * hc_bytes + K * 4,
-    }
+    hc = L * D * T * 2 * H * s_a                              # h and c per layer-direction-step
+    out = {"flop_train": 3 * fwd_flop * B, "bytes_train": (2 * x_bytes + 2 * hc + K * 4) * B}
+    if cfg["precision"] == "fp32":                          # one launch = both layers, all steps
+        out.update(fwd_flop=fwd_flop * B, bwd_flop=2 * fwd_flop * B, fwd_bytes=(x_bytes + hc) * B, bwd_bytes=(x_bytes + hc) * B)
+    else:                                                   # one scan launch = one layer (all directions): the recurrent product
+        rec = 2 * T * D * 4 * H * H
+        out.update(fwd_flop=rec * B, bwd_flop=rec * B, fwd_bytes=D * T * 2 * H * s_a * B, bwd_bytes=D * T * 2 * H * s_a * B)
+    return out
 
 
 class KernelTimer:
@@ -80,22 +137,34 @@ class KernelTimer:
         return {n: (1e3 * sum(a.elapsed_time(b) for a, b in ev) / len(ev)) if ev else None for n, ev in self.events.items()}
 
 
+def event_times_ms(fn, n):
+    """Per-call durations of n calls of fn measured with HIP events on the current stream (calls issued back to back)."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in evs]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)      # the GPU clock ramps over the first tens of steps
-    ap.add_argument("--batch-per-gpu", type=int, default=256)
-    ap.add_argument("--T", type=int, default=250)
-    ap.add_argument("--preheat-steps", type=int, default=500, help="untimed steps before the warm-up steps (GPU clock ramp, ~0.15 s)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--T", type=int, default=None)
+    ap.add_argument("--preheat-steps", type=int, default=None, help="untimed steps before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as captured hipGraphs (Trainer.step_static).  Measured on MI355X: a replay costs more "
-                         "than the eager launches it replaces for this 0.33 ms / 8-kernel step (the host runs ahead), so eager is "
-                         "the default")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events and the extra points")
+    ap.add_argument("--no-extras", action="store_true", help="skip the inference / T=625 points")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    small = cfg["precision"] == "fp32"
+    steps = args.steps if args.steps is not None else (200 if small else 20)
+    warmup = args.warmup if args.warmup is not None else (50 if small else 5)
+    preheat = args.preheat_steps if args.preheat_steps is not None else (500 if small else 10)
 
     import nsd_amd
     from nsd_amd import ops
@@ -113,15 +182,16 @@ def main():
     dev = torch.device("cuda", local)
     nsd_amd.load_library()
 
-    B, T, C, H, L, K = args.batch_per_gpu, args.T, 8, 48, 2, 3
-    model = nsd_amd.EEG_LSTM(C, H, L, K, dropout=0.60)
+    B, T = args.batch_per_gpu or cfg["B"], args.T or cfg["T"]
+    C, H, L, K = cfg["C"], cfg["H"], cfg["L"], cfg["K"]
+    torch.manual_seed(4321)                       # identical initial weights on every rank (the Trainer broadcasts rank 0's anyway)
+    model = nsd_amd.EEG_LSTM(C, H, L, K, dropout=0.60, precision=cfg["precision"], bidirectional=cfg["bidirectional"])
     wpath = os.path.join(ROOT, "tests", "golden", "weights_3class.npz")
-    if os.path.exists(wpath):
+    weights = "seeded default init (torch.manual_seed(4321))"
+    if args.config in ("cfg2", "cfg4") and os.path.exists(wpath):
         w = np.load(wpath)
         model.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files}, strict=True)
         weights = "reference checkpoint"
-    else:
-        weights = "random init"
     model.to(dev).train()
     trainer = Trainer(model, lr=1e-3, seed=1234, stochastic=True)
 
@@ -129,33 +199,24 @@ def main():
     x = (2.7 * torch.randn(B, T, C, generator=g)).to(dev)
     y = torch.randint(0, K, (B,), generator=g).to(torch.int32).to(dev)
 
-    timer = None
-    if not args.no_kernel_timing:
-        timer = KernelTimer(["nsd_lstm_head_train_rng", "nsd_lstm_head_train", "nsd_lstm_fwd", "nsd_lstm_bwd_rng", "nsd_lstm_bwd",
-                             "nsd_head_train", "nsd_grad_reduce", "nsd_grad_reduce_adam", "nsd_adam_step"])
-
     def note(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    use_graph = args.graph
-    if use_graph:
-        xs, ys = trainer.static_inputs(B, T)        # inputs resident in HBM before the timed region
-        xs.copy_(x); ys.copy_(y)
-        do_step = lambda: trainer.step_static(B, T)
-    else:
-        do_step = lambda: trainer.step(x, y)
-    # clock ramp: the GPU reaches its sustained clock only after some tens of milliseconds of load; run the same step
-    # untimed first (library load, allocator and RCCL set-up happen here too), then the W warm-up steps.  A FIXED number
-    # of steps, not a time budget: with more than one rank every step contains a collective, so all ranks must run
-    # exactly the same number of them.
-    for _ in range(max(args.preheat_steps, 0)):
+    do_step = lambda: trainer.step(x, y)
+    # clock ramp: the GPU reaches its sustained clock only after some tens of milliseconds of load; run the same step untimed
+    # first (library load, allocator and RCCL set-up happen here too), then the W warm-up steps.  A FIXED number of steps, not
+    # a time budget: with more than one rank every step contains a collective, so all ranks must run the same number of them.
+    for _ in range(max(preheat, 0)):
         do_step()
     torch.cuda.synchronize()
-    note(f"warm-up: {args.warmup} steps of B={B}/GPU T={T} on {world} GPU(s), {'hipGraph replay' if use_graph else 'eager launches'}")
-    for _ in range(max(args.warmup, 1)):
+    note(f"{args.config}: warm-up {warmup} steps of B={B}/GPU T={T} on {world} GPU(s)")
+    for _ in range(max(warmup, 1)):
         do_step()
     torch.cuda.synchronize()
+    if trainer.scan_status() != 0:
+        print(f"bench.py: scan status {trainer.scan_status()} (a scan group timed out): results invalid", file=sys.stderr)
+        sys.exit(3)
     note("timing")
 
     def barrier():
@@ -165,20 +226,33 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         do_step()
     barrier()
     dt = time.perf_counter() - t0
     loss = trainer.last_loss()
-    # per-kernel launch times: HIP events around each C-ABI launch on the launch stream, over the same K steps issued
-    # one by one right after the timed region (events cannot be recorded inside a graph replay); the profiles/ rocprofv3
-    # summary of the same command is the cross-check
-    if timer:
-        ops.set_launch_hook(timer)
-        for _ in range(args.steps):
-            trainer.step(x, y)
-        torch.cuda.synchronize()
-        ops.set_launch_hook(None)
+
+    # second loop of the same K steps: per-step HIP events + per-kernel HIP events on the launch stream (kept out of the
+    # timed region so that recording does not perturb `value`); profiles/ holds the rocprofv3 summary of the same command
+    step_ms, kern_us = None, {}
+    if not args.no_kernel_timing:
+        step_ms = event_times_ms(do_step, steps)
+        if small:
+            timer = KernelTimer(["nsd_lstm_head_train_rng", "nsd_lstm_head_train", "nsd_lstm_fwd", "nsd_lstm_bwd_rng", "nsd_lstm_bwd",
+                                 "nsd_head_train", "nsd_grad_reduce", "nsd_grad_reduce_adam", "nsd_adam_step"])
+            ops.set_launch_hook(timer)
+            for _ in range(steps):
+                do_step()
+            torch.cuda.synchronize()
+            ops.set_launch_hook(None)
+            kern_us = {k: v for k, v in timer.mean_us().items() if v is not None}
+        else:
+            ops.seq_profile(True)
+            for _ in range(steps):
+                do_step()
+            torch.cuda.synchronize()
+            kern_us = {k: 1e3 * ms / n for k, (ms, n) in ops.seq_profile_read().items() if n}
+            ops.seq_profile(False)
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -186,66 +260,101 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        alg = algorithmic_per_trial(T, C, H, L, K)
-        ms_per_step = 1e3 * dt / args.steps
-        value = world * B * args.steps / dt
+        alg = algorithmic(cfg, B, T)
+        peak = PEAK_TFLOPS[cfg["dtype"]]
+        ms_per_step = 1e3 * dt / steps
+        value = world * B * steps / dt
         out = {
             "metric": "EEG-trials/sec (train fwd+bwd)", "value": round(value, 1), "unit": "trials/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg2: 3-class EEG_LSTM train step (dropout 0.6 + RReLU noise, CE, Adam), "
-                                   f"8ch x {T}-step windows, batch {B}/GPU, H=48 L=2 fp32",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+            "preheat_steps": preheat,
+            "config": {"workload": f"{cfg['text']}, batch {B}/GPU", "name": args.config,
                        "batch_per_gpu": B, "global_batch": B * world, "T": T, "C": C, "H": H, "L": L, "K": K,
-                       "weights": weights, "parallelism": f"dp{world}", "loss_last_step": round(loss, 5),
-                       "launch": "hipGraph replay" if use_graph else "eager"},
+                       "bidirectional": cfg["bidirectional"], "weights": weights, "parallelism": f"dp{world}",
+                       "loss_last_step": round(loss, 5), "launch": "eager"},
         }
-        if timer:
-            us = timer.mean_us()
-            # the launch names depend on the path taken (single-launch fwd + head, in-kernel random streams)
-            fwd_key = next(k for k in ("nsd_lstm_head_train_rng", "nsd_lstm_head_train", "nsd_lstm_fwd") if us.get(k))
-            bwd_key = next(k for k in ("nsd_lstm_bwd_rng", "nsd_lstm_bwd") if us.get(k))
-            flop = {fwd_key: alg["flop_fwd"], bwd_key: alg["flop_bwd"]}
-            byts = {fwd_key: alg["bytes_fwd_kernel"], bwd_key: alg["bytes_bwd_kernel"]}
-            dom = max((fwd_key, bwd_key), key=lambda n: us[n] or 0.0)
-            t_s = us[dom] * 1e-6
-            tf = flop[dom] * B / t_s / 1e12
-            gbs = byts[dom] * B / t_s / 1e9
+        if step_ms:
+            out["step_ms_events"] = {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "n": len(step_ms),
+                                     "trials_per_s_at_median": round(world * B / (statistics.median(step_ms) * 1e-3), 1)}
+        if kern_us:
+            if small:
+                fwd_key = next(k for k in ("nsd_lstm_head_train_rng", "nsd_lstm_head_train", "nsd_lstm_fwd") if kern_us.get(k))
+                bwd_key = next(k for k in ("nsd_lstm_bwd_rng", "nsd_lstm_bwd") if kern_us.get(k))
+                names = {fwd_key: "lstm2_fwd48_kernel", bwd_key: "lstm2_bwd48_kernel"}
+                bound = "fp32-valu"
+                why = ("fp32 path: arithmetic intensity ~110 FLOP/B >> ridge (~20) so the compute roof binds, not HBM; peak = 157.3 "
+                       "TFLOP/s fp32 (packed-FMA vector rate == f32 MFMA rate on gfx950); the kernels are v_pk_fma_f32 (VALU) "
+                       "recurrences, one trial per CU at this batch, bound by instruction issue + the LDS hand-off of h per step; "
+                       "north_star's 40 % of HBM is out of reach for H=48 by construction (at the fp32 peak the step would still "
+                       "take 71 us = 18 % of 8 TB/s for its algorithmic bytes): see `hbm` for the measured HBM view")
+            else:
+                fwd_key, bwd_key = "scan_fwd", "scan_bwd"
+                names = {fwd_key: "scan_fwd_kernel", bwd_key: "scan_bwd_kernel"}
+                bound = "mfma"
+                why = ("bf16 path: peak = 2.5 PFLOP/s dense bf16 MFMA; the scan kernels hold the recurrent weights in registers and "
+                       "are bound by the per-time-step exchange latency between the workgroups of a batch tile (T serial steps per "
+                       "launch), not by the matrix pipe or HBM: both fractions are printed")
+            dom = max((fwd_key, bwd_key), key=lambda n: kern_us[n])
+            t_s = kern_us[dom] * 1e-6
+            fl = alg["fwd_flop"] if dom == fwd_key else alg["bwd_flop"]
+            by = alg["fwd_bytes"] if dom == fwd_key else alg["bwd_bytes"]
+            tf, gbs = fl / t_s / 1e12, by / t_s / 1e9
+            traffic, tsrc = recorded_traffic(args.config, cfg["precision"], names[dom], B, T)
             out["roofline"] = {
-                "kernel": "lstm2_bwd48_kernel<1>" if dom == bwd_key else "lstm2_fwd48_kernel<1>",
-                "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                "avg_launch_us": round(us[dom], 2), "algorithmic_flop_per_launch": flop[dom] * B,
+                "kernel": names[dom], "bound": bound, "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(tf / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                "avg_launch_us": round(kern_us[dom], 2), "algorithmic_flop_per_launch": fl,
                 "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                        "algorithmic_bytes_per_launch": byts[dom] * B},
-                "note": "fp32 path: arithmetic intensity ~110 FLOP/B >> ridge (~20), so the compute roof binds; "
-                        "peak = 157.3 TFLOP/s fp32 (packed-FMA vector rate == f32 MFMA rate on gfx950); the kernel is a "
-                        "per-trial recurrence, one trial per CU at this batch, bound by instruction issue + LDS hand-off "
-                        "latency of the step (DESIGN.md)",
+                        "algorithmic_bytes_per_launch": by},
+                "note": why,
             }
-            # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-            # gfx950, + WRITE_SIZE), collected in separate rocprofv3 passes by tools/pmc_run.sh on this workload and
-            # committed under profiles/ (bench.py cannot run the profiler on itself)
-            tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-            if os.path.exists(tpath) and B == 256 and T == 250:
-                kname = "lstm2_bwd48_kernel" if dom == bwd_key else "lstm2_fwd48_kernel"
-                tj = json.load(open(tpath))["kernels"].get(kname)
-                if tj:
-                    out["roofline"]["traffic"] = tj["hbm_bytes_per_launch_corrected"]
-                    out["roofline"]["traffic_source"] = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-            out["kernels_us"] = {k: round(v, 2) for k, v in us.items() if v is not None}
-            step_alg = alg["flop_train"] * B / (ms_per_step * 1e-3) / 1e12
-            out["step_frac_of_fp32_peak"] = round(step_alg / FP32_PEAK_TFLOPS, 4)
-            out["step_hbm_frac"] = round(alg["bytes_train"] * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            out["kernels_us"] = {k: round(v, 2) for k, v in kern_us.items()}
+            out["step_frac_of_peak"] = round(alg["flop_train"] / (ms_per_step * 1e-3) / 1e12 / peak, 4)
+            out["step_hbm_frac"] = round(alg["bytes_train"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         note(f"GPU: {value:.0f} trials/s, {ms_per_step:.3f} ms/step")
+
+        # ---- further points of SURVEY 8(d) (one GPU only; bounded) -------------------------------------------------------
+        if world == 1 and not args.no_extras and not args.no_kernel_timing:
+            model.eval()
+            with torch.no_grad():
+                for _ in range(5):
+                    model(x)
+                ms = event_times_ms(lambda: model.predict_proba(x), 50 if small else 10)
+                out["inference"] = {"batch": {"B": B, "T": T, "median_ms": round(statistics.median(ms), 4),
+                                              "trials_per_s": round(B / (statistics.median(ms) * 1e-3), 1)}}
+                if small:
+                    x1 = (2.7 * torch.randn(1, 625, C, generator=g)).to(dev)
+                    for _ in range(5):
+                        model.predict_proba(x1)
+                    ms1 = event_times_ms(lambda: model.predict_proba(x1), 100)
+                    out["inference"]["single_window_T625"] = {"median_ms": round(statistics.median(ms1), 4), "min_ms": round(min(ms1), 4)}
+            model.train()
+            if small:
+                x6 = (2.7 * torch.randn(B, 625, C, generator=g)).to(dev)
+                for _ in range(20):
+                    trainer.step(x6, y)
+                ms6 = event_times_ms(lambda: trainer.step(x6, y), 50)
+                out["T625"] = {"B": B, "T": 625, "median_ms_per_step": round(statistics.median(ms6), 4),
+                               "trials_per_s": round(B / (statistics.median(ms6) * 1e-3), 1)}
+
         if world == 1 and not args.no_cpu_baseline:
             note("timing the PyTorch-CPU baseline")
-            from oracle.torch_ref import time_cpu_train
-            cpu = time_cpu_train(B=B, T=T, C=C, H=H, L=L, K=K, budget_s=args.cpu_budget_s)
+            from oracle.torch_ref import host_cores, time_cpu_train
+            # a BOUNDED sample of the same workload: the full batch where a step takes a fraction of a second, a slice of
+            # the batch for the large models (the CPU rate per trial does not depend on the batch beyond oneDNN's blocking)
+            Bs = B if small else (64 if args.config == "cfg3" else 4)
+            kw = dict(B=Bs, T=T, C=C, H=H, L=L, K=K, stacked=True, bidirectional=cfg["bidirectional"])
+            cpu = time_cpu_train(budget_s=args.cpu_budget_s, **kw)
+            cpu1 = time_cpu_train(threads=1, budget_s=args.cpu_budget_s / 2, min_steps=2, **kw)
+            torch.set_num_threads(host_cores())
             out["cpu_baseline"] = {"value": round(cpu["trials_per_s"], 1), "unit": "trials/s", "cores": cpu["threads"],
                                    "kind": "port",
-                                   "sample": f"{cpu['steps']} train steps of the same workload (B={B}, T={T}) on PyTorch-CPU "
-                                             f"{torch.__version__} (stock nn.LSTM/oneDNN re-declaration of the reference module), "
-                                             f"median {cpu['ms_per_step']:.1f} ms/step"}
+                                   "sample": f"{cpu['steps']} train steps of {Bs} trials of the same workload (T={T}) on PyTorch-CPU "
+                                             f"{torch.__version__}: the reference module's structure on stock stacked nn.LSTM "
+                                             f"(dropout 0.6) / oneDNN, Adam, median {cpu['ms_per_step']:.1f} ms/step",
+                                   "one_thread": {"value": round(cpu1["trials_per_s"], 1), "cores": 1,
+                                                  "sample": f"{cpu1['steps']} steps, median {cpu1['ms_per_step']:.1f} ms/step"}}
             out["speedup_vs_cpu"] = round(value / cpu["trials_per_s"], 1)
         print(json.dumps(out), flush=True)
 

@@ -276,6 +276,13 @@ int nsd_seq_train_bwd(const nsd_dims *d, const float *params, const nsd_rng *rng
                       int64_t workspace_bytes, float *grads, void *stream);
 int nsd_seq_loss_sum(const nsd_dims *d, uint32_t flags, const void *workspace, int64_t workspace_bytes, float *out, void *stream);
 int nsd_seq_status(const void *workspace, int32_t *status_out, void *stream);
+/* Opt-in launch timing for benchmarks (off by default, nothing is recorded): nsd_seq_profile(1) records HIP events on the
+ * launch stream around the kernels of every following nsd_seq_* call, nsd_seq_profile(0) stops and discards;
+ * nsd_seq_profile_read sums the records of one kind and forgets them (BLOCKING).  kind: 0 forward scan, 1 backward scan,
+ * 2 input-projection GEMM, 3 weight-gradient GEMMs, 4 input-gradient GEMM, 5 head, 6 head parameter gradients, 7 operand
+ * preparation. */
+int nsd_seq_profile(int32_t enable);
+int nsd_seq_profile_read(int32_t kind, float *total_ms, int32_t *count);
 
 #ifdef __cplusplus
 }

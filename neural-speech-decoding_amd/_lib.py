@@ -80,6 +80,8 @@ SYMBOLS = {
     "nsd_seq_train_bwd": (C.c_int, [_dp, _fp, _vp, C.c_uint32, _vp, C.c_int64, _fp, _vp]),
     "nsd_seq_loss_sum": (C.c_int, [_dp, C.c_uint32, _vp, C.c_int64, _fp, _vp]),
     "nsd_seq_status": (C.c_int, [_vp, C.POINTER(C.c_int32), _vp]),
+    "nsd_seq_profile": (C.c_int, [C.c_int32]),
+    "nsd_seq_profile_read": (C.c_int, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "nsd_train_masks": (C.c_int, [C.c_uint64, C.c_uint32, C.c_float, C.c_float, C.c_int64, _fp, C.c_int64, _fp, _fp, _vp]),
 }
 

@@ -4,10 +4,29 @@
 // Model: EEG_LSTM of Neuro-Alpha-App/Utilities/lstm_eeg_model.py:13-39 (+ bidirectional nn.LSTM where :16-22 would take the
 // kwarg); parameter order = torch's state_dict order (…_l{k}, then …_l{k}_reverse per layer).
 #include <string.h>
+#include <vector>
 #include "nsd_seq.h"
 #include "nsd_args.h"
 
 namespace {
+
+// ---- opt-in launch timing (nsd_seq_profile): HIP events on the launch stream around the kernels of the path, so that a
+// benchmark can quote the dominant kernel's own duration.  Off by default: no events are created, nothing is recorded.
+enum { PK_SCAN_FWD = 0, PK_SCAN_BWD = 1, PK_GEMM_XPROJ = 2, PK_GEMM_DW = 3, PK_GEMM_DIN = 4, PK_HEAD = 5, PK_HEAD_GRADS = 6, PK_PREP = 7, PK_COUNT = 8 };
+struct ProfRec { hipEvent_t a, b; int kind; };
+struct ProfState { bool on = false; std::vector<ProfRec> recs; } g_prof;
+struct ProfScope {
+    hipStream_t st; int idx = -1;
+    ProfScope(int kind, hipStream_t s) : st(s) {
+        if (!g_prof.on) return;
+        ProfRec r; r.kind = kind;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        (void)hipEventRecord(r.a, st);
+        g_prof.recs.push_back(r);
+        idx = (int)g_prof.recs.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.recs[idx].b, st); }
+};
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
@@ -139,7 +158,8 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
     if (hipMemsetAsync(at<char>(c.ws, c.w.status), 0, (size_t)(c.w.flags + c.w.flags_bytes - c.w.status), c.st) != hipSuccess) {
         nsd_set_error("seq: memset failed"); return NSD_E_LAUNCH;
     }
-    if (const int rc = nsd_seq_xbf_launch(x, at<bf16_t>(c.ws, c.w.xbf), s.B, s.Bp, s.T, s.C, s.CP, c.st)) return rc;
+    ProfScope *prep = new ProfScope(PK_PREP, c.st);
+    if (const int rc = nsd_seq_xbf_launch(x, at<bf16_t>(c.ws, c.w.xbf), s.B, s.Bp, s.T, s.C, s.CP, c.st)) { delete prep; return rc; }
     for (int l = 0; l < s.L; ++l)
         for (int d = 0; d < s.D; ++d) {
             PrepArgs p;
@@ -150,8 +170,9 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             p.wxt = l > 0 ? at<bf16_t>(c.ws, c.w.wxt[l]) : nullptr;
             p.bsum = at<float>(c.ws, c.w.bsum[l][d]);
             p.H = H; p.I = l == 0 ? s.C : DH; p.Ipad = l == 0 ? s.CP : DH; p.wxt_ld = s.D * G; p.wxt_off = d * G;
-            if (const int rc = nsd_seq_prep_launch(p, c.st)) return rc;
+            if (const int rc = nsd_seq_prep_launch(p, c.st)) { delete prep; return rc; }
         }
+    delete prep;
     for (int l = 0; l < s.L; ++l) {
         // inter-layer dropout active: layer l < L-1 writes its multiplied output to lk[l], which layer l+1 then reads
         const bool lstm_drop = train && rng.on && rng.thr_lstm != 0;
@@ -164,6 +185,7 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             g.A = at<bf16_t>(c.ws, c.w.wx[l][d]); g.lda = Kin; g.B = in; g.ldb = Kin;
             g.C = at<bf16_t>(c.ws, c.w.xproj[d]); g.bias = at<float>(c.ws, c.w.bsum[l][d]);
             g.M = G; g.N = (int)R; g.K = Kin; g.splits = 1; g.epi = GEMM_EPI_TILE_BF16;
+            ProfScope ps(PK_GEMM_XPROJ, c.st);
             if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
         }
         for (int g0 = 0; g0 < s.groups; g0 += c.cap) {
@@ -184,6 +206,7 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             a.rng = rng;
             a.rng.on = masked ? 1 : 0;
             a.allow_l2_mode = c.l2_mode;
+            ProfScope ps(PK_SCAN_FWD, c.st);
             if (const int rc = nsd_scan_fwd_launch(a, H, s.MG, c.st)) return rc;
         }
     }
@@ -230,6 +253,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             a.rng = rng;
             a.rng.on = masked ? 1 : 0;
             a.allow_l2_mode = c.l2_mode;
+            ProfScope ps(PK_SCAN_BWD, c.st);
             if (const int rc = nsd_scan_bwd_launch(a, H, s.MG, c.st)) return rc;
         }
         // ---- contractions over the whole sequence
@@ -238,6 +262,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
         const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : at<bf16_t>(c.ws, in_masked ? c.w.lk[l - 1] : c.w.hs[l - 1]);
         const int Kin = l == 0 ? s.CP : DH, I = l == 0 ? s.C : DH;
         for (int d = 0; d < s.D; ++d) {
+            ProfScope ps(PK_GEMM_DW, c.st);
             GemmArgs g;
             memset(&g, 0, sizeof(g));
             g.A = da + (long)d * G; g.lda = (long)s.D * G; g.a_kmajor = 1; g.b_kmajor = 1;
@@ -265,10 +290,12 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             memset(&g, 0, sizeof(g));
             g.A = da; g.lda = (long)s.D * G; g.B = at<bf16_t>(c.ws, c.w.wxt[l]); g.ldb = (long)s.D * G;
             g.C = at<float>(c.ws, c.w.din[0]); g.ldc = DH; g.M = (int)R; g.N = DH; g.K = (long)s.D * G; g.splits = 1; g.epi = GEMM_EPI_F32;
+            ProfScope ps(PK_GEMM_DIN, c.st);
             if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
         }
     }
     const long hbs = c.w.hb_stride;
+    ProfScope ps(PK_HEAD_GRADS, c.st);
     return nsd_head_tm_grads_launch(at<float>(c.ws, c.w.hb), hbs, s.B, DH, s.F, s.K, parts, grads + c.pl.ln_w, grads + c.pl.ln_b, grads + c.pl.attn_w,
                                     grads + c.pl.attn_b, grads + c.pl.fc0_w, grads + c.pl.fc0_b, grads + c.pl.fc3_w, grads + c.pl.fc3_b, c.st);
 }
@@ -354,6 +381,7 @@ int nsd_seq_infer(const nsd_dims *d, const float *params, const float *x, uint32
     memset(&off, 0, sizeof(off));
     if (const int rc = forward(c, x, off, false)) return rc;
     HeadTmArgs h = head_args(c, logits, probs);
+    ProfScope ps(PK_HEAD, c.st);
     return nsd_head_tm_launch(h, c.st);
 }
 
@@ -381,6 +409,7 @@ int nsd_seq_train_fwd(const nsd_dims *d, const float *params, const float *x, co
             return NSD_E_LAUNCH;
         }
     }
+    ProfScope ps(PK_HEAD, c.st);
     return nsd_head_tm_launch(h, c.st);
 }
 
@@ -413,6 +442,31 @@ int nsd_seq_status(const void *workspace, int32_t *status_out, void *stream) {
         nsd_set_error("seq_status: %s", hipGetErrorString(hipGetLastError()));
         return NSD_E_LAUNCH;
     }
+    return NSD_OK;
+}
+
+// Opt-in launch timing for benchmarks: enable != 0 starts recording HIP events (on the launch stream) around the kernels of
+// every following nsd_seq_* call, 0 stops and discards.  nsd_seq_profile_read sums one kind and forgets its records
+// (BLOCKING: waits for those events).  kind: 0 forward scan, 1 backward scan, 2 input-projection GEMM, 3 weight-gradient
+// GEMMs (+ their reductions), 4 input-gradient GEMM, 5 head, 6 head parameter gradients, 7 operand preparation.
+int nsd_seq_profile(int32_t enable) {
+    for (ProfRec &r : g_prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.recs.clear();
+    g_prof.on = enable != 0;
+    return NSD_OK;
+}
+int nsd_seq_profile_read(int32_t kind, float *total_ms, int32_t *count) {
+    if (kind < 0 || kind >= PK_COUNT || !total_ms || !count) { nsd_set_error("seq_profile_read: bad argument"); return NSD_E_INVALID; }
+    float tot = 0.f; int n = 0;
+    std::vector<ProfRec> keep;
+    for (ProfRec &r : g_prof.recs) {
+        if (r.kind != kind) { keep.push_back(r); continue; }
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; ++n; }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.recs.swap(keep);
+    *total_ms = tot; *count = n;
     return NSD_OK;
 }
 

@@ -442,3 +442,21 @@ def seq_loss_sum(spec: ModelSpec, ws: torch.Tensor, B: int, T: int, out: Optiona
     out = torch.empty(1, dtype=torch.float32, device=ws.device) if out is None else out
     _call("nsd_seq_loss_sum", ws.device, C.byref(d), spec.seq_flags, ws.data_ptr(), _nbytes(ws), out.data_ptr(), STREAM)
     return out
+
+
+SEQ_PROFILE_KINDS = ("scan_fwd", "scan_bwd", "gemm_xproj", "gemm_dw", "gemm_din", "head", "head_grads", "prep")
+
+
+def seq_profile(enable: bool) -> None:
+    """Start / stop the opt-in HIP-event timing of the sequence-batched path's kernels (nsd_seq_profile)."""
+    _call("nsd_seq_profile", None, 1 if enable else 0)
+
+
+def seq_profile_read() -> Dict[str, Tuple[float, int]]:
+    """kind -> (total ms, launches) recorded since seq_profile(True) / the last read.  Synchronises."""
+    out = {}
+    for i, name in enumerate(SEQ_PROFILE_KINDS):
+        ms, n = C.c_float(0), C.c_int32(0)
+        _call("nsd_seq_profile_read", None, i, C.byref(ms), C.byref(n))
+        out[name] = (float(ms.value), int(n.value))
+    return out

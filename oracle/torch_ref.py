@@ -122,8 +122,31 @@ def host_cores() -> int:
     return max(1, n)
 
 
+class StackedTorchEEG(nn.Module):
+    """The reference module's own structure for CPU timing: ONE stacked torch.nn.LSTM with its built-in inter-layer dropout
+    (Neuro-Alpha-App/Utilities/lstm_eeg_model.py:16-22), attention pooling, LayerNorm, fc (:23-39) -- re-declared from stock
+    PyTorch primitives because the reference tree is not present on the GPU box.  `bidirectional` is where :16-22 would take
+    the kwarg (BASELINE cfg5).  Same oneDNN kernels as the reference class; verified equal to it in
+    tests/test_oracle_golden.py (state_dict keys are the reference's)."""
+
+    def __init__(self, C=8, H=48, L=2, K=3, dropout=0.60, bidirectional=False):
+        super().__init__()
+        D = 2 if bidirectional else 1
+        self.lstm = nn.LSTM(input_size=C, hidden_size=H, num_layers=L, batch_first=True,
+                            dropout=dropout if L > 1 else 0.0, bidirectional=bidirectional)
+        self.ln = nn.LayerNorm(D * H)
+        self.attn = nn.Linear(D * H, 1)
+        self.fc = nn.Sequential(nn.Linear(D * H, 32), nn.RReLU(), nn.Dropout(dropout), nn.Linear(32, K))
+
+    def forward(self, x):
+        out, _ = self.lstm(x)
+        w = torch.softmax(self.attn(out).squeeze(-1), dim=1)
+        return self.fc(self.ln((out * w.unsqueeze(-1)).sum(dim=1)))
+
+
 def time_cpu_train(B=256, T=250, C=8, H=48, L=2, K=3, threads: Optional[int] = None,
-                   budget_s: float = 15.0, min_steps: int = 3, seed: int = 1234):
+                   budget_s: float = 15.0, min_steps: int = 3, seed: int = 1234, stacked: bool = False,
+                   bidirectional: bool = False):
     """CPU baseline: CE train step (zero_grad, fwd with dropout+RReLU noise, bwd, Adam lr=1e-3)
     on synthetic x = 2.7*randn.  Runs whole steps until ~budget_s of CPU time is spent.
     Returns dict(trials_per_s, ms_per_step, steps, threads)."""
@@ -133,12 +156,13 @@ def time_cpu_train(B=256, T=250, C=8, H=48, L=2, K=3, threads: Optional[int] = N
     g = torch.Generator().manual_seed(seed)
     x = 2.7 * torch.randn(B, T, C, generator=g)
     y = torch.randint(0, K, (B,), generator=g)
-    m = TorchRefEEG(C, H, L, K).train()
+    m = (StackedTorchEEG(C, H, L, K, bidirectional=bidirectional) if (stacked or bidirectional) else TorchRefEEG(C, H, L, K)).train()
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    fwd = (lambda: m(x)) if (stacked or bidirectional) else (lambda: m(x, stochastic=True))
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.cross_entropy(m(x, stochastic=True), y)
+        loss = torch.nn.functional.cross_entropy(fwd(), y)
         loss.backward()
         opt.step()
 
@@ -154,3 +178,24 @@ def time_cpu_train(B=256, T=250, C=8, H=48, L=2, K=3, threads: Optional[int] = N
     times.sort()
     med = times[len(times) // 2]
     return {"trials_per_s": B / med, "ms_per_step": med * 1e3, "steps": len(times), "threads": threads}
+
+
+def time_cpu_infer(B=256, T=250, C=8, H=48, L=2, K=3, threads: Optional[int] = None, budget_s: float = 5.0, seed: int = 1234,
+                   bidirectional: bool = False):
+    """CPU baseline of eval-mode inference (the reference's predict() arithmetic, lstm_eeg_model.py:95-98, on a batch)."""
+    import time
+    threads = threads or host_cores()
+    torch.set_num_threads(threads)
+    x = 2.7 * torch.randn(B, T, C, generator=torch.Generator().manual_seed(seed))
+    m = StackedTorchEEG(C, H, L, K, bidirectional=bidirectional).eval()
+    times = []
+    with torch.inference_mode():
+        m(x)
+        t_end = time.perf_counter() + budget_s
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 200):
+            t0 = time.perf_counter()
+            torch.softmax(m(x), dim=-1)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"trials_per_s": B / med, "ms_per_call": med * 1e3, "calls": len(times), "threads": threads}

@@ -152,3 +152,28 @@ def test_counter_rng_properties():
     assert np.array_equal(m, orc.dropout_mask(5, 0, 0.6, (200000,)))       # deterministic
     s = orc.rrelu_noise(5, 2, (100000,))
     assert s.min() >= 0.125 and s.max() <= 1 / 3 + 1e-7 and abs(s.mean() - (0.125 + 1 / 3) / 2) < 1e-3
+
+
+def test_cpu_baseline_module_is_the_reference_model(golden, ref_state):
+    """bench.py's cpu_baseline times oracle.torch_ref.StackedTorchEEG: the reference module's structure re-declared from stock
+    torch (the reference tree does not travel to the GPU box).  It must carry the reference's state_dict keys and give the
+    reference's logits on the recorded windows; its bidirectional form must give the torch bidirectional goldens."""
+    import torch
+    from oracle.torch_ref import StackedTorchEEG
+    from tests.golden.make_goldens import BIDIR_CASES, synth_params, synth_x
+    m = StackedTorchEEG().eval()
+    assert list(m.state_dict().keys()) == list(ref_state.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in ref_state.items()}, strict=True)
+    g = golden("real_trials")
+    with torch.no_grad():
+        lg = m(torch.from_numpy(g["x"])).numpy()
+    assert np.abs(lg - g["logits"]).max() < 2e-5
+    ext = golden("extensions")
+    for tag, (C, H, L, K, B, T) in BIDIR_CASES.items():
+        st = synth_params(C, H, L, K, seed=70 + H, D=2)
+        mb = StackedTorchEEG(C, H, L, K, bidirectional=True).eval()
+        assert list(mb.state_dict().keys()) == list(st.keys())
+        mb.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+        with torch.no_grad():
+            lgb = mb(torch.from_numpy(synth_x(B, T, C=C, seed=60))).numpy()
+        assert np.abs(lgb - ext[f"{tag}.logits"]).max() < 2e-5, tag

@@ -2,7 +2,7 @@
 """Summarise the rocprofv3 passes of tools/pmc_run.sh into profiles/<tag>_hbm_traffic.json and
 profiles/<tag>_kernel_stats.csv.
 
-    python tools/pmc_summarize.py <tag>        (reads gpurun_out/prof_<tag>/{trace,fetch,write})
+    python tools/pmc_summarize.py <tag> [config]      (reads gpurun_out/prof_<tag>/{trace,fetch,write})
 
 HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): MI355X_MICROARCH.md, HBM / rocprofv3 section -- on
 gfx950 FETCH_SIZE reports half of wide coalesced reads; the counters are collected in separate --pmc passes."""
@@ -15,9 +15,17 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                     # noqa: E402  (CONFIGS, algorithmic figures, kernel-source hash)
 tag = sys.argv[1]
+config = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+cfg = bench.CONFIGS[config]
 base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-ALG = {"lstm2_fwd48_kernel": 51200000, "lstm2_bwd48_kernel": 51200000}     # bench.py algorithmic_per_trial x 256 trials
+alg = bench.algorithmic(cfg, cfg["B"], cfg["T"])
+if cfg["precision"] == "fp32":
+    ALG = {"lstm2_fwd48_kernel": alg["fwd_bytes"], "lstm2_bwd48_kernel": alg["bwd_bytes"]}
+else:
+    ALG = {"scan_fwd_kernel": alg["fwd_bytes"], "scan_bwd_kernel": alg["bwd_bytes"]}
 
 
 def counters(sub, name):
@@ -33,7 +41,8 @@ def counters(sub, name):
 
 
 fetch, write = counters("fetch", "FETCH_SIZE"), counters("write", "WRITE_SIZE")
-out = {"workload": "bench.py default (B=256,T=250) on one MI355X",
+out = {"workload": f"bench.py --config {config} (B={cfg['B']}, T={cfg['T']}) on one MI355X", "config": config, "B": cfg["B"], "T": cfg["T"],
+       "source_sha256": bench.kernel_source_hash(cfg["precision"]),
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_run.sh); FETCH_SIZE doubled per "
                "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); units KB; mean over the launches of the pass",
        "kernels": {}}
