@@ -349,3 +349,65 @@ def test_module_and_trainer_on_the_bf16_path(nsd, dev, tmp_path):
     for _ in range(30):
         tr.step(x, y.to(torch.int32))
     assert tr.scan_status() == 0 and tr.last_loss() < 0.8 * l0
+
+
+# ---------------------------------------------------------------------------------------------------
+# bidirectional (BASELINE cfg5's structure): extension, oracle = stock torch.nn.LSTM(bidirectional=True)
+# ---------------------------------------------------------------------------------------------------
+def _flat_from_state(spec, st, dev):
+    offs, shapes = spec.offsets(), spec.shapes()
+    flat = np.zeros(spec.param_count, np.float32)
+    assert list(st.keys()) == spec.names()                   # torch's state_dict order, `_reverse` tensors included
+    for k, v in st.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+        flat[offs[k]:offs[k] + v.size] = v.ravel()
+    return torch.from_numpy(flat).to(dev)
+
+
+@pytest.mark.parametrize("tag", sorted(BIDIR_CASES))
+def test_bidirectional_against_torch_goldens(nsd, dev, tag):
+    from nsd_amd import ops
+    C, H, L, K, B, T = BIDIR_CASES[tag]
+    ext = np.load(os.path.join(GOLDEN, "extensions.npz"))
+    spec = ops.ModelSpec(C=C, H=H, L=L, K=K, D=2)
+    assert spec.seq_path(B, T)
+    st = synth_params(C, H, L, K, seed=70 + H, D=2)
+    flat = _flat_from_state(spec, st, dev)
+    x = torch.from_numpy(synth_x(B, T, C=C, seed=60)).to(dev)
+    y = torch.from_numpy(synth_labels(B, K=K, seed=60)).to(dev)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    logits = ops.seq_train_fwd(spec, flat, x, y, ws)
+    g = ops.seq_train_bwd(spec, flat, ws, B, T).cpu().numpy()
+    loss = float(ops.seq_loss_sum(spec, ws, B, T).item()) / B
+    assert ops.seq_status(ws) == 0
+    assert np.abs(logits.cpu().numpy() - ext[f"{tag}.logits"]).max() < SEQ_LOGIT_TOL
+    assert abs(loss - float(ext[f"{tag}.loss"])) < 2e-2
+    _cfg3_check(ext, tag, g, spec.names(), spec.shapes(), spec.offsets())
+    lg_inf, probs = ops.seq_infer(spec, flat, x)
+    assert torch.equal(lg_inf, logits) and torch.allclose(probs.sum(1), torch.ones(B, device=dev), atol=1e-5)
+
+
+def test_bidirectional_module_surface_and_dropout_streams(nsd, dev):
+    """EEG_LSTM(bidirectional=True, precision='bf16'): torch's `_reverse` state_dict keys, 2H-wide head, the torch-oracle module
+    loads the same state_dict and agrees in eval mode; training with the in-kernel streams is deterministic and learns."""
+    from nsd_amd.trainer import Trainer
+    from oracle.torch_ref import StackedTorchEEG
+    torch.manual_seed(3)
+    m = nsd.EEG_LSTM(8, 64, 2, 3, dropout=0.5, bidirectional=True, precision="bf16").to(dev).eval()
+    ref = StackedTorchEEG(8, 64, 2, 3, dropout=0.5, bidirectional=True).eval()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert list(sd.keys()) == list(ref.state_dict().keys())
+    ref.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(synth_x(21, 16, seed=8))
+    with torch.no_grad():
+        want = ref(x).numpy()
+        got = m(x.to(dev)).cpu().numpy()
+    assert np.abs(got - want).max() < SEQ_LOGIT_TOL
+    y = torch.from_numpy(synth_labels(21, K=3, seed=8)).to(dev)
+    tr = Trainer(m.train(), lr=3e-3, seed=5)
+    tr.step(x.to(dev), y); l0 = tr.last_loss()
+    for _ in range(40):
+        tr.step(x.to(dev), y)
+    assert tr.scan_status() == 0 and tr.last_loss() < 0.7 * l0
+    with pytest.raises(ValueError):
+        nsd.EEG_LSTM(8, 64, 2, 3, bidirectional=True)          # needs precision='bf16'
