@@ -54,6 +54,8 @@ extern "C" {
                                     sequence fed to the attention pooling and the head is 2H wide */
 #define NSD_FLAG_NO_L2_EXCHANGE 16u /* nsd_seq_* only, diagnostics: scan groups always use the write-through exchange, also when
                                     all their workgroups report the same XCD (results are identical either way) */
+#define NSD_FLAG_SPREAD_GROUPS 32u /* nsd_seq_* only, diagnostics: give the workgroups of a scan group consecutive block ids, i.e.
+                                    spread every group over all XCDs (exercises the write-through exchange for real) */
 #define NSD_FLAG_BF16       4u   /* large-H batched path only (H % 16 == 0, H >= 64, B >= 16; ignored elsewhere): GEMM operands
                                     rounded to bf16 at the matrix pipe (fp32 accumulate, fp32 storage and cell arithmetic) --
                                     BASELINE cfg3's precision; results differ from fp32 at the 1e-2 level */
@@ -261,8 +263,9 @@ int nsd_gemm_bf16(const void *A, int64_t lda, int32_t a_kmajor, const void *B, i
  *   nsd_seq_train_fwd   forward + head + mean CE (scale = 1/B_global) + head backward; logits[B,K] written
  *   nsd_seq_train_bwd   BPTT + all parameter gradients -> grads[P] (overwritten), same rng as the forward call
  *   nsd_seq_loss_sum    sum of the per-trial CE losses of the last nsd_seq_train_fwd -> out[0] (device)
- *   nsd_seq_status      BLOCKING (the only entry point that synchronises): 0 ok; 1 / 2 a forward / backward scan group
- *                       timed out waiting for one of its workgroups (results are then invalid)
+ *   nsd_seq_status      BLOCKING: status_out[4] = {0 ok | 1 / 2 a forward / backward scan group timed out waiting for one of
+ *                       its workgroups (results are then invalid), reserved, scan groups (over all scan launches since the last
+ *                       nsd_seq_train_fwd / nsd_seq_infer) whose workgroups all reported ONE XCD, groups spread over several}
  */
 int64_t nsd_seq_param_count(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int32_t D);
 int     nsd_seq_param_layout(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int32_t D, int64_t *offsets);

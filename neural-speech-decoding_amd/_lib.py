@@ -18,6 +18,7 @@ NSD_FLAG_TRAIN = 2
 NSD_FLAG_BF16 = 4
 NSD_FLAG_BIDIR = 8
 NSD_FLAG_NO_L2_EXCHANGE = 16
+NSD_FLAG_SPREAD_GROUPS = 32
 
 
 class Rng(C.Structure):

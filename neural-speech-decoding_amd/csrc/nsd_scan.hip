@@ -106,12 +106,12 @@ __global__ __launch_bounds__(256) void seq_xbf_kernel(const float *x, bf16_t *xb
 struct Member { int dir, group, p; };
 // Members of a group get block ids that are equal mod 8 where the grid allows it: those blocks are observed to share an XCD,
 // so the exchange stays inside one L2.  Speed only -- the protocol does not depend on placement.
-__device__ __forceinline__ Member member_of(const int bid, const int groups, const int P) {
+__device__ __forceinline__ Member member_of(const int bid, const int groups, const int P, const int spread) {
     Member m;
     const int nper = groups * P;
     m.dir = bid / nper;
     const int rem = bid - m.dir * nper;
-    if ((nper & 7) == 0 && ((nper >> 3) % P) == 0) {
+    if (!spread && (nper & 7) == 0 && ((nper >> 3) % P) == 0) {
         const int x = rem & 7, slot = rem >> 3;
         m.group = x * ((nper >> 3) / P) + slot / P;
         m.p = slot % P;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     __shared__ __align__(16) bf16_t Bt2[2][MG * LDB];
     __shared__ int s_abort;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Member me = member_of(blockIdx.x, a.groups, P);
+    const Member me = member_of(blockIdx.x, a.groups, P, a.spread_groups);
     const int dir = me.dir;
     const int gt = 4 * me.p + wave;                            // this wave's accumulator tile = units 8gt .. 8gt+7
     const int b0 = (a.group0 + me.group) * MG;
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     __syncthreads();
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
+    if (tid == 0 && me.p == 0) atomicAdd(a.status + (rv == 1 ? 2 : 3), 1);     // diagnostics: groups on one XCD / spread over several
     const long ld = a.ld, Bp = a.Bp;
     const int u0 = 8 * gt + 4 * hh;                            // first of this lane's 4 units
     const bool train = a.cs[0] != nullptr;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     __shared__ __align__(16) bf16_t stg[4][MG * LDS_];         // one private strip per wave
     __shared__ int s_abort;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Member me = member_of(blockIdx.x, a.groups, P);
+    const Member me = member_of(blockIdx.x, a.groups, P, a.spread_groups);
     const int dir = me.dir;
     const int b0 = (a.group0 + me.group) * MG;
     const int col = lane & 31, hh = lane >> 5;
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     __syncthreads();
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
+    if (tid == 0 && me.p == 0) atomicAdd(a.status + (rv == 1 ? 2 : 3), 1);
     const long ld = a.ld, Bp = a.Bp, ldda = (long)a.D * G;
     float dbs[16];                                             // bias gradient of this lane's 16 gate columns, summed over time and tiles
 #pragma unroll

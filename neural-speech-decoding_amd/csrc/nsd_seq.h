@@ -60,6 +60,7 @@ struct ScanFwdArgs {
     int *status;
     int B, Bp, T, D, ld, groups, group0, layer;  // groups of THIS launch, the first of them being batch tile group0
     int allow_l2_mode;                       // 0: always the write-through exchange (tests: both modes must agree)
+    int spread_groups;                       // diagnostics: consecutive block ids per group = a group spread over all XCDs
     RngArgs rng;                             // rng.on: multiplier of stream rng.base on this layer's output
 };
 struct ScanBwdArgs {
@@ -74,7 +75,7 @@ struct ScanBwdArgs {
     unsigned *flags;
     int *status;
     int B, Bp, T, D, ld, groups, group0, groups_total, layer;
-    int allow_l2_mode;
+    int allow_l2_mode, spread_groups;
     RngArgs rng;
 };
 int nsd_scan_fwd_launch(const ScanFwdArgs &a, int H, int MG, hipStream_t st);

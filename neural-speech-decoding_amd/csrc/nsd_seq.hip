@@ -138,6 +138,7 @@ struct Ctx {
     const float *params;
     hipStream_t st;
     int cap;                                                     // groups per scan launch
+    int spread;                                                  // NSD_FLAG_SPREAD_GROUPS
     int l2_mode;                                                 // same-XCD exchange shortcut allowed (NSD_FLAG_NO_L2_EXCHANGE clears it)
 };
 
@@ -205,7 +206,7 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
             a.rng = rng;
             a.rng.on = masked ? 1 : 0;
-            a.allow_l2_mode = c.l2_mode;
+            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread;
             ProfScope ps(PK_SCAN_FWD, c.st);
             if (const int rc = nsd_scan_fwd_launch(a, H, s.MG, c.st)) return rc;
         }
@@ -252,7 +253,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
             a.rng = rng;
             a.rng.on = masked ? 1 : 0;
-            a.allow_l2_mode = c.l2_mode;
+            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread;
             ProfScope ps(PK_SCAN_BWD, c.st);
             if (const int rc = nsd_scan_bwd_launch(a, H, s.MG, c.st)) return rc;
         }
@@ -312,6 +313,7 @@ int make_ctx(const nsd_dims *d, uint32_t flags, const float *params, void *ws, i
     c->ws = ws; c->params = params; c->st = (hipStream_t)stream;
     c->cap = nsd_num_cus() / (c->s.P * c->s.D);
     c->l2_mode = (flags & NSD_FLAG_NO_L2_EXCHANGE) ? 0 : 1;
+    c->spread = (flags & NSD_FLAG_SPREAD_GROUPS) ? 1 : 0;
     return NSD_OK;
 }
 
@@ -438,7 +440,7 @@ int nsd_seq_loss_sum(const nsd_dims *d, uint32_t flags, const void *workspace, i
 int nsd_seq_status(const void *workspace, int32_t *status_out, void *stream) {
     if (!workspace || !status_out) { nsd_set_error("seq_status: null pointer"); return NSD_E_INVALID; }
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
-        hipMemcpy(status_out, workspace, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        hipMemcpy(status_out, workspace, 4 * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
         nsd_set_error("seq_status: %s", hipGetErrorString(hipGetLastError()));
         return NSD_E_LAUNCH;
     }

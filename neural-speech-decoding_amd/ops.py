@@ -113,10 +113,11 @@ _extra_flags = 0
 _seq_extra_flags = 0
 
 
-def set_seq_l2_exchange(on: bool) -> None:
-    """Sequence-batched path, diagnostics: off = scan groups always use the write-through exchange (NSD_FLAG_NO_L2_EXCHANGE)."""
+def set_seq_l2_exchange(on: bool, spread_groups: bool = False) -> None:
+    """Sequence-batched path, diagnostics: on=False -> scan groups always use the write-through exchange
+    (NSD_FLAG_NO_L2_EXCHANGE); spread_groups=True -> every group is spread over all XCDs (NSD_FLAG_SPREAD_GROUPS)."""
     global _seq_extra_flags
-    _seq_extra_flags = 0 if on else _lib.NSD_FLAG_NO_L2_EXCHANGE
+    _seq_extra_flags = (0 if on else _lib.NSD_FLAG_NO_L2_EXCHANGE) | (_lib.NSD_FLAG_SPREAD_GROUPS if spread_groups else 0)
 
 
 def set_gemm_bf16(on: bool) -> None:
@@ -390,11 +391,12 @@ def _seq_rng(rng: Optional[dict]):
                             float(rng["p_head"])))
 
 
-def seq_status(ws: torch.Tensor) -> int:
-    """0 = ok; 1 / 2 = a forward / backward scan group timed out (results invalid).  Synchronises."""
-    out = C.c_int32(-1)
-    _call("nsd_seq_status", ws.device, ws.data_ptr(), C.byref(out), STREAM)
-    return int(out.value)
+def seq_status(ws: torch.Tensor, detail: bool = False):
+    """0 = ok; 1 / 2 = a forward / backward scan group timed out (results invalid).  detail=True: (status, groups that ran on
+    one XCD, groups spread over several XCDs) counted over the scan launches since the last forward.  Synchronises."""
+    out = (C.c_int32 * 4)(-1, 0, 0, 0)
+    _call("nsd_seq_status", ws.device, ws.data_ptr(), out, STREAM)
+    return (int(out[0]), int(out[2]), int(out[3])) if detail else int(out[0])
 
 
 def seq_infer(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: Optional[torch.Tensor] = None, *,

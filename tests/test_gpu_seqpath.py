@@ -199,28 +199,37 @@ def test_seq_train_with_counter_streams_matches_oracle_with_the_same_masks(nsd, 
 
 
 def test_seq_exchange_modes_agree(nsd, dev):
-    """Scan groups whose workgroups report one XCD exchange through that L2 (plain stores), other groups write through; the
-    diagnostic flag NSD_FLAG_NO_L2_EXCHANGE forces the write-through protocol everywhere.  Both must give the same bits."""
+    """Scan groups whose workgroups report one XCD exchange through that L2 (plain stores), other groups write through.
+    Diagnostics force (a) the write-through protocol everywhere, (b) every group SPREAD over all XCDs (consecutive block ids),
+    which is the placement the write-through protocol exists for.  All three must give the same bits, and the status word
+    must report where the groups really ran."""
     from nsd_amd import ops
-    H, L, K, B, T = 256, 2, 5, 96, 40
+    H, L, K, B, T = 256, 2, 5, 256, 24          # 8 batch tiles x 8 workgroups: the XCD-aware block mapping applies
     d = orc.Dims(C=8, H=H, L=L, K=K)
-    spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
     st = synth_params(8, H, L, K, seed=5)
     x, y = synth_x(B, T, seed=2), synth_labels(B, K, seed=2)
     flat = _flat(st, d, dev)
     xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
-    out = []
-    for on in (True, False):
-        ops.set_seq_l2_exchange(on)
+    out, placement = [], []
+    for on, spread in ((True, False), (False, False), (True, True)):
+        ops.set_seq_l2_exchange(on, spread)
         try:
+            spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
             ws = ops.seq_workspace(spec, B, T, dev)
             lg = ops.seq_train_fwd(spec, flat, xt, yt, ws).clone()
             g = ops.seq_train_bwd(spec, flat, ws, B, T).clone()
-            assert ops.seq_status(ws) == 0
+            stt, one_xcd, spread_n = ops.seq_status(ws, detail=True)
+            assert stt == 0
+            placement.append((one_xcd, spread_n))
             out.append((lg, g))
         finally:
-            ops.set_seq_l2_exchange(True)
-    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+            ops.set_seq_l2_exchange(True, False)
+    print("scan groups on one XCD / spread, per mode:", placement)
+    for lg, g in out[1:]:
+        assert torch.equal(out[0][0], lg) and torch.equal(out[0][1], g)
+    n_groups = 2 * L * 8                                        # forward + backward scans, L layers, 256 / 32 batch tiles
+    assert all(a + b == n_groups for a, b in placement)
+    assert placement[2][1] == n_groups                          # spread really means spread: the write-through path carried the run
 
 
 # ---------------------------------------------------------------------------------------------------
