@@ -95,6 +95,7 @@ struct GemmArgs {
     void *C;
     long ldc;
     const float *bias;       // [M] (GEMM_EPI_TILE_BF16) or null
+    const float *add;        // GEMM_EPI_F32, splits == 1: C = A.B + add[m][n] (same leading dimension as C) or null
     int M, N;
     long K;
     int splits;              // split-K parts (GEMM_EPI_F32 only)

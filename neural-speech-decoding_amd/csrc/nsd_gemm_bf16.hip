@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
                     const int m = mb + mfma32_row(r, lane);
                     if (m >= g.M) continue;
                     if (EPI == GEMM_EPI_F32)
-                        (reinterpret_cast<float *>(g.C) + (long)blockIdx.z * g.M * g.ldc)[(long)m * g.ldc + n] = acc[i][j][r];
+                        (reinterpret_cast<float *>(g.C) + (long)blockIdx.z * g.M * g.ldc)[(long)m * g.ldc + n] =
+                            acc[i][j][r] + (g.add ? g.add[(long)m * g.ldc + n] : 0.f);
                     else
                         reinterpret_cast<bf16_t *>(g.C)[(long)m * g.ldc + n] = (bf16_t)acc[i][j][r];
                 }
@@ -176,6 +177,7 @@ int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
     if (g.epi == GEMM_EPI_TILE_BF16 && (g.M % 32 || g.N % 32)) { nsd_set_error("gemm_bf16: tile output needs M, N multiples of 32"); return NSD_E_INVALID; }
     const int splits = (g.epi == GEMM_EPI_F32 && g.splits > 1) ? g.splits : 1;
     if (g.b_shift != 0 && !g.b_kmajor) { nsd_set_error("gemm_bf16: b_shift needs a k-major B"); return NSD_E_INVALID; }
+    if (g.add && (g.epi != GEMM_EPI_F32 || splits != 1)) { nsd_set_error("gemm_bf16: addend needs the fp32 epilogue without split-K"); return NSD_E_INVALID; }
     GemmArgs a = g;
     a.splits = splits;
     const dim3 grid((g.N + GN - 1) / GN, (g.M + GM - 1) / GM, splits);

@@ -129,7 +129,9 @@ __device__ __forceinline__ bool wait_group(const unsigned *gflags, const unsigne
     for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
         const unsigned v = lane < NW ? ld_sc1_u32(gflags + lane) : 0xffffffffu;
         if (__all(v >= need)) return true;
+#if !defined(NSD_POLL_NO_SLEEP)
         __builtin_amdgcn_s_sleep(1);
+#endif
     }
     return false;
 }
@@ -291,8 +293,12 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) m[j] = nsd_rand_u32(a.rng.seed, a.rng.base, base + j) >= a.rng.thr_lstm ? a.rng.keep_lstm : 0.f;
                 }
-                // the multiplier acts on the value the next layer really reads: the bf16 h
-                const float h0 = bf16_lo(hw[nt][0]), h1 = bf16_hi(hw[nt][0]), h2 = bf16_lo(hw[nt][1]), h3 = bf16_hi(hw[nt][1]);
+                // the multiplier acts on the value the next layer really reads: the bf16 h (+ the residual input, extension)
+                float h0 = bf16_lo(hw[nt][0]), h1 = bf16_hi(hw[nt][0]), h2 = bf16_lo(hw[nt][1]), h3 = bf16_hi(hw[nt][1]);
+                if (a.res) {
+                    const u32x2 rv2 = *reinterpret_cast<const u32x2 *>(a.res + row * ld + dir * H + u0);
+                    h0 += bf16_lo(rv2[0]); h1 += bf16_hi(rv2[0]); h2 += bf16_lo(rv2[1]); h3 += bf16_hi(rv2[1]);
+                }
                 u32x2 v = {pack_bf16x2(h0 * m[0], h1 * m[1]), pack_bf16x2(h2 * m[2], h3 * m[3])};
                 *reinterpret_cast<u32x2 *>(a.lk + row * ld + dir * H + u0) = v;
             }
@@ -400,6 +406,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dup[nt][j] = fmaf(al, dpl[nt][j], ds * aw[j]);
             }
+            if (a.dres) *reinterpret_cast<f32x4 *>(a.dres + row * ld + dir * H + u0) = f32x4{dup[nt][0], dup[nt][1], dup[nt][2], dup[nt][3]};
         }
         float drec[NT][4];
 #pragma unroll

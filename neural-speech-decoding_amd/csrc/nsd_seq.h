@@ -23,6 +23,7 @@
 
 struct SeqDims {
     int B, T, C, H, L, K, F, D;
+    int residual;                   // extension: out_l = LSTM_l(in_l) + in_l for l >= 1
     int Bp, MG, CP, P, groups;      // derived: padded batch, trials per group (32 or 64), padded channels, workgroups per group, groups per direction
 };
 
@@ -53,7 +54,8 @@ struct ScanFwdArgs {
     const bf16_t *wf[NSD_SEQ_MAX_DIRS];      // [4H][H] recurrent weights, rows in accumulator-tile order
     const bf16_t *xproj[NSD_SEQ_MAX_DIRS];   // accumulator tiles, bias included
     bf16_t *hs;                              // [T*Bp][ld]
-    bf16_t *lk;                              // [T*Bp][ld] or null (no multiplier: readers use hs)
+    bf16_t *lk;                              // [T*Bp][ld] linked output (h [+ res]) * multiplier, or null (== h: readers use hs)
+    const bf16_t *res;                       // [T*Bp][ld] residual input added to h (extension; the layer's own input) or null
     bf16_t *cs[NSD_SEQ_MAX_DIRS];            // [T*Bp][H] or null (inference)
     bf16_t *ga[NSD_SEQ_MAX_DIRS];            // [T*Bp][4H] or null
     unsigned *flags;                         // [D][groups][128] (one word per wave of every member + XCC ids), zeroed before the launch
@@ -69,6 +71,7 @@ struct ScanBwdArgs {
     bf16_t *da;                              // [T*Bp][D*4H]
     float *dbp;                              // [D][groups_total][4H] bias-gradient partials, one row per batch tile (unit-major columns)
     const float *din;                        // [T*Bp][ld] gradient w.r.t. this layer's (multiplied) output, or null (top layer)
+    float *dres;                             // [T*Bp][ld] residual extension: d(linked output) * multiplier, added to the input gradient; or null
     const float *alpha, *dscore;             // [T*Bp] (top layer)
     const float *dpooled;                    // [Bp][ld]
     const float *attn_w;                     // [ld]

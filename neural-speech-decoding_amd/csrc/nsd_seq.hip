@@ -35,9 +35,9 @@ int derive(const nsd_dims *d, uint32_t flags, SeqDims *o) {
     SeqDims s;
     s.B = d->B; s.T = d->T; s.C = d->C; s.H = d->H; s.L = d->L; s.K = d->K; s.F = d->F;
     s.D = (flags & NSD_FLAG_BIDIR) ? 2 : 1;
+    s.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
     if (!nsd_scan_supported(s.H)) { nsd_set_error("seq path: hidden size %d not covered (64, 128, 256, 512)", s.H); return NSD_E_INVALID; }
     if (s.F > 64 || s.K > 64) { nsd_set_error("seq path: F=%d K=%d exceed 64", s.F, s.K); return NSD_E_INVALID; }
-    if (flags & NSD_FLAG_RESIDUAL) { nsd_set_error("seq path: the residual extension is not available on this path"); return NSD_E_INVALID; }
     s.P = s.H / 32;
     s.CP = (int)align_up(s.C, 16);
     const int cus = nsd_num_cus();
@@ -72,7 +72,7 @@ SeqWs make_ws(const SeqDims &s) {
         }
         w.wxt[l] = l > 0 ? take(DH * s.D * G * 2) : 0;
         w.hs[l] = take(R * DH * 2);
-        w.lk[l] = l < s.L - 1 ? take(R * DH * 2) : 0;
+        w.lk[l] = (l < s.L - 1 || s.residual) ? take(R * DH * 2) : 0;
         for (int d = 0; d < s.D; ++d) {
             w.cs[l][d] = take(R * H * 2);
             w.ga[l][d] = take(R * G * 2);
@@ -81,6 +81,7 @@ SeqWs make_ws(const SeqDims &s) {
     for (int d = 0; d < s.D; ++d) w.xproj[d] = take(R * G * 2);
     w.da = take(R * s.D * G * 2);
     w.din[0] = take(R * DH * 4);
+    w.din[1] = s.residual ? take(R * DH * 4) : 0;           // residual extension: d(linked output) passed around the LSTM
     w.alpha = take(R * 4);
     w.dscore = take(R * 4);
     w.pooled = take((int64_t)s.Bp * DH * 4);
@@ -152,6 +153,9 @@ int split_count(int M, int N, long K) {
     return S;
 }
 
+bool writes_lk(const SeqDims &s, int l, bool lstm_drop) { return (lstm_drop && l < s.L - 1) || (s.residual && l >= 1); }
+const bf16_t *out_of(Ctx &c, int l, bool lstm_drop) { return at<bf16_t>(c.ws, writes_lk(c.s, l, lstm_drop) ? c.w.lk[l] : c.w.hs[l]); }
+
 int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
     const SeqDims &s = c.s;
     const int H = s.H, G = 4 * H, DH = s.D * H;
@@ -175,10 +179,11 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
         }
     delete prep;
     for (int l = 0; l < s.L; ++l) {
-        // inter-layer dropout active: layer l < L-1 writes its multiplied output to lk[l], which layer l+1 then reads
+        // a layer writes its LINKED output lk[l] = (h [+ its input]) * multiplier when that differs from h: inter-layer dropout
+        // active (l < L-1) or the residual extension (l >= 1); readers take lk[l] then, hs[l] otherwise
         const bool lstm_drop = train && rng.on && rng.thr_lstm != 0;
         const bool masked = lstm_drop && l < s.L - 1;
-        const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : at<bf16_t>(c.ws, lstm_drop ? c.w.lk[l - 1] : c.w.hs[l - 1]);
+        const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : out_of(c, l - 1, lstm_drop);
         const int Kin = l == 0 ? s.CP : DH;
         for (int d = 0; d < s.D; ++d) {
             GemmArgs g;
@@ -200,7 +205,8 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
                 a.ga[d] = train ? at<bf16_t>(c.ws, c.w.ga[l][d]) : nullptr;
             }
             a.hs = at<bf16_t>(c.ws, c.w.hs[l]);
-            a.lk = masked ? at<bf16_t>(c.ws, c.w.lk[l]) : nullptr;
+            a.lk = writes_lk(s, l, lstm_drop) ? at<bf16_t>(c.ws, c.w.lk[l]) : nullptr;
+            a.res = (s.residual && l >= 1) ? in : nullptr;
             a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)l * s.D * s.groups + (long)g0 * s.D) * 128;   // disjoint per chunk
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
@@ -218,7 +224,7 @@ HeadTmArgs head_args(Ctx &c, float *logits, float *probs) {
     const SeqDims &s = c.s;
     HeadTmArgs h;
     memset(&h, 0, sizeof(h));
-    h.top = at<bf16_t>(c.ws, c.w.hs[s.L - 1]);
+    h.top = out_of(c, s.L - 1, false);                           // (the last layer is never multiplied; with the residual extension it is lk)
     h.ln_w = c.params + c.pl.ln_w; h.ln_b = c.params + c.pl.ln_b; h.attn_w = c.params + c.pl.attn_w; h.attn_b = c.params + c.pl.attn_b;
     h.fc0_w = c.params + c.pl.fc0_w; h.fc0_b = c.params + c.pl.fc0_b; h.fc3_w = c.params + c.pl.fc3_w; h.fc3_b = c.params + c.pl.fc3_b;
     h.eval_slope = (float)((0.125 + 1.0 / 3.0) / 2.0);           // nn.RReLU eval slope, lstm_eeg_model.py:27
@@ -245,6 +251,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             }
             a.da = at<bf16_t>(c.ws, c.w.da);
             a.din = l == s.L - 1 ? nullptr : at<float>(c.ws, c.w.din[0]);
+            a.dres = (s.residual && l >= 1) ? at<float>(c.ws, c.w.din[1]) : nullptr;
             a.alpha = at<float>(c.ws, c.w.alpha); a.dscore = at<float>(c.ws, c.w.dscore); a.dpooled = at<float>(c.ws, c.w.dpooled);
             a.attn_w = c.params + c.pl.attn_w;
             a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)(s.L + l) * s.D * s.groups + (long)g0 * s.D) * 128;
@@ -259,8 +266,8 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
         }
         // ---- contractions over the whole sequence
         const bf16_t *da = at<bf16_t>(c.ws, c.w.da);
-        const bool in_masked = rng.on && rng.thr_lstm != 0 && l > 0;
-        const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : at<bf16_t>(c.ws, in_masked ? c.w.lk[l - 1] : c.w.hs[l - 1]);
+        const bool lstm_drop = rng.on && rng.thr_lstm != 0;
+        const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : out_of(c, l - 1, lstm_drop);
         const int Kin = l == 0 ? s.CP : DH, I = l == 0 ? s.C : DH;
         for (int d = 0; d < s.D; ++d) {
             ProfScope ps(PK_GEMM_DW, c.st);
@@ -291,6 +298,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             memset(&g, 0, sizeof(g));
             g.A = da; g.lda = (long)s.D * G; g.B = at<bf16_t>(c.ws, c.w.wxt[l]); g.ldb = (long)s.D * G;
             g.C = at<float>(c.ws, c.w.din[0]); g.ldc = DH; g.M = (int)R; g.N = DH; g.K = (long)s.D * G; g.splits = 1; g.epi = GEMM_EPI_F32;
+            g.add = s.residual ? at<float>(c.ws, c.w.din[1]) : nullptr;       // residual extension: + d(linked output) of this layer
             ProfScope ps(PK_GEMM_DIN, c.st);
             if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
         }

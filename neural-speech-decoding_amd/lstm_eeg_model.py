@@ -127,12 +127,10 @@ class EEG_LSTM(nn.Module):
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"precision={precision!r}: expected 'fp32' or 'bf16'")
         self.spec = ops.ModelSpec(C=input_size, H=hidden_size, L=num_layers, K=num_classes, F=ops.FC_HIDDEN,
-                                  D=2 if bidirectional else 1)
+                                  D=2 if bidirectional else 1, residual=bool(residual) and precision == "bf16")
         self.precision = precision
         if bidirectional and precision != "bf16":
             raise ValueError("bidirectional=True is built on the sequence-batched path only: pass precision='bf16'")
-        if precision == "bf16" and residual:
-            raise ValueError("the residual extension is not available with precision='bf16'")
         self.dropout_p = float(dropout) if num_layers > 1 else 0.0   # nn.LSTM drops only between layers (:21)
         self.head_dropout_p = float(dropout)
         self.residual, self.normalize = bool(residual), bool(normalize)
@@ -337,7 +335,7 @@ class SimplePredictor:
                  num_layers: int = 2, num_classes: int = 3, dropout: float = 0.60, device: str = "cpu",
                  tailoring_lambda: float = 1.25e-29, class_names=None, *, preprocess=None,
                  preprocess_package: Optional[str] = None, gpu: str = "cuda", residual: bool = False,
-                 normalize: bool = False):
+                 normalize: bool = False, bidirectional: bool = False, precision: str = "fp32"):
         self.device = torch.device(device)
         self.class_names = class_names or CLASS_NAMES
         if preprocess is None:
@@ -353,7 +351,8 @@ class SimplePredictor:
                            "no CPU fallback")
         self.gpu = torch.device(gpu)
         self.model = EEG_LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
-                              num_classes=num_classes, dropout=dropout, residual=residual, normalize=normalize)
+                              num_classes=num_classes, dropout=dropout, residual=residual, normalize=normalize,
+                              bidirectional=bidirectional, precision=precision)
         state = torch.load(pth_path, map_location="cpu", weights_only=True)
         if isinstance(state, dict) and "state_dict" in state:     # both forms, as lstm_eeg_model.py:79-80
             state = state["state_dict"]

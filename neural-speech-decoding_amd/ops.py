@@ -26,6 +26,7 @@ class ModelSpec:
     K: int = 3
     F: int = FC_HIDDEN
     D: int = 1          # directions: 2 = bidirectional (torch's nn.LSTM(bidirectional=True)); sequence-batched path only
+    residual: bool = False   # sequence-batched path: the residual extension (NSD_FLAG_RESIDUAL) as part of the model's shape
 
     def dims(self, B: int, T: int) -> Dims:
         return Dims(B, T, self.C, self.H, self.L, self.K, self.F)
@@ -74,7 +75,7 @@ class ModelSpec:
 
     @property
     def seq_flags(self) -> int:
-        return (_lib.NSD_FLAG_BIDIR if self.D == 2 else 0) | _seq_extra_flags
+        return (_lib.NSD_FLAG_BIDIR if self.D == 2 else 0) | (_lib.NSD_FLAG_RESIDUAL if self.residual else 0) | _seq_extra_flags
 
     def seq_path(self, B: int = 32, T: int = 1) -> bool:
         """True where the sequence-batched bf16 path (nsd_seq_*) covers this model (H in 64/128/256/512, F, K <= 64)."""
