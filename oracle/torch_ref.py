@@ -22,22 +22,26 @@ RRELU_LOWER, RRELU_UPPER = 1.0 / 8.0, 1.0 / 3.0
 class TorchRefEEG(nn.Module):
     """Stacked LSTM -> additive attention pooling over time -> LayerNorm -> MLP head."""
 
-    def __init__(self, C=8, H=48, L=2, K=3, F=32, p_drop=0.6, residual=False):
+    def __init__(self, C=8, H=48, L=2, K=3, F=32, p_drop=0.6, residual=False, bidirectional=False):
+        """bidirectional (extension, BASELINE cfg5): every layer is a stock one-layer nn.LSTM(bidirectional=True); explicit
+        masks then have shape [L-1, B, T, 2H] -- the element order of the product's counter streams."""
         super().__init__()
         self.dims = (C, H, L, K, F)
-        self.p_drop, self.residual = p_drop, residual
-        self.cells = nn.ModuleList([nn.LSTM(C if l == 0 else H, H, 1, batch_first=True) for l in range(L)])
-        self.norm = nn.LayerNorm(H)
-        self.score = nn.Linear(H, 1)
-        self.dense_a = nn.Linear(H, F)
+        self.p_drop, self.residual, self.bidirectional = p_drop, residual, bidirectional
+        D = 2 if bidirectional else 1
+        self.cells = nn.ModuleList([nn.LSTM(C if l == 0 else D * H, H, 1, batch_first=True, bidirectional=bidirectional) for l in range(L)])
+        self.norm = nn.LayerNorm(D * H)
+        self.score = nn.Linear(D * H, 1)
+        self.dense_a = nn.Linear(D * H, F)
         self.dense_b = nn.Linear(F, K)
 
     # -- parameter exchange with the reference's state_dict naming ------------------
     def load_reference_state(self, state: Dict[str, torch.Tensor]) -> None:
         with torch.no_grad():
             for l, cell in enumerate(self.cells):
-                for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
-                    getattr(cell, f"{nm}_l0").copy_(torch.as_tensor(state[f"lstm.{nm}_l{l}"]))
+                for sfx in (("", "_reverse") if self.bidirectional else ("",)):
+                    for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                        getattr(cell, f"{nm}_l0{sfx}").copy_(torch.as_tensor(state[f"lstm.{nm}_l{l}{sfx}"]))
             self.norm.weight.copy_(torch.as_tensor(state["ln.weight"]))
             self.norm.bias.copy_(torch.as_tensor(state["ln.bias"]))
             self.score.weight.copy_(torch.as_tensor(state["attn.weight"]))
@@ -50,8 +54,9 @@ class TorchRefEEG(nn.Module):
     def reference_named_grads(self) -> Dict[str, torch.Tensor]:
         g = {}
         for l, cell in enumerate(self.cells):
-            for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
-                g[f"lstm.{nm}_l{l}"] = getattr(cell, f"{nm}_l0").grad
+            for sfx in (("", "_reverse") if self.bidirectional else ("",)):
+                for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                    g[f"lstm.{nm}_l{l}{sfx}"] = getattr(cell, f"{nm}_l0{sfx}").grad
         g.update({"ln.weight": self.norm.weight.grad, "ln.bias": self.norm.bias.grad,
                   "attn.weight": self.score.weight.grad, "attn.bias": self.score.bias.grad,
                   "fc.0.weight": self.dense_a.weight.grad, "fc.0.bias": self.dense_a.bias.grad,

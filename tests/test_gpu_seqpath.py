@@ -456,3 +456,36 @@ def test_seq_residual_extension_matches_oracle(nsd, dev, H, L, B, T):
     # and it is not the plain model
     plain, _ = ops.seq_infer(ops.ModelSpec(C=8, H=H, L=L, K=K), flat, xt)
     assert (plain - lg_eval).abs().max().item() > 10 * SEQ_LOGIT_TOL
+
+
+def test_bidirectional_training_with_dropout_streams_vs_torch(nsd, dev):
+    """Bidirectional train mode: the in-kernel counter streams (inter-layer dropout over the 2H-wide layer output, RReLU
+    slopes, head dropout) against the torch composition fed the tensors of the same streams."""
+    from nsd_amd import ops
+    from oracle.torch_ref import TorchRefEEG
+    C, H, L, K, B, T, F = 8, 64, 2, 5, 70, 18, 32
+    st = synth_params(C, H, L, K, seed=31, D=2)
+    spec = ops.ModelSpec(C=C, H=H, L=L, K=K, D=2)
+    flat = _flat_from_state(spec, st, dev)
+    x, y = synth_x(B, T, seed=13), synth_labels(B, K, seed=13)
+    seed, base, p = 0xFACE, 20, 0.5
+    dl = orc.dropout_mask(seed, base, p, (L - 1, B, T, 2 * H))
+    sl = orc.rrelu_noise(seed, base + 1, (B, F))
+    dh = orc.dropout_mask(seed, base + 2, p, (B, F))
+    m = TorchRefEEG(C, H, L, K, bidirectional=True)
+    m.load_reference_state({k: torch.from_numpy(v) for k, v in st.items()})
+    lg_ref = m(torch.from_numpy(x), torch.from_numpy(dl), torch.from_numpy(sl), torch.from_numpy(dh))
+    torch.nn.functional.cross_entropy(lg_ref, torch.from_numpy(y.astype(np.int64))).backward()
+    g_ref = m.reference_named_grads()
+    ws = ops.seq_workspace(spec, B, T, dev)
+    rng = dict(seed=seed, base_stream=base, p_lstm=p, p_head=p)
+    logits = ops.seq_train_fwd(spec, flat, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), ws, rng=rng)
+    g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).cpu().numpy()
+    assert ops.seq_status(ws) == 0
+    assert np.abs(logits.cpu().numpy() - lg_ref.detach().numpy()).max() < SEQ_LOGIT_TOL
+    offs, shapes = spec.offsets(), spec.shapes()
+    for k in spec.names():
+        ref = g_ref[k].numpy().ravel()
+        got = g[offs[k]:offs[k] + ref.size]
+        tol = 1e-4 if k == "attn.bias" else SEQ_GRAD_RTOL * max(np.abs(ref).max(), 1e-6) + 1e-6
+        assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())

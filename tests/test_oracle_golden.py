@@ -177,3 +177,25 @@ def test_cpu_baseline_module_is_the_reference_model(golden, ref_state):
         with torch.no_grad():
             lgb = mb(torch.from_numpy(synth_x(B, T, C=C, seed=60))).numpy()
         assert np.abs(lgb - ext[f"{tag}.logits"]).max() < 2e-5, tag
+
+
+def test_torch_composition_bidirectional_equals_stock_stacked_lstm(golden):
+    """oracle.torch_ref.TorchRefEEG(bidirectional=True) -- L one-layer bidirectional nn.LSTMs, explicit masks between them: the
+    oracle of the bidirectional train-mode GPU tests -- reproduces the stock stacked nn.LSTM(bidirectional=True) goldens."""
+    import torch
+    from oracle.torch_ref import TorchRefEEG
+    from tests.golden.make_goldens import BIDIR_CASES, synth_labels, synth_params, synth_x
+    ext = golden("extensions")
+    for tag, (C, H, L, K, B, T) in BIDIR_CASES.items():
+        st = synth_params(C, H, L, K, seed=70 + H, D=2)
+        m = TorchRefEEG(C, H, L, K, bidirectional=True).eval()
+        m.load_reference_state({k: torch.from_numpy(v) for k, v in st.items()})
+        x = torch.from_numpy(synth_x(B, T, C=C, seed=60))
+        y = torch.from_numpy(synth_labels(B, K=K, seed=60).astype(np.int64))
+        lg = m(x)
+        torch.nn.functional.cross_entropy(lg, y).backward()
+        assert np.abs(lg.detach().numpy() - ext[f"{tag}.logits"]).max() < 2e-5
+        for k, g in m.reference_named_grads().items():
+            if f"{tag}.grad.{k}" in ext.files:
+                ref = ext[f"{tag}.grad.{k}"]
+                assert np.abs(g.numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6) + 2e-6, (tag, k)
