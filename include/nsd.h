@@ -56,6 +56,8 @@ extern "C" {
                                     all their workgroups report the same XCD (results are identical either way) */
 #define NSD_FLAG_SPREAD_GROUPS 32u /* nsd_seq_* only, diagnostics: give the workgroups of a scan group consecutive block ids, i.e.
                                     spread every group over all XCDs (exercises the write-through exchange for real) */
+#define NSD_FLAG_NO_FUSED_LAYERS 64u /* nsd_seq_* only, diagnostics: two unidirectional layers as two scans + GEMMs (the general
+                                    route) instead of the single skewed launch */
 #define NSD_FLAG_BF16       4u   /* large-H batched path only (H % 16 == 0, H >= 64, B >= 16; ignored elsewhere): GEMM operands
                                     rounded to bf16 at the matrix pipe (fp32 accumulate, fp32 storage and cell arithmetic) --
                                     BASELINE cfg3's precision; results differ from fp32 at the 1e-2 level */

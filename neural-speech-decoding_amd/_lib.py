@@ -19,6 +19,7 @@ NSD_FLAG_BF16 = 4
 NSD_FLAG_BIDIR = 8
 NSD_FLAG_NO_L2_EXCHANGE = 16
 NSD_FLAG_SPREAD_GROUPS = 32
+NSD_FLAG_NO_FUSED_LAYERS = 64
 
 
 class Rng(C.Structure):

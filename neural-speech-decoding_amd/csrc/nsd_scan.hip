@@ -29,19 +29,10 @@
 // Backward.  Same grouping; per step the group exchanges da_t [trials, 4H] (written for the weight-gradient GEMMs anyway),
 // workgroup p computes dh_rec for its 32 units as W_hh^T[32, 4H] . da_t^T with the contraction split over its 4 waves (B
 // fragments straight from global memory -- each 16-byte piece is needed by exactly one wave), partial tiles meet in LDS.
-#include "nsd_seq.h"
-
-// timing experiments only (make ABL=n -> libnsd_hip_abl.so, never shipped): bit 0 skip the flag wait, bit 1 skip the tile
-// gather, bit 2 skip the drain of the published stores -- results are wrong by construction, only the time is of interest
-#ifndef NSD_SCAN_ABLATE
-#define NSD_SCAN_ABLATE 0
-#endif
+#include "nsd_scan_common.h"
 
 namespace {
 
-constexpr unsigned SPIN_LIMIT = 1u << 20;          // polls (each >= ~1 us with the sleep): ~1-2 s, then give up
-constexpr int ST_FWD_TIMEOUT = 1, ST_BWD_TIMEOUT = 2;
-constexpr int GROUP_WORDS = 128;                   // flag words per group: [0,64) one per wave of every member, [64,80) XCC ids
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // operand preparation
@@ -101,73 +92,6 @@ __global__ __launch_bounds__(256) void seq_xbf_kernel(const float *x, bf16_t *xb
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// group geometry shared by both scans
-// ---------------------------------------------------------------------------------------------------------------------------
-struct Member { int dir, group, p; };
-// Members of a group get block ids that are equal mod 8 where the grid allows it: those blocks are observed to share an XCD,
-// so the exchange stays inside one L2.  Speed only -- the protocol does not depend on placement.
-__device__ __forceinline__ Member member_of(const int bid, const int groups, const int P, const int spread) {
-    Member m;
-    const int nper = groups * P;
-    m.dir = bid / nper;
-    const int rem = bid - m.dir * nper;
-    if (!spread && (nper & 7) == 0 && ((nper >> 3) % P) == 0) {
-        const int x = rem & 7, slot = rem >> 3;
-        m.group = x * ((nper >> 3) / P) + slot / P;
-        m.p = slot % P;
-    } else {
-        m.group = rem / P;
-        m.p = rem % P;
-    }
-    return m;
-}
-
-// one wave: wait until every wave of every member of the group has published `need` steps (NW = 4P flag words, one per
-// lane).  Returns false on timeout.
-template <int NW>
-__device__ __forceinline__ bool wait_group(const unsigned *gflags, const unsigned need, const int lane) {
-    for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
-        const unsigned v = lane < NW ? ld_sc1_u32(gflags + lane) : 0xffffffffu;
-        if (__all(v >= need)) return true;
-#if !defined(NSD_POLL_NO_SLEEP)
-        __builtin_amdgcn_s_sleep(1);
-#endif
-    }
-    return false;
-}
-
-// Start of a scan: publish this workgroup's XCC id, wait for the whole group (every wave polls; bounded), report whether the
-// group sits on one XCD.  Returns -1 on timeout, else 0 / 1.
-template <int P>
-__device__ __forceinline__ int group_rendezvous(unsigned *gwords, const int p, const int wave, const int lane) {
-    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;       // HW_REG_XCC_ID[3:0]
-    if (wave == 0 && lane == 0) st_sc1_u32(gwords + 64 + p, xcc + 1u);
-    for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
-        const unsigned v = lane < P ? ld_sc1_u32(gwords + 64 + lane) : xcc + 1u;
-        if (__all(v != 0u)) return __all(v == xcc + 1u) ? 1 : 0;
-        __builtin_amdgcn_s_sleep(4);
-    }
-    return -1;
-}
-// exchange stores: plain when the group shares an L2, write-through otherwise
-__device__ __forceinline__ void st_xchg_u64(const bool same_l2, void *p, const unsigned long long v) {
-    if (same_l2) *reinterpret_cast<unsigned long long *>(p) = v; else st_sc1_u64(p, v);
-}
-__device__ __forceinline__ void st_xchg_u32(const bool same_l2, void *p, const unsigned v) {
-    if (same_l2) *reinterpret_cast<unsigned *>(p) = v; else st_sc1_u32(p, v);
-}
-
-__device__ __forceinline__ f32x16 unpack_tile(const u32x4 lo, const u32x4 hi) {
-    f32x16 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[2 * i] = bf16_lo(lo[i]); v[2 * i + 1] = bf16_hi(lo[i]);
-        v[8 + 2 * i] = bf16_lo(hi[i]); v[8 + 2 * i + 1] = bf16_hi(hi[i]);
-    }
-    return v;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
 // forward scan
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int H, int NT>
@@ -210,17 +134,22 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     const int u0 = 8 * gt + 4 * hh;                            // first of this lane's 4 units
     const bool train = a.cs[0] != nullptr;
 
-    for (int s = 0; s < a.T; ++s) {
-        const int t = dir == 0 ? s : a.T - 1 - s;
-        const int tp = dir == 0 ? t - 1 : t + 1;
-        // input projection of this step (independent of the recurrence: its latency runs under the wait below)
-        u32x4 xp[NT][2];
+    // input projection tiles: the one of step s+1 is requested AFTER the tile gather of step s has landed (vector memory
+    // returns in issue order: an HBM read issued ahead of the gather would put its latency on every step's critical path)
+    u32x4 xp[NT][2], xpn[NT][2];
+    auto load_xp = [&](const int t, u32x4 (&dst)[NT][2]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const bf16_t *src = a.xproj[dir] + ((((long)t * (Bp >> 5) + (b0 >> 5) + nt) * (G >> 5) + gt) * 64 + lane) * 16;
-            xp[nt][0] = *reinterpret_cast<const u32x4 *>(src);
-            xp[nt][1] = *reinterpret_cast<const u32x4 *>(src + 8);
+            dst[nt][0] = *reinterpret_cast<const u32x4 *>(src);
+            dst[nt][1] = *reinterpret_cast<const u32x4 *>(src + 8);
         }
+    };
+    load_xp(dir == 0 ? 0 : a.T - 1, xp);
+    for (int s = 0; s < a.T; ++s) {
+        const int t = dir == 0 ? s : a.T - 1 - s;
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const int tnx = dir == 0 ? t + 1 : t - 1;              // next step's time index
         f32x16 acc[NT];
         if (s > 0) {
             bf16_t *Bt = Bt2[s & 1];
@@ -244,16 +173,12 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
             }
             __syncthreads();
             if (s_abort) break;                                 // uniform: every thread reads the same word after the barrier
+            if (s + 1 < a.T) load_xp(tnx, xpn);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(Bt + (32 * nt + col) * LDB + 16 * ks + 8 * hh);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], b, acc[nt], 0, 0, 0);
-                }
+            mfma_rows<NT, KS, LDB>(w, Bt, col, hh, acc);
         } else {
+            if (s + 1 < a.T) load_xp(tnx, xpn);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
         }
@@ -316,6 +241,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 *reinterpret_cast<u32x4 *>(gd + 8) = u32x4{gw[4], gw[5], gw[6], gw[7]};
             }
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { xp[nt][0] = xpn[nt][0]; xp[nt][1] = xpn[nt][1]; }
     }
 }
 
@@ -447,13 +374,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                         pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}
                                                       : ld_sc1_b128(rd, (unsigned)(((lrow + RPI * i) * ldda + CW * (ch + 1) + 8 * lpc) * 2));
                 }
-#pragma unroll
-                for (int k = 0; k < CW / 16; ++k)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(strip + (32 * nt + col) * LDS_ + 16 * k + 8 * hh);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ch * (CW / 16) + k], b, acc[nt], 0, 0, 0);
-                    }
+                mfma_rows<NT, CW / 16, LDS_>(w + ch * (CW / 16), strip, col, hh, acc);
                 // (the compiler orders the next chunk's ds_write behind these ds_reads: same wave, same LDS object)
             }
 #pragma unroll

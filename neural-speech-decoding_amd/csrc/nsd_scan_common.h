@@ -1,0 +1,197 @@
+// nsd_scan_common.h -- what the persistent scan kernels share (nsd_scan.hip: one layer per launch; nsd_scan2.hip: two
+// unidirectional layers skewed by one step in one launch): group geometry, the flag protocol, exchange stores.
+#pragma once
+#include "nsd_seq.h"
+
+// timing experiments only (make ABL=n -> libnsd_hip_abl.so, never shipped): bit 0 skip the flag wait, bit 1 skip the tile
+// gather, bit 2 skip the drain of the published stores -- results are wrong by construction, only the time is of interest
+#ifndef NSD_SCAN_ABLATE
+#define NSD_SCAN_ABLATE 0
+#endif
+
+// diagnostic build only (-DNSD_SCAN_STAMPS=1, never shipped): s_memtime stamps around the phases of a scan step, summed by
+// wave 0 of workgroup 0 into the words behind the status word (read with tools/seq_stamps.py)
+#ifndef NSD_SCAN_STAMPS
+#define NSD_SCAN_STAMPS 0
+#endif
+
+namespace {
+
+struct Stamps {
+    unsigned long long last, acc[8];
+    __device__ __forceinline__ void start() {
+        if (NSD_SCAN_STAMPS) { for (int i = 0; i < 8; ++i) acc[i] = 0; __builtin_amdgcn_sched_barrier(0); last = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    }
+    // WAITV: also drain the wave's vector-memory queue first, so that the phase ends when its loads have really arrived
+    template <bool WAITV = false>
+    __device__ __forceinline__ void mark(const int i) {
+        if (NSD_SCAN_STAMPS) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (WAITV) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the stamp lands behind the phase's LDS traffic
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            acc[i] += t - last; last = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __device__ __forceinline__ void store(int *status, const bool who) {
+        if (NSD_SCAN_STAMPS && who) for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long *>(status + 4)[i] = acc[i];
+    }
+};
+
+constexpr unsigned SPIN_LIMIT = 1u << 20;          // polls (each >= ~1 us with the sleep): ~1-2 s, then give up
+constexpr int ST_FWD_TIMEOUT = 1, ST_BWD_TIMEOUT = 2;
+constexpr int GROUP_WORDS = 128;                   // flag words per group: [0,64) one per wave of every member, [64,80) XCC ids
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// group geometry shared by both scans
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Member { int dir, group, p; };
+// Members of a group get block ids that are equal mod 8 where the grid allows it: those blocks are observed to share an XCD,
+// so the exchange stays inside one L2.  Speed only -- the protocol does not depend on placement.
+__device__ __forceinline__ Member member_of(const int bid, const int groups, const int P, const int spread) {
+    Member m;
+    const int nper = groups * P;
+    m.dir = bid / nper;
+    const int rem = bid - m.dir * nper;
+    if (!spread && (nper & 7) == 0 && ((nper >> 3) % P) == 0) {
+        const int x = rem & 7, slot = rem >> 3;
+        m.group = x * ((nper >> 3) / P) + slot / P;
+        m.p = slot % P;
+    } else {
+        m.group = rem / P;
+        m.p = rem % P;
+    }
+    return m;
+}
+
+// one wave: wait until every wave of every member of the group has published `need` steps (NW = 4P flag words, one per
+// lane).  Returns false on timeout.
+template <int NW>
+__device__ __forceinline__ bool wait_group(const unsigned *gflags, const unsigned need, const int lane) {
+    for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        const unsigned v = lane < NW ? ld_sc1_u32(gflags + lane) : 0xffffffffu;
+        if (__all(v >= need)) return true;
+#if !defined(NSD_POLL_NO_SLEEP)
+        __builtin_amdgcn_s_sleep(1);
+#endif
+    }
+    return false;
+}
+
+// Start of a scan: publish this workgroup's XCC id, wait for the whole group (every wave polls; bounded), report whether the
+// group sits on one XCD.  Returns -1 on timeout, else 0 / 1.
+template <int P>
+__device__ __forceinline__ int group_rendezvous(unsigned *gwords, const int p, const int wave, const int lane) {
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;       // HW_REG_XCC_ID[3:0]
+    if (wave == 0 && lane == 0) st_sc1_u32(gwords + 64 + p, xcc + 1u);
+    for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        const unsigned v = lane < P ? ld_sc1_u32(gwords + 64 + lane) : xcc + 1u;
+        if (__all(v != 0u)) return __all(v == xcc + 1u) ? 1 : 0;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return -1;
+}
+// exchange stores: plain when the group shares an L2, write-through otherwise
+__device__ __forceinline__ void st_xchg_u64(const bool same_l2, void *p, const unsigned long long v) {
+    if (same_l2) *reinterpret_cast<unsigned long long *>(p) = v; else st_sc1_u64(p, v);
+}
+__device__ __forceinline__ void st_xchg_u32(const bool same_l2, void *p, const unsigned v) {
+    if (same_l2) *reinterpret_cast<unsigned *>(p) = v; else st_sc1_u32(p, v);
+}
+
+__device__ __forceinline__ f32x16 unpack_tile(const u32x4 lo, const u32x4 hi) {
+    f32x16 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = bf16_lo(lo[i]); v[2 * i + 1] = bf16_hi(lo[i]);
+        v[8 + 2 * i] = bf16_lo(hi[i]); v[8 + 2 * i + 1] = bf16_hi(hi[i]);
+    }
+    return v;
+}
+
+
+// acc[nt] += W[k0 .. k0+NK) . tile: the B fragments of FB k steps are read from LDS into DISTINCT registers first, then the
+// MFMAs issue back to back.  (Left to itself hipcc reuses one fragment register set: ds_read -> lgkmcnt(0) -> mfma, 48 times
+// a step -- the LDS latency, not the matrix pipe, then sets the pace: 4.8 us of a 6.7 us fused step.)
+template <int NT, int NK, int LD>
+__device__ __forceinline__ void mfma_rows(const bf16x8 *w, const bf16_t *tile, const int col, const int hh, f32x16 (&acc)[NT]) {
+    constexpr int FB = NK < 8 ? NK : 8;
+#pragma unroll
+    for (int k0 = 0; k0 < NK; k0 += FB) {
+        bf16x8 b[NT][FB];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < FB; ++k) b[nt][k] = *reinterpret_cast<const bf16x8 *>(tile + (32 * nt + col) * LD + 16 * (k0 + k) + 8 * hh);
+        __builtin_amdgcn_sched_barrier(0);          // keep the batch of reads ahead of the batch of MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+        for (int k = 0; k < FB; ++k)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[k0 + k], b[nt][k], acc[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- exchange rings -------------------------------------------------------------------------------------------------------
+// The workgroups of a group do not exchange through the saved sequences (hs[t], da[t]): there an 8- or 32-byte piece of a
+// 128-byte line comes from each of up to 8 producer waves, and lines assembled from partial writes are merged beyond the L2
+// -- every gather load then waited ~5 000 cycles (in-kernel stamps).  They exchange through small rings (two slots, step
+// parity) in which every producer wave owns whole lines and writes them with ONE store instruction each:
+//   h  block of a batch tile, MG*H bf16:   [gate tile gt = 4p + wave][nt][trial 32][8 units]           lane (trial, hh): 8 bytes at hh*8
+//   da block of a batch tile, MG*4H bf16:  [gate tile][nt][half 2][trial 32][hh 2][8 columns]          lane: 16 bytes per half
+//      (half 0: the lane's units 4hh+0,1; half 1: units 4hh+2,3 -- a wave's two 16-byte stores are each one contiguous KB)
+// Two slots are enough: a member publishes step s only after it has gathered step s-1 from every member, i.e. after every
+// member has finished reading slot (s & 1) for step s-2.  The row-major tensors are still written (plain stores, behind the
+// flag) for the GEMMs and the head that read them after the scan.
+__device__ __forceinline__ long ring_h_off(const int gt, const int nt, const int NT, const int col, const int hh) {
+    return ((long)(gt * NT + nt) * 32 + col) * 8 + 4 * hh;
+}
+__device__ __forceinline__ void ring_put_da(const bool same_l2, bf16_t *block, const int gt, const int nt, const int NT, const int col,
+                                            const int hh, const unsigned (&dw)[8]) {
+    bf16_t *p0 = block + ((((long)(gt * NT + nt) * 2 + 0) * 32 + col) * 2 + hh) * 8;
+    bf16_t *p1 = block + ((((long)(gt * NT + nt) * 2 + 1) * 32 + col) * 2 + hh) * 8;
+    if (same_l2) {
+        *reinterpret_cast<u32x4 *>(p0) = u32x4{dw[0], dw[1], dw[2], dw[3]};
+        *reinterpret_cast<u32x4 *>(p1) = u32x4{dw[4], dw[5], dw[6], dw[7]};
+    } else {
+        const nsd_rsrc r0 = make_rsrc(block, 0x7fffffffu);
+        st_sc1_b128(r0, (unsigned)((p0 - block) * 2), u32x4{dw[0], dw[1], dw[2], dw[3]});
+        st_sc1_b128(r0, (unsigned)((p1 - block) * 2), u32x4{dw[4], dw[5], dw[6], dw[7]});
+    }
+}
+// one chunk (CW columns = CW/32 gate tiles starting at gt0) of a da block -> registers (NLD = (CW/32) * NT * 2 pieces per lane,
+// each load instruction reads one contiguous KB) and -> the wave's LDS strip [MG rows][CW + 8], columns in unit-major order
+template <int NT, int CW>
+struct DaChunk {
+    static constexpr int TPC = CW / 32, NLD = TPC * NT * 2, LDS_ = CW + 8;
+    u32x4 v[NLD];
+    __device__ __forceinline__ void load(const nsd_rsrc r, const int gt0, const int lane) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int gtl = i / (2 * NT), rr = i % (2 * NT), nt = rr >> 1, half = rr & 1;
+            v[i] = ld_sc1_b128(r, (unsigned)((((((long)(gt0 + gtl) * NT + nt) * 2 + half) * 64 + lane) * 8) * 2));
+        }
+    }
+    __device__ __forceinline__ void to_strip(bf16_t *strip, const int lane) const {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int gtl = i / (2 * NT), rr = i % (2 * NT), nt = rr >> 1, half = rr & 1;
+            *reinterpret_cast<u32x4 *>(strip + (32 * nt + (lane >> 1)) * LDS_ + 32 * gtl + 16 * (lane & 1) + 8 * half) = v[i];
+        }
+    }
+};
+
+// dropout multipliers of 4 adjacent units of one (layer, trial, step): the product's counter stream (nsd_rand_u32, index
+// ((layer * B + b) * T + t) * ld + column); all 1 for padding trials or when the stream is off
+__device__ __forceinline__ void drop_mult4(const RngArgs &rng, const bool on, const int layer, const int B, const int T, const int b,
+                                           const int t, const long ld, const int col0, float (&m)[4]) {
+    m[0] = m[1] = m[2] = m[3] = 1.f;
+    if (on && b < B) {
+        const uint64_t base = (((uint64_t)layer * B + b) * T + t) * (uint64_t)ld + (uint64_t)col0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = nsd_rand_u32(rng.seed, rng.base, base + j) >= rng.thr_lstm ? rng.keep_lstm : 0.f;
+    }
+}
+
+}  // namespace

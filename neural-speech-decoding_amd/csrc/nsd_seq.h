@@ -24,6 +24,7 @@
 struct SeqDims {
     int B, T, C, H, L, K, F, D;
     int residual;                   // extension: out_l = LSTM_l(in_l) + in_l for l >= 1
+    int fused2;                     // two unidirectional layers advance in one launch (nsd_scan2.hip)
     int Bp, MG, CP, P, groups;      // derived: padded batch, trials per group (32 or 64), padded channels, workgroups per group, groups per direction
 };
 
@@ -43,8 +44,8 @@ struct SeqWs {
     int64_t hs[NSD_MAX_LAYERS], lk[NSD_MAX_LAYERS];
     int64_t cs[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS], ga[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS];
     int64_t xproj[NSD_SEQ_MAX_DIRS];
-    int64_t da, din[2];
-    int64_t alpha, dscore, pooled, dpooled, loss, hb, parts, dbp;
+    int64_t da, da2, din[2];
+    int64_t alpha, dscore, pooled, dpooled, loss, hb, parts, dbp, xch;
     int64_t total;
     int64_t flags_bytes, hb_stride;
 };
@@ -81,6 +82,38 @@ struct ScanBwdArgs {
     int allow_l2_mode, spread_groups;
     RngArgs rng;
 };
+// two unidirectional layers in ONE launch, layer 1 one time step behind layer 0 (nsd_scan2.hip): half the serial steps, the
+// input projection of layer 1 and the input gradient of layer 1 ride in the scans (no GEMM, no xproj / din round trip)
+struct Scan2FwdArgs {
+    const bf16_t *wf0, *wx1, *wf1;           // [4H][H] each, rows in accumulator-tile order: W_hh0, W_ih1, W_hh1
+    const float *bsum1;                      // [4H] b_ih1 + b_hh1, tile order
+    const bf16_t *xproj0;                    // layer-0 input projection tiles (bias included)
+    bf16_t *hs0, *lk0, *hs1;                 // [T*Bp][H]; lk0 = h0 * multiplier or null
+    bf16_t *xch;                             // exchange ring [2][groups_total][3][MG*H]
+    int groups_total;
+    bf16_t *cs0, *ga0, *cs1, *ga1;           // saves or null (inference)
+    unsigned *flags;
+    int *status;
+    int B, Bp, T, groups, group0;
+    int allow_l2_mode, spread_groups;
+    RngArgs rng;
+};
+struct Scan2BwdArgs {
+    const bf16_t *wb0, *wb1, *wxt1;          // [H][4H] each: W_hh0^T, W_hh1^T, W_ih1^T (k = unit-major gate column)
+    const bf16_t *cs0, *ga0, *cs1, *ga1;
+    bf16_t *da0, *da1;                       // [T*Bp][4H]
+    bf16_t *xch;                             // exchange ring [2][groups_total][2][MG*4H]
+    float *dbp0, *dbp1;                      // [groups_total][4H]
+    const float *alpha, *dscore, *dpooled, *attn_w;
+    unsigned *flags;
+    int *status;
+    int B, Bp, T, groups, group0, groups_total;
+    int allow_l2_mode, spread_groups;
+    RngArgs rng;                             // rng.on: multiplier of layer 0's output
+};
+bool nsd_scan2_supported(int H, int MG);
+int nsd_scan2_fwd_launch(const Scan2FwdArgs &a, int H, int MG, hipStream_t st);
+int nsd_scan2_bwd_launch(const Scan2BwdArgs &a, int H, int MG, hipStream_t st);
 int nsd_scan_fwd_launch(const ScanFwdArgs &a, int H, int MG, hipStream_t st);
 int nsd_scan_bwd_launch(const ScanBwdArgs &a, int H, int MG, hipStream_t st);
 bool nsd_scan_supported(int H);

@@ -47,6 +47,8 @@ int derive(const nsd_dims *d, uint32_t flags, SeqDims *o) {
     s.MG = (g32 <= cap) ? 32 : 64;
     s.Bp = (int)align_up(s.B > 0 ? s.B : 1, s.MG);
     s.groups = s.Bp / s.MG;
+    // two unidirectional layers: one launch advances both, layer 1 a step behind layer 0 (nsd_scan2.hip)
+    s.fused2 = (s.D == 1 && s.L == 2 && !s.residual && !(flags & NSD_FLAG_NO_FUSED_LAYERS) && nsd_scan2_supported(s.H, s.MG)) ? 1 : 0;
     *o = s;
     return NSD_OK;
 }
@@ -80,6 +82,7 @@ SeqWs make_ws(const SeqDims &s) {
     }
     for (int d = 0; d < s.D; ++d) w.xproj[d] = take(R * G * 2);
     w.da = take(R * s.D * G * 2);
+    w.da2 = s.fused2 ? take(R * G * 2) : 0;                  // fused two-layer scans: layer 1's da next to layer 0's
     w.din[0] = take(R * DH * 4);
     w.din[1] = s.residual ? take(R * DH * 4) : 0;           // residual extension: d(linked output) passed around the LSTM
     w.alpha = take(R * 4);
@@ -89,7 +92,8 @@ SeqWs make_ws(const SeqDims &s) {
     w.loss = take((int64_t)s.Bp * 4);
     w.hb_stride = align_up(nsd_head_tm_row_floats((int)DH, s.F, s.K), 4);
     w.hb = take((int64_t)s.Bp * w.hb_stride * 4);
-    w.dbp = take((int64_t)s.D * s.groups * G * 4);
+    w.dbp = take((int64_t)(s.D > 2 ? s.D : 2) * s.groups * G * 4);
+    w.xch = take(2LL * s.groups * 3 * s.MG * (s.D * 4LL * H) * 2);   // exchange rings of the scans (sized for the widest: da tiles)
     w.parts = take(64LL * 1024 * 1024);                          // split-K partials of the weight-gradient GEMMs (<= 16 M floats)
     w.total = p;
     return w;
@@ -178,6 +182,38 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             if (const int rc = nsd_seq_prep_launch(p, c.st)) { delete prep; return rc; }
         }
     delete prep;
+    if (s.fused2) {
+        const bool lstm_drop = train && rng.on && rng.thr_lstm != 0;
+        {
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A = at<bf16_t>(c.ws, c.w.wx[0][0]); g.lda = s.CP; g.B = at<bf16_t>(c.ws, c.w.xbf); g.ldb = s.CP;
+            g.C = at<bf16_t>(c.ws, c.w.xproj[0]); g.bias = at<float>(c.ws, c.w.bsum[0][0]);
+            g.M = G; g.N = (int)R; g.K = s.CP; g.splits = 1; g.epi = GEMM_EPI_TILE_BF16;
+            ProfScope ps(PK_GEMM_XPROJ, c.st);
+            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+        }
+        for (int g0 = 0; g0 < s.groups; g0 += c.cap) {
+            Scan2FwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.wf0 = at<bf16_t>(c.ws, c.w.wf[0][0]); a.wx1 = at<bf16_t>(c.ws, c.w.wx[1][0]); a.wf1 = at<bf16_t>(c.ws, c.w.wf[1][0]);
+            a.bsum1 = at<float>(c.ws, c.w.bsum[1][0]); a.xproj0 = at<bf16_t>(c.ws, c.w.xproj[0]);
+            a.hs0 = at<bf16_t>(c.ws, c.w.hs[0]); a.lk0 = lstm_drop ? at<bf16_t>(c.ws, c.w.lk[0]) : nullptr; a.hs1 = at<bf16_t>(c.ws, c.w.hs[1]);
+            a.xch = at<bf16_t>(c.ws, c.w.xch); a.groups_total = s.groups;
+            if (train) {
+                a.cs0 = at<bf16_t>(c.ws, c.w.cs[0][0]); a.ga0 = at<bf16_t>(c.ws, c.w.ga[0][0]);
+                a.cs1 = at<bf16_t>(c.ws, c.w.cs[1][0]); a.ga1 = at<bf16_t>(c.ws, c.w.ga[1][0]);
+            }
+            a.flags = at<unsigned>(c.ws, c.w.flags) + (long)g0 * 128;
+            a.status = at<int>(c.ws, c.w.status);
+            a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.groups = s.groups - g0 < c.cap ? s.groups - g0 : c.cap; a.group0 = g0;
+            a.rng = rng; a.rng.on = lstm_drop ? 1 : 0;
+            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread;
+            ProfScope ps(PK_SCAN_FWD, c.st);
+            if (const int rc = nsd_scan2_fwd_launch(a, H, s.MG, c.st)) return rc;
+        }
+        return NSD_OK;
+    }
     for (int l = 0; l < s.L; ++l) {
         // a layer writes its LINKED output lk[l] = (h [+ its input]) * multiplier when that differs from h: inter-layer dropout
         // active (l < L-1) or the residual extension (l >= 1); readers take lk[l] then, hs[l] otherwise
@@ -238,8 +274,62 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
     const int H = s.H, G = 4 * H, DH = s.D * H;
     const long R = (long)s.T * s.Bp;
     float *parts = at<float>(c.ws, c.w.parts);
+    const bool lstm_drop = rng.on && rng.thr_lstm != 0;
+    // contractions over the whole sequence for layer l: dW_hh, dW_ih (split-K, fixed-order reduction), biases from the scan's
+    // per-tile sums.  da: [T*Bp][ldda] with direction d in columns d*4H..; dbp: [D][groups][4H]
+    auto weight_grads = [&](int l, const bf16_t *da, long ldda, const float *dbp) -> int {
+        const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : out_of(c, l - 1, lstm_drop);
+        const int Kin = l == 0 ? s.CP : DH, I = l == 0 ? s.C : DH;
+        for (int d = 0; d < s.D; ++d) {
+            ProfScope ps(PK_GEMM_DW, c.st);
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A = da + (long)d * G; g.lda = ldda; g.a_kmajor = 1; g.b_kmajor = 1;
+            g.C = parts; g.M = G; g.K = R; g.epi = GEMM_EPI_F32;
+            // recurrent weights: operand h_{t-1} of the direction (one time step = Bp rows away)
+            g.B = at<bf16_t>(c.ws, c.w.hs[l]) + (long)d * H; g.ldb = DH; g.N = H; g.ldc = H;
+            g.b_shift = d == 0 ? -(long)s.Bp : (long)s.Bp;
+            g.splits = split_count(G, H, R);
+            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+            hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * H + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, H, H,
+                               grads + c.pl.w_hh[l][d]);
+            // input weights
+            g.B = in; g.ldb = Kin; g.N = Kin; g.ldc = Kin; g.b_shift = 0;
+            g.splits = split_count(G, Kin, R);
+            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+            hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * I + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, Kin, I,
+                               grads + c.pl.w_ih[l][d]);
+            hipLaunchKernelGGL(seq_reduce_db_kernel, dim3((G + 255) / 256), dim3(256), 0, c.st, dbp + (long)d * s.groups * G, s.groups, H,
+                               grads + c.pl.b_ih[l][d], grads + c.pl.b_hh[l][d]);
+            NSD_CHECK_LAUNCH("seq weight gradients");
+        }
+        return NSD_OK;
+    };
+    if (s.fused2) {
+        float *dbp0 = at<float>(c.ws, c.w.dbp), *dbp1 = dbp0 + (long)s.groups * G;
+        for (int g0 = 0; g0 < s.groups; g0 += c.cap) {
+            Scan2BwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.wb0 = at<bf16_t>(c.ws, c.w.wb[0][0]); a.wb1 = at<bf16_t>(c.ws, c.w.wb[1][0]); a.wxt1 = at<bf16_t>(c.ws, c.w.wxt[1]);
+            a.cs0 = at<bf16_t>(c.ws, c.w.cs[0][0]); a.ga0 = at<bf16_t>(c.ws, c.w.ga[0][0]);
+            a.cs1 = at<bf16_t>(c.ws, c.w.cs[1][0]); a.ga1 = at<bf16_t>(c.ws, c.w.ga[1][0]);
+            a.da0 = at<bf16_t>(c.ws, c.w.da); a.da1 = at<bf16_t>(c.ws, c.w.da2); a.dbp0 = dbp0; a.dbp1 = dbp1;
+            a.xch = at<bf16_t>(c.ws, c.w.xch);
+            a.alpha = at<float>(c.ws, c.w.alpha); a.dscore = at<float>(c.ws, c.w.dscore); a.dpooled = at<float>(c.ws, c.w.dpooled);
+            a.attn_w = c.params + c.pl.attn_w;
+            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)s.L * s.D * s.groups + (long)g0) * 128;
+            a.status = at<int>(c.ws, c.w.status);
+            a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.groups = s.groups - g0 < c.cap ? s.groups - g0 : c.cap; a.group0 = g0; a.groups_total = s.groups;
+            a.rng = rng; a.rng.on = lstm_drop ? 1 : 0;
+            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread;
+            ProfScope ps(PK_SCAN_BWD, c.st);
+            if (const int rc = nsd_scan2_bwd_launch(a, H, s.MG, c.st)) return rc;
+        }
+        if (const int rc = weight_grads(1, at<bf16_t>(c.ws, c.w.da2), G, dbp1)) return rc;
+        if (const int rc = weight_grads(0, at<bf16_t>(c.ws, c.w.da), G, dbp0)) return rc;
+    } else
     for (int l = s.L - 1; l >= 0; --l) {
-        const bool masked = rng.on && l < s.L - 1 && rng.thr_lstm != 0;
+        const bool masked = lstm_drop && l < s.L - 1;
         for (int g0 = 0; g0 < s.groups; g0 += c.cap) {
             ScanBwdArgs a;
             memset(&a, 0, sizeof(a));
@@ -264,39 +354,11 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             ProfScope ps(PK_SCAN_BWD, c.st);
             if (const int rc = nsd_scan_bwd_launch(a, H, s.MG, c.st)) return rc;
         }
-        // ---- contractions over the whole sequence
-        const bf16_t *da = at<bf16_t>(c.ws, c.w.da);
-        const bool lstm_drop = rng.on && rng.thr_lstm != 0;
-        const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : out_of(c, l - 1, lstm_drop);
-        const int Kin = l == 0 ? s.CP : DH, I = l == 0 ? s.C : DH;
-        for (int d = 0; d < s.D; ++d) {
-            ProfScope ps(PK_GEMM_DW, c.st);
-            GemmArgs g;
-            memset(&g, 0, sizeof(g));
-            g.A = da + (long)d * G; g.lda = (long)s.D * G; g.a_kmajor = 1; g.b_kmajor = 1;
-            g.C = parts; g.M = G; g.K = R; g.epi = GEMM_EPI_F32;
-            // recurrent weights: operand h_{t-1} of the direction (one time step = Bp rows away)
-            g.B = at<bf16_t>(c.ws, c.w.hs[l]) + (long)d * H; g.ldb = DH; g.N = H; g.ldc = H;
-            g.b_shift = d == 0 ? -(long)s.Bp : (long)s.Bp;
-            g.splits = split_count(G, H, R);
-            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
-            hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * H + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, H, H,
-                               grads + c.pl.w_hh[l][d]);
-            // input weights
-            g.B = in; g.ldb = Kin; g.N = Kin; g.ldc = Kin; g.b_shift = 0;
-            g.splits = split_count(G, Kin, R);
-            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
-            hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * I + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, Kin, I,
-                               grads + c.pl.w_ih[l][d]);
-            // biases: the backward scan summed da over time per batch tile
-            hipLaunchKernelGGL(seq_reduce_db_kernel, dim3((G + 255) / 256), dim3(256), 0, c.st, at<float>(c.ws, c.w.dbp) + (long)d * s.groups * G,
-                               s.groups, H, grads + c.pl.b_ih[l][d], grads + c.pl.b_hh[l][d]);
-            NSD_CHECK_LAUNCH("seq weight gradients");
-        }
+        if (const int rc = weight_grads(l, at<bf16_t>(c.ws, c.w.da), (long)s.D * G, at<float>(c.ws, c.w.dbp))) return rc;
         if (l > 0) {                                             // gradient w.r.t. the layer's input, both directions in one contraction
             GemmArgs g;
             memset(&g, 0, sizeof(g));
-            g.A = da; g.lda = (long)s.D * G; g.B = at<bf16_t>(c.ws, c.w.wxt[l]); g.ldb = (long)s.D * G;
+            g.A = at<bf16_t>(c.ws, c.w.da); g.lda = (long)s.D * G; g.B = at<bf16_t>(c.ws, c.w.wxt[l]); g.ldb = (long)s.D * G;
             g.C = at<float>(c.ws, c.w.din[0]); g.ldc = DH; g.M = (int)R; g.N = DH; g.K = (long)s.D * G; g.splits = 1; g.epi = GEMM_EPI_F32;
             g.add = s.residual ? at<float>(c.ws, c.w.din[1]) : nullptr;       // residual extension: + d(linked output) of this layer
             ProfScope ps(PK_GEMM_DIN, c.st);

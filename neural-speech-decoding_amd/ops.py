@@ -114,11 +114,13 @@ _extra_flags = 0
 _seq_extra_flags = 0
 
 
-def set_seq_l2_exchange(on: bool, spread_groups: bool = False) -> None:
+def set_seq_l2_exchange(on: bool, spread_groups: bool = False, fused_layers: bool = True) -> None:
     """Sequence-batched path, diagnostics: on=False -> scan groups always use the write-through exchange
-    (NSD_FLAG_NO_L2_EXCHANGE); spread_groups=True -> every group is spread over all XCDs (NSD_FLAG_SPREAD_GROUPS)."""
+    (NSD_FLAG_NO_L2_EXCHANGE); spread_groups=True -> every group is spread over all XCDs (NSD_FLAG_SPREAD_GROUPS);
+    fused_layers=False -> two unidirectional layers run as two scans + GEMMs instead of one skewed launch."""
     global _seq_extra_flags
-    _seq_extra_flags = (0 if on else _lib.NSD_FLAG_NO_L2_EXCHANGE) | (_lib.NSD_FLAG_SPREAD_GROUPS if spread_groups else 0)
+    _seq_extra_flags = ((0 if on else _lib.NSD_FLAG_NO_L2_EXCHANGE) | (_lib.NSD_FLAG_SPREAD_GROUPS if spread_groups else 0)
+                        | (0 if fused_layers else _lib.NSD_FLAG_NO_FUSED_LAYERS))
 
 
 def set_gemm_bf16(on: bool) -> None:

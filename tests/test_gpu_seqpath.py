@@ -227,9 +227,38 @@ def test_seq_exchange_modes_agree(nsd, dev):
     print("scan groups on one XCD / spread, per mode:", placement)
     for lg, g in out[1:]:
         assert torch.equal(out[0][0], lg) and torch.equal(out[0][1], g)
-    n_groups = 2 * L * 8                                        # forward + backward scans, L layers, 256 / 32 batch tiles
+    n_groups = 2 * 8                                            # one skewed two-layer scan forward + one backward, 256 / 32 batch tiles
     assert all(a + b == n_groups for a, b in placement)
     assert placement[2][1] == n_groups                          # spread really means spread: the write-through path carried the run
+
+
+def test_two_layer_skewed_launch_vs_layer_by_layer(nsd, dev):
+    """L = 2 unidirectional runs as ONE launch with layer 1 a step behind layer 0 (its input projection and input gradient ride
+    in the scans); the diagnostic flag restores the general route (scan + GEMM per layer).  Same model, same streams: the
+    two routes differ only in where bf16 roundings fall (the general route rounds the input projection to bf16 tiles)."""
+    from nsd_amd import ops
+    H, L, K, B, T = 128, 2, 5, 100, 30
+    d = orc.Dims(C=8, H=H, L=L, K=K)
+    st = synth_params(8, H, L, K, seed=9)
+    x, y = synth_x(B, T, seed=3), synth_labels(B, K, seed=3)
+    flat = _flat(st, d, dev)
+    xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    rng = dict(seed=77, base_stream=16, p_lstm=0.5, p_head=0.5)
+    res = []
+    for fused in (True, False):
+        ops.set_seq_l2_exchange(True, False, fused)
+        try:
+            spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+            ws = ops.seq_workspace(spec, B, T, dev)
+            lg = ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng).clone()
+            g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
+            stt, a, b = ops.seq_status(ws, detail=True)
+            assert stt == 0 and a + b == (2 if fused else 4) * 4          # 4 batch tiles; 2 scan launches fused, 4 layer by layer
+            res.append((lg, g))
+        finally:
+            ops.set_seq_l2_exchange(True, False, True)
+    assert (res[0][0] - res[1][0]).abs().max().item() < 2e-2
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 3e-2 * res[1][1].abs().max().item()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,36 @@
+"""Per-phase cycles of a scan step from the diagnostic build (NSD_LIB=libnsd_hip_stamps.so): forward of cfg3, inference and training."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import nsd_amd
+from nsd_amd import ops
+spec, B, T = ops.ModelSpec(C=8, H=256, L=2, K=5), 1024, 250
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+flat = (torch.rand(spec.param_count, device=dev) * 2 - 1) / 16
+x = 2.7 * torch.randn(B, T, 8, device=dev)
+y = torch.randint(0, 5, (B,), device=dev, dtype=torch.int32)
+ws = ops.seq_workspace(spec, B, T, dev)
+names = ["poll", "barrier (wait for the other waves)", "mfma", "cells", "publish(store+drain+flag)", "saves+rotate", "gather loads -> arrival", "ds_write"]
+for mode in ("infer", "train"):
+    for _ in range(3):
+        if mode == "infer":
+            ops.seq_infer(spec, flat, x, ws, want_probs=False)
+        else:
+            ops.seq_train_fwd(spec, flat, x, y, ws, rng=dict(seed=1, base_stream=4, p_lstm=0.6, p_head=0.6))
+        torch.cuda.synchronize()
+    st = ws[:128].cpu().numpy().view(np.int32)
+    acc = st[4:20].view(np.uint64)
+    tot = acc.sum()
+    print(f"{mode}: forward scan, cycles per step of workgroup 0 wave 0 (s_memtime = 100 MHz ticks? see total): total/step {tot / (T + 1):.0f}")
+    for n, v in zip(names, acc):
+        print(f"   {n:28s} {v / (T + 1):9.1f}  ({100.0 * v / max(tot, 1):5.1f} %)")
+g = torch.zeros(spec.param_count, device=dev)
+for _ in range(3):
+    ops.seq_train_bwd(spec, flat, ws, B, T, rng=dict(seed=1, base_stream=4, p_lstm=0.6, p_head=0.6), grads=g)
+    torch.cuda.synchronize()
+acc = ws[:128].cpu().numpy().view(np.int32)[4:20].view(np.uint64)
+tot = acc.sum()
+print(f"backward scan: total/step {tot / (T + 1):.0f}")
+for n, v in zip(["top: issue saved-activation loads + poll", "X tile: stage + 2x16 MFMA", "Y tile: stage + 16 MFMA", "partials -> LDS", "barrier", "reduce + wait for saved activations", "cells + ring stores", "drain + flag"], acc):
+    print(f"   {n:40s} {v / (T + 1):9.1f}  ({100.0 * v / max(tot, 1):5.1f} %)")
