@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 
     // input projection tiles: the one of step s+1 is requested AFTER the tile gather of step s has landed (vector memory
     // returns in issue order: an HBM read issued ahead of the gather would put its latency on every step's critical path)
-    u32x4 xp[NT][2], xpn[NT][2];
+    u32x4 xp[NT][2];
     auto load_xp = [&](const int t, u32x4 (&dst)[NT][2]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -173,14 +173,18 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
             }
             __syncthreads();
             if (s_abort) break;                                 // uniform: every thread reads the same word after the barrier
-            if (s + 1 < a.T) load_xp(tnx, xpn);
+        }
+        // the next step's projection tile is requested only AFTER this step's has been unpacked: requested before, hipcc guards
+        // the unpack with vmcnt(0) and the wave sits out the HBM latency of the new request every step
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
-            mfma_rows<NT, KS, LDB>(w, Bt, col, hh, acc);
-        } else {
-            if (s + 1 < a.T) load_xp(tnx, xpn);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < a.T) load_xp(tnx, xp);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+            const bf16x8 *const ws1[1] = {w};
+            const bf16_t *const ts1[1] = {Bt2[s & 1]};
+            mfma_pipe<NT, KS, LDB, 1, 12>(ws1, ts1, col, hh, [&](const int, const int nt) -> f32x16 & { return acc[nt]; });
         }
         // ---- LSTM cell in registers: registers 4j..4j+3 = gates i,f,g,o of unit u0 + j for trial b0 + 32nt + col
         float hv[NT][4], gi[NT][4], gf[NT][4], gg[NT][4], go[NT][4];
@@ -241,8 +245,6 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 *reinterpret_cast<u32x4 *>(gd + 8) = u32x4{gw[4], gw[5], gw[6], gw[7]};
             }
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { xp[nt][0] = xpn[nt][0]; xp[nt][1] = xpn[nt][1]; }
     }
 }
 

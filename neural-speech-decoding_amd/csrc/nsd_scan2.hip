@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { c0[nt][j] = 0.f; c1[nt][j] = 0.f; }
     if (tid == 0) s_abort = 0;
+    for (int i = tid; i < 2 * 3 * MG * LDB / 8; i += 256) reinterpret_cast<u32x4 *>(&tiles[0][0][0])[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
 
     unsigned *gflags = a.flags + (long)me.group * GROUP_WORDS;
@@ -63,8 +64,10 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     const int T = a.T;
 
     // layer-0 input projection tiles: the one of step s+1 is requested AFTER the gather of step s has landed (vector memory
-    // returns in issue order: an HBM read issued ahead of the gather would put its latency on every step's critical path)
-    u32x4 xp[NT][2], xpn[NT][2];
+    // returns in issue order: an HBM read issued ahead of the gather would put its latency on every step's critical path) and
+    // AFTER the tile of step s has been unpacked into the accumulators -- requested before, hipcc guards the unpack with
+    // vmcnt(0) and the wave sits out the whole HBM latency every step (2 300 of 9 200 cycles)
+    u32x4 xp[NT][2];
     auto load_xp = [&](const int t, u32x4 (&dst)[NT][2]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -82,7 +85,6 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         float mult[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) drop_mult4(a.rng, masked && a.rng.on && do0, 0, a.B, T, b0 + 32 * nt + col, t0, H, u0, mult[nt]);
-        if (s == 0 && T > 1) load_xp(1, xpn);
         const bf16_t *TA = tiles[s & 1][0], *TB = tiles[s & 1][masked ? 1 : 0], *TC = tiles[s & 1][2];
         if (s >= 1) {
             if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
@@ -119,7 +121,6 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             __syncthreads();
             if (s_abort) break;
             stp.mark(1);
-            if (s + 1 < T) load_xp(s + 1, xpn);
         }
         f32x16 acc0[NT], acc1[NT];
 #pragma unroll
@@ -128,14 +129,15 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[nt][r] = bias1[r];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < T) load_xp(s + 1, xp);
+        __builtin_amdgcn_sched_barrier(0);
         if (s >= 1) {
-            if (do0) {
-                mfma_rows<NT, KS, LDB>(w0, TA, col, hh, acc0);
-            }
-            mfma_rows<NT, KS, LDB>(wx, TB, col, hh, acc1);
-            if (s >= 2) {
-                mfma_rows<NT, KS, LDB>(w1, TC, col, hh, acc1);
-            }
+            // all three products every step, branch-free: at s == 1 the h1 tile is the zero state the buffers start with, at
+            // s == T the layer-0 product feeds nothing (its cell is guarded by do0)
+            const bf16x8 *const ws3[3] = {w0, wx, w1};
+            const bf16_t *const ts3[3] = {TA, TB, TC};
+            mfma_pipe<NT, KS, LDB, 3, 12>(ws3, ts3, col, hh, [&](const int st, const int nt) -> f32x16 & { return st == 0 ? acc0[nt] : acc1[nt]; });
         }
         stp.mark(2);
         // ---- the two cells; registers 4j..4j+3 = gates i,f,g,o of unit u0 + j for trial b0 + 32nt + col
@@ -215,8 +217,6 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
                 }
             }
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { xp[nt][0] = xpn[nt][0]; xp[nt][1] = xpn[nt][1]; }
         stp.mark(5);
     }
     stp.store(a.status, blockIdx.x == 0 && tid == 0);
@@ -257,10 +257,11 @@ __device__ __forceinline__ void cell_bwd4(const u32x4 gq0, const u32x4 gq1, cons
 template <int H, int NT>
 __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
     constexpr int P = H / 32, MG = 32 * NT, G = 4 * H, KQ = G / 16 / 4;
-    constexpr int CW = (G / 4) < 128 ? (G / 4) : 128, NCH = (G / 4) / CW, LDS_ = CW + 8;
+    constexpr int NX = P * NT * 2, NB = 2 * NX, NSLOT = 8, FA = 3;   // 1-KB blocks (= MFMA k-steps) of a wave's quarter: X, then Y
+    static_assert(NB >= NSLOT, "");
     // partial tiles of the 4 waves: [buffer][wave][rec1 | din0 | rec0][tile][unit of the workgroup][trial]
     __shared__ __align__(16) float red2[2][4][3][NT][32][32];
-    __shared__ __align__(16) bf16_t stg[4][MG * LDS_];
+    __shared__ __align__(16) bf16_t dring[4][NSLOT][512];      // per wave: LDS-DMA landing ring of 1-KB blocks
     __shared__ int s_abort;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Member me = member_of(blockIdx.x, a.groups, P, a.spread_groups);
@@ -269,12 +270,15 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
 
     bf16x8 wq1[KQ], wqx[KQ], wq0[KQ];
     {
-        const long ro = (long)(32 * me.p + col) * G + wave * (G / 4) + 8 * hh;
+        // k-step ks = 2 * (gate tile) + half carries, in lane half hh, the columns 16hh + 8half + 0..7 of the gate tile: the order
+        // of the ring's 1-KB blocks (nsd_scan_common.h)
+        const long ro = (long)(32 * me.p + col) * G + wave * (G / 4) + 16 * hh;
 #pragma unroll
         for (int ks = 0; ks < KQ; ++ks) {
-            wq1[ks] = *reinterpret_cast<const bf16x8 *>(a.wb1 + ro + 16 * ks);
-            wqx[ks] = *reinterpret_cast<const bf16x8 *>(a.wxt1 + ro + 16 * ks);
-            wq0[ks] = *reinterpret_cast<const bf16x8 *>(a.wb0 + ro + 16 * ks);
+            const int co = 32 * (ks >> 1) + 8 * (ks & 1);
+            wq1[ks] = *reinterpret_cast<const bf16x8 *>(a.wb1 + ro + co);
+            wqx[ks] = *reinterpret_cast<const bf16x8 *>(a.wxt1 + ro + co);
+            wq0[ks] = *reinterpret_cast<const bf16x8 *>(a.wb0 + ro + co);
         }
     }
     float dc1[NT][4], dc0[NT][4], dbs1[16], dbs0[16];
@@ -304,7 +308,8 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dpl[nt][j] = a.dpooled[(long)(b0 + 32 * nt + col) * H + u0 + j];
-    bf16_t *strip = stg[wave];
+    bf16_t (*land)[512] = dring[wave];
+    const unsigned land_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(&dring[wave][0][0]));
     constexpr long XB = (long)MG * G;                          // elements of one da block of the exchange ring
 
     // Saved activations / upstream terms of a step (HBM reads, independent of the recurrence).  Vector memory returns in issue
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             for (int j = 0; j < 4; ++j) dup1[nt][j] = do1 ? fmaf(sv.al[nt], dpl[nt][j], sv.ds[nt] * aw[j]) : 0.f;
             drop_mult4(a.rng, a.rng.on != 0 && do0, 0, a.B, T, b0 + 32 * nt + col, t0, H, u0, m0[nt]);
         }
-        if (s == 0 && T >= 1) load_saved(1, svn);              // (step 0 has nothing staged to wait behind)
+        if (s == 0 && T >= 1) load_saved(1, svn);              // (step 0 has no exchange phase to wait behind)
         float drec1[NT][4], dinx[NT][4], drec0[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -375,50 +380,43 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             f32x16 aR1[NT], aX0[NT], aR0[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { aR1[nt] = zero16(); aX0[nt] = zero16(); aR0[nt] = zero16(); }
-            // the ring slot the group filled at step s-1: [da1_{t0} | da0_{t0+1}]
-            const bf16_t *ring = a.xch + ((long)((s - 1) & 1) * a.groups_total + a.group0 + me.group) * 2 * XB;
-            const nsd_rsrc rx = make_rsrc(ring, (unsigned)(2 * XB * 2));
-            const int gq0 = wave * P;                           // first gate tile of this wave's quarter of the columns
-            // X = da1_{t0} (this wave's quarter of its columns): recurrent term of layer 1 AND input gradient of layer 1
-            {
-                DaChunk<NT, CW> ck;
-                ck.load(rx, gq0, lane);
+            // the ring slot the group filled at step s-1: [X = da1_{t0} | Y = da0_{t0+1}].  X feeds the recurrent term of layer 1
+            // AND layer 1's input gradient (= layer 0's upstream term): the same fragment, two MFMAs; Y the recurrent term of
+            // layer 0 (zeros at s == 1: step 0 publishes them).  This wave's quarter of the columns is NX contiguous 1-KB blocks
+            // of each; they come by LDS-DMA, NSLOT in flight, the fragment read FA blocks ahead of its MFMA -- after the first
+            // block has landed the matrix pipe does not wait (register staging + ds_write cost 6 800 cycles of a 13 500-cycle
+            // step for 1 540 cycles of MFMA).
+            const bf16_t *ring = a.xch + ((long)((s - 1) & 1) * a.groups_total + a.group0 + me.group) * 2 * XB + ((long)wave * NX * 64 + lane) * 8;
+            auto src_of = [&](const int j) { return ring + (j < NX ? (long)j * 512 : XB + (long)(j - NX) * 512); };
+            auto frag_of = [&](const int j) { return *reinterpret_cast<const bf16x8 *>(&land[j % NSLOT][lane * 8]); };
 #pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    ck.to_strip(strip, lane);
-                    if (ch + 1 < NCH) ck.load(rx, gq0 + (ch + 1) * (CW / 32), lane);
-                    {   // the same B fragments feed both products: read them once, into distinct registers
-                        constexpr int NKC = CW / 16;
-                        bf16x8 bf[NT][NKC];
+            for (int j = 0; j < NSLOT; ++j) dma_block_sc1(src_of(j), land_addr + 1024u * j);
+            bf16x8 fr[FA + 1];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+            for (int j = 0; j < FA; ++j) { wait_vm(NSLOT - 1 - j); fr[j] = frag_of(j); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int k = 0; k < NKC; ++k) bf[nt][k] = *reinterpret_cast<const bf16x8 *>(strip + (32 * nt + col) * LDS_ + 16 * k + 8 * hh);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int k = 0; k < NKC; ++k)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-                                if (do1) aR1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq1[ch * NKC + k], bf[nt][k], aR1[nt], 0, 0, 0);
-                                aX0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqx[ch * NKC + k], bf[nt][k], aX0[nt], 0, 0, 0);
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < NB; ++j) {
+                if (j + FA < NB) {
+                    const int issued = (NSLOT + j) < NB ? (NSLOT + j) : NB;
+                    wait_vm(issued - 1 - (j + FA));
+                    fr[(j + FA) % (FA + 1)] = frag_of(j + FA);
+                    // the last block has landed: request the next step's saved set (HBM) -- nothing of this step waits behind it
+                    if (j + FA == NB - 1 && s + 1 <= T) load_saved(s + 1, svn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int jj = j < NX ? j : j - NX, half = jj & 1, nt = (jj >> 1) % NT, ks = 2 * (jj / (2 * NT)) + half;
+                    if (j < NX) {
+                        aR1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq1[ks], fr[j % (FA + 1)], aR1[nt], 0, 0, 0);
+                        aX0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqx[ks], fr[j % (FA + 1)], aX0[nt], 0, 0, 0);
+                    } else {
+                        aR0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq0[ks], fr[j % (FA + 1)], aR0[nt], 0, 0, 0);
                     }
                 }
-            }
-            stp.mark(1);
-            if (s < 2 && s + 1 <= T) load_saved(s + 1, svn);
-            if (s >= 2) {            // Y = da0_{t0+1}: recurrent term of layer 0
-                const nsd_rsrc ry = make_rsrc(ring + XB, (unsigned)(XB * 2));
-                DaChunk<NT, CW> ck;
-                ck.load(ry, gq0, lane);
-#pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    ck.to_strip(strip, lane);
-                    if (ch + 1 < NCH) ck.load(ry, gq0 + (ch + 1) * (CW / 32), lane);
-                    else if (s + 1 <= T) load_saved(s + 1, svn);   // the last staged chunk has landed: next step's saved set
-                    mfma_rows<NT, CW / 16, LDS_>(wq0 + ch * (CW / 16), strip, col, hh, aR0);
-                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + NSLOT < NB) dma_block_sc1(src_of(j + NSLOT), land_addr + 1024u * (j % NSLOT));
+                if (j == NX - 1) stp.mark(1);
             }
             stp.mark(2);
 #pragma unroll
@@ -464,8 +462,11 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dh[j] = fmaf(dinx[nt][j], m0[nt][j], drec0[nt][j]);
                 cell_bwd4(sv.q0[nt][0], sv.q0[nt][1], sv.cq0[nt], sv.cp0[nt], dh, dc0[nt], dbs0, dw0[nt]);
-                ring_put_da(same_l2, slot + XB, gtw, nt, NT, col, hh, dw0[nt]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dw0[nt][j] = 0u;    // step 0: the Y block step 1 reads is da0_{T} = 0
             }
+            ring_put_da(same_l2, slot + XB, gtw, nt, NT, col, hh, dw0[nt]);
         }
         stp.mark(6);
         if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -508,10 +509,10 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
 
 }  // namespace
 
-// LDS of the forward kernel: 2 x 3 tiles of MG x (H + 8) bf16; of the backward kernel: 96 KB x NT of partials + the strips
+// LDS of the forward kernel: 2 x 3 tiles of MG x (H + 8) bf16; of the backward kernel: 96 KB x NT of partials + 32 KB of DMA landing rings
 bool nsd_scan2_supported(int H, int MG) {
     if (!(H == 64 || H == 128 || H == 256)) return false;
-    const long fwd = 2L * 3 * MG * (H + 8) * 2, bwd = 2L * 4 * 3 * (MG / 32) * 4096 + 4L * MG * 136 * 2;
+    const long fwd = 2L * 3 * MG * (H + 8) * 2, bwd = 2L * 4 * 3 * (MG / 32) * 4096 + 4L * 8 * 1024;
     return fwd <= 150 * 1024 && bwd <= 150 * 1024;
 }
 
