@@ -91,7 +91,8 @@ struct GemmArgs {
     const bf16_t *A, *B;
     long lda, ldb;
     int a_kmajor, b_kmajor;
-    long b_shift;            // K-row shift of operand B (k-major B only)
+    long b_shift;            // K-row shift of operand B (k-major B only): row k of A meets row k + b_shift of B; rows shifted out read zero
+    long b_period;           // 0: ... out of [0, K); > 0: ... out of row k's own block of b_period rows (tile-major sequences: one batch tile)
     void *C;
     long ldc;
     const float *bias;       // [M] (GEMM_EPI_TILE_BF16) or null

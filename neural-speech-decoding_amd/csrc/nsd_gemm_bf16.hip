@@ -44,13 +44,17 @@ __device__ __forceinline__ void store_rowmajor(bf16_t *S, const Pieces &p, const
 }
 // k-major operand P[K][ld]: chunk rows k0.. (shifted by `shift`, rows outside [0, K) are zero), columns c0..
 __device__ __forceinline__ Pieces load_kmajor(const bf16_t *P, const long ld, const int c0, const int ncols, const long k0, const long k_hi,
-                                              const long shift, const long K, const int tid) {
+                                              const long shift, const long period, const long K, const int tid) {
     Pieces p;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = tid + 256 * i, kr = e >> 4, cc = e & 15;
         const long k = k0 + kr, ks = k + shift;
-        const bool ok = k < k_hi && ks >= 0 && ks < K && c0 + 8 * cc < ncols;
+        bool ok = k < k_hi && ks >= 0 && ks < K && c0 + 8 * cc < ncols;
+        if (period > 0 && shift != 0) {                         // (K < 2^31 on this path: checked at launch)
+            const long kin = (long)((unsigned)k % (unsigned)period) + shift;
+            ok = ok && kin >= 0 && kin < period;
+        }
         p.v[i] = ok ? *reinterpret_cast<const u32x4 *>(P + ks * ld + c0 + 8 * cc) : u32x4{0u, 0u, 0u, 0u};
     }
     return p;
@@ -91,8 +95,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
 
-    auto lda_ = [&](long k0) { return AK ? load_kmajor(g.A, g.lda, m0, g.M, k0, k_hi, 0, g.K, tid) : load_rowmajor(g.A, g.lda, m0, g.M, k0, k_hi, tid); };
-    auto ldb_ = [&](long k0) { return BK ? load_kmajor(g.B, g.ldb, n0, g.N, k0, k_hi, g.b_shift, g.K, tid) : load_rowmajor(g.B, g.ldb, n0, g.N, k0, k_hi, tid); };
+    auto lda_ = [&](long k0) { return AK ? load_kmajor(g.A, g.lda, m0, g.M, k0, k_hi, 0, 0, g.K, tid) : load_rowmajor(g.A, g.lda, m0, g.M, k0, k_hi, tid); };
+    auto ldb_ = [&](long k0) { return BK ? load_kmajor(g.B, g.ldb, n0, g.N, k0, k_hi, g.b_shift, g.b_period, g.K, tid) : load_rowmajor(g.B, g.ldb, n0, g.N, k0, k_hi, tid); };
     if (k_lo < k_hi) {
         Pieces pa = lda_(k_lo), pb = ldb_(k_lo);
         for (long k0 = k_lo; k0 < k_hi; k0 += GK) {
@@ -177,6 +181,7 @@ int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
     if (g.epi == GEMM_EPI_TILE_BF16 && (g.M % 32 || g.N % 32)) { nsd_set_error("gemm_bf16: tile output needs M, N multiples of 32"); return NSD_E_INVALID; }
     const int splits = (g.epi == GEMM_EPI_F32 && g.splits > 1) ? g.splits : 1;
     if (g.b_shift != 0 && !g.b_kmajor) { nsd_set_error("gemm_bf16: b_shift needs a k-major B"); return NSD_E_INVALID; }
+    if (g.b_period < 0 || (g.b_period > 0 && (g.K >= (1L << 31) || g.b_shift >= g.b_period || -g.b_shift >= g.b_period))) { nsd_set_error("gemm_bf16: bad b_period"); return NSD_E_INVALID; }
     if (g.add && (g.epi != GEMM_EPI_F32 || splits != 1)) { nsd_set_error("gemm_bf16: addend needs the fp32 epilogue without split-K"); return NSD_E_INVALID; }
     GemmArgs a = g;
     a.splits = splits;

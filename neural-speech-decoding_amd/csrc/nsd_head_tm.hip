@@ -43,12 +43,12 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
     const int b = blockIdx.x * 4 + wave;
     if (b >= a.B) return;                                       // whole waves leave; nothing below needs the workgroup
     const int c0 = lane * VPL, T = a.T, F = a.F, K = a.K;
-    const long Bp = a.Bp;
     float aw[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) aw[v] = a.attn_w[c0 + v];
     const float ab = a.attn_b[0];
-    const bf16_t *seq = a.top + (long)b * DH + c0;              // row t at seq + t * Bp * DH
+    const long arow = seq_row(0, b, T);                          // tile-major rows: step t of the trial is row arow + 32 t
+    const bf16_t *seq = a.top + arow * DH + c0;
 
     // ---- pass 1: online softmax over time ------------------------------------------------------------------------------
     float m = -3.0e38f, l = 0.f, acc[VPL];
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
             const int t = t0 + q < T ? t0 + q : T - 1;
-            load_bf16_vals<VPL>(seq + (long)t * Bp * DH, hv[q]);
+            load_bf16_vals<VPL>(seq + (long)t * 32 * DH, hv[q]);
         }
 #pragma unroll
         for (int q = 0; q < U; ++q) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
 #pragma unroll
             for (int v = 0; v < VPL; ++v) part = fmaf(hv[q][v], aw[v], part);
             const float s = wave_sum(part) + ab;
-            if (TRAIN && lane == 0) a.alpha[(long)(t0 + q) * Bp + b] = s;          // raw score; normalised below
+            if (TRAIN && lane == 0) a.alpha[arow + 32L * (t0 + q)] = s;          // raw score; normalised below
             const float mn = fmaxf(m, s);
             const float sc = __expf(m - mn), e = __expf(s - mn);
             l = fmaf(l, sc, e);
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
             const int t = t0 + q < T ? t0 + q : T - 1;
-            load_bf16_vals<VPL>(seq + (long)t * Bp * DH, hv[q]);
-            sraw[q] = a.alpha[(long)t * Bp + b];                 // written by this wave's lane 0 in pass 1
+            load_bf16_vals<VPL>(seq + (long)t * 32 * DH, hv[q]);
+            sraw[q] = a.alpha[arow + 32L * t];                 // written by this wave's lane 0 in pass 1
         }
 #pragma unroll
         for (int q = 0; q < U; ++q) {
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
             const float al = __expf(sraw[q] - m) * inv_l;
             const float ds = al * (qd - dp_pooled);
             if (lane == 0) {
-                a.alpha[(long)(t0 + q) * Bp + b] = al;
-                a.dscore[(long)(t0 + q) * Bp + b] = ds;
+                a.alpha[arow + 32L * (t0 + q)] = al;
+                a.dscore[arow + 32L * (t0 + q)] = ds;
             }
             dsum += ds;
 #pragma unroll

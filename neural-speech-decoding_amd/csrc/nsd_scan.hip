@@ -80,13 +80,13 @@ __global__ __launch_bounds__(256) void seq_prep_kernel(const PrepArgs a) {
     }
 }
 
-// x [B][T][C] fp32 -> xbf [T][Bp][CP] bf16, zero padded
+// x [B][T][C] fp32 -> xbf [seq_row(t, b)][CP] bf16, zero padded
 __global__ __launch_bounds__(256) void seq_xbf_kernel(const float *x, bf16_t *xbf, int B, int Bp, int T, int C, int CP) {
     const long total = (long)T * Bp * CP;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int c = (int)(e % CP);
         const long r = e / CP;
-        const int b = (int)(r % Bp), t = (int)(r / Bp);
+        const int b = (int)(r / ((long)T * 32)) * 32 + (int)(r & 31), t = (int)((r >> 5) % T);
         xbf[e] = (b < B && c < C) ? (bf16_t)x[((long)b * T + t) * C + c] : (bf16_t)0.f;
     }
 }
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
     if (tid == 0 && me.p == 0) atomicAdd(a.status + (rv == 1 ? 2 : 3), 1);     // diagnostics: groups on one XCD / spread over several
-    const long ld = a.ld, Bp = a.Bp;
+    const long ld = a.ld, tstride = (long)a.T * 32;            // rows between the 32-trial halves of a 64-trial tile (tile-major rows)
+    auto trow = [&](const int row) { return (row >> 5) * tstride + (row & 31); };
     const int u0 = 8 * gt + 4 * hh;                            // first of this lane's 4 units
     const bool train = a.cs[0] != nullptr;
 
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     auto load_xp = [&](const int t, u32x4 (&dst)[NT][2]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const bf16_t *src = a.xproj[dir] + ((((long)t * (Bp >> 5) + (b0 >> 5) + nt) * (G >> 5) + gt) * 64 + lane) * 16;
+            const bf16_t *src = a.xproj[dir] + ((((long)((b0 >> 5) + nt) * a.T + t) * (G >> 5) + gt) * 64 + lane) * 16;
             dst[nt][0] = *reinterpret_cast<const u32x4 *>(src);
             dst[nt][1] = *reinterpret_cast<const u32x4 *>(src + 8);
         }
@@ -158,13 +159,13 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 atomicExch(a.status, ST_FWD_TIMEOUT);
             }
             // gather h_{t-1} of the whole tile (all H units): sc1 loads, 16 bytes each
-            const nsd_rsrc rh = make_rsrc(a.hs + ((long)tp * Bp + b0) * ld + dir * H, (unsigned)((long)MG * ld * 2));
+            const nsd_rsrc rh = make_rsrc(a.hs + seq_row(tp, b0, a.T) * ld + dir * H, (unsigned)(((NT - 1) * tstride + 32) * ld * 2));
             constexpr int PIECES = MG * (H / 8) / 256;
             u32x4 pv[PIECES];
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
                 const int e = tid + 256 * i, row = e / (H / 8), pc = e % (H / 8);
-                pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u} : ld_sc1_b128(rh, (unsigned)((row * ld + 8 * pc) * 2));
+                pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u} : ld_sc1_b128(rh, (unsigned)((trow(row) * ld + 8 * pc) * 2));
             }
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             hw[nt][0] = pack_bf16x2(hv[nt][0], hv[nt][1]);
             hw[nt][1] = pack_bf16x2(hv[nt][2], hv[nt][3]);
-            const long row = (long)t * Bp + b0 + 32 * nt + col;
+            const long row = seq_row(t, b0 + 32 * nt + col, a.T);
             st_xchg_u64(same_l2, a.hs + row * ld + dir * H + u0, ((unsigned long long)hw[nt][1] << 32) | hw[nt][0]);
         }
         if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int b = b0 + 32 * nt + col;
-            const long row = (long)t * Bp + b;
+            const long row = seq_row(t, b, a.T);
             if (a.lk) {
                 float m[4] = {1.f, 1.f, 1.f, 1.f};
                 if (a.rng.on && b < a.B) {
@@ -233,16 +234,17 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
             }
             if (train) {
                 u32x2 cv = {pack_bf16x2(c[nt][0], c[nt][1]), pack_bf16x2(c[nt][2], c[nt][3])};
-                *reinterpret_cast<u32x2 *>(a.cs[dir] + row * H + u0) = cv;
+                const long blk = saved_block((b0 >> 5) + nt, P, me.p, a.T, t, wave);
+                *reinterpret_cast<u32x2 *>(a.cs[dir] + saved_cs(blk, lane)) = cv;
                 unsigned gw[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     gw[2 * j] = pack_bf16x2(gi[nt][j], gf[nt][j]);
                     gw[2 * j + 1] = pack_bf16x2(gg[nt][j], go[nt][j]);
                 }
-                bf16_t *gd = a.ga[dir] + row * G + 4 * u0;
+                bf16_t *gd = a.ga[dir] + saved_ga(blk, 0, lane);
                 *reinterpret_cast<u32x4 *>(gd) = u32x4{gw[0], gw[1], gw[2], gw[3]};
-                *reinterpret_cast<u32x4 *>(gd + 8) = u32x4{gw[4], gw[5], gw[6], gw[7]};
+                *reinterpret_cast<u32x4 *>(gd + 512) = u32x4{gw[4], gw[5], gw[6], gw[7]};
             }
         }
     }
@@ -288,7 +290,8 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
     if (tid == 0 && me.p == 0) atomicAdd(a.status + (rv == 1 ? 2 : 3), 1);
-    const long ld = a.ld, Bp = a.Bp, ldda = (long)a.D * G;
+    const long ld = a.ld, ldda = (long)a.D * G, tstride = (long)a.T * 32;
+    auto trow = [&](const int row) { return (row >> 5) * tstride + (row & 31); };
     float dbs[16];                                             // bias gradient of this lane's 16 gate columns, summed over time and tiles
 #pragma unroll
     for (int k = 0; k < 16; ++k) dbs[k] = 0.f;
@@ -313,13 +316,14 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int b = b0 + 32 * nt + col;
-            const long row = (long)t * Bp + b;
-            const bf16_t *gs = a.ga[dir] + row * G + 4 * u0;
+            const long row = seq_row(t, b, a.T);
+            const long blk = saved_block((b0 >> 5) + nt, P, me.p, a.T, t, wave);
+            const bf16_t *gs = a.ga[dir] + saved_ga(blk, 0, lane);
             gq[nt][0] = *reinterpret_cast<const u32x4 *>(gs);
-            gq[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 8);
-            cq[nt] = *reinterpret_cast<const u32x2 *>(a.cs[dir] + row * H + u0);
+            gq[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 512);
+            cq[nt] = *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk, lane));
             const bool first = dir == 0 ? t == 0 : t == a.T - 1;
-            cpq[nt] = first ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs[dir] + ((long)tprev * Bp + b) * H + u0);
+            cpq[nt] = first ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk + 4 * (tprev - t), lane));
             if (a.din) {
                 const f32x4 dv = *reinterpret_cast<const f32x4 *>(a.din + row * ld + dir * H + u0);
                 float m[4] = {1.f, 1.f, 1.f, 1.f};
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             f32x16 acc[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
-            const nsd_rsrc rd = make_rsrc(a.da + ((long)tn * Bp + b0) * ldda + dir * G + wave * (G / 4), (unsigned)((long)MG * ldda * 2));
+            const nsd_rsrc rd = make_rsrc(a.da + seq_row(tn, b0, a.T) * ldda + dir * G + wave * (G / 4), (unsigned)(((NT - 1) * tstride + 32) * ldda * 2));
             bf16_t *strip = stg[wave];
             constexpr int LPI = CW / 8;                          // lanes per row of a chunk (16-byte pieces)
             constexpr int RPI = 64 / LPI;                        // rows per load instruction
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i)
                 pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}
-                                              : ld_sc1_b128(rd, (unsigned)(((lrow + RPI * i) * ldda + 8 * lpc) * 2));
+                                              : ld_sc1_b128(rd, (unsigned)((trow(lrow + RPI * i) * ldda + 8 * lpc) * 2));
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
                     for (int i = 0; i < NLD; ++i)
                         pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}
-                                                      : ld_sc1_b128(rd, (unsigned)(((lrow + RPI * i) * ldda + CW * (ch + 1) + 8 * lpc) * 2));
+                                                      : ld_sc1_b128(rd, (unsigned)((trow(lrow + RPI * i) * ldda + CW * (ch + 1) + 8 * lpc) * 2));
                 }
                 mfma_rows<NT, CW / 16, LDS_>(w + ch * (CW / 16), strip, col, hh, acc);
                 // (the compiler orders the next chunk's ds_write behind these ds_reads: same wave, same LDS object)
@@ -416,8 +420,8 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                 dbs[4 * j] += dai; dbs[4 * j + 1] += daf; dbs[4 * j + 2] += dag; dbs[4 * j + 3] += dao;
             }
             // (descriptor base wave-uniform, the lane's position in the offset)
-            const nsd_rsrc rs = make_rsrc(a.da + ((long)t * Bp + b0) * ldda + dir * G, (unsigned)((long)MG * ldda * 2));
-            const unsigned off = (unsigned)(((32 * nt + col) * ldda + 4 * u0) * 2);
+            const nsd_rsrc rs = make_rsrc(a.da + seq_row(t, b0, a.T) * ldda + dir * G, (unsigned)(((NT - 1) * tstride + 32) * ldda * 2));
+            const unsigned off = (unsigned)((trow(32 * nt + col) * ldda + 4 * u0) * 2);
             if (same_l2) {
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[0], dw[1], dw[2], dw[3]}, rs, (int)off, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[4], dw[5], dw[6], dw[7]}, rs, (int)off + 16, 0, 0);

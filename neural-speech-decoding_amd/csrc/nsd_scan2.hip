@@ -58,7 +58,6 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
     if (tid == 0 && me.p == 0) atomicAdd(a.status + (rv == 1 ? 2 : 3), 1);
-    const long Bp = a.Bp;
     const int u0 = 8 * gt + 4 * hh;
     const bool train = a.cs0 != nullptr, masked = a.lk0 != nullptr;
     const int T = a.T;
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     auto load_xp = [&](const int t, u32x4 (&dst)[NT][2]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const bf16_t *src = a.xproj0 + ((((long)t * (Bp >> 5) + (b0 >> 5) + nt) * (G >> 5) + gt) * 64 + lane) * 16;
+            const bf16_t *src = a.xproj0 + ((((long)((b0 >> 5) + nt) * T + t) * (G >> 5) + gt) * 64 + lane) * 16;
             dst[nt][0] = *reinterpret_cast<const u32x4 *>(src);
             dst[nt][1] = *reinterpret_cast<const u32x4 *>(src + 8);
         }
@@ -187,32 +186,31 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int b = b0 + 32 * nt + col;
             if (do0 && train) {
-                const long row = (long)t0 * Bp + b;
+                const long row = seq_row(t0, b, T);
                 *reinterpret_cast<u32x2 *>(a.hs0 + row * H + u0) = u32x2{hw0[nt][0], hw0[nt][1]};
                 if (masked) *reinterpret_cast<u32x2 *>(a.lk0 + row * H + u0) = u32x2{lw0[nt][0], lw0[nt][1]};
             }
-            if (do1) *reinterpret_cast<u32x2 *>(a.hs1 + ((long)t1 * Bp + b) * H + u0) = u32x2{hw1[nt][0], hw1[nt][1]};
+            if (do1) *reinterpret_cast<u32x2 *>(a.hs1 + seq_row(t1, b, T) * H + u0) = u32x2{hw1[nt][0], hw1[nt][1]};
         }
         if (train) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int b = b0 + 32 * nt + col;
                 if (do0) {
-                    const long row = (long)t0 * Bp + b;
-                    *reinterpret_cast<u32x2 *>(a.cs0 + row * H + u0) = u32x2{pack_bf16x2(c0[nt][0], c0[nt][1]), pack_bf16x2(c0[nt][2], c0[nt][3])};
-                    bf16_t *gd = a.ga0 + row * G + 4 * u0;
+                    const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t0, wave);
+                    *reinterpret_cast<u32x2 *>(a.cs0 + saved_cs(blk, lane)) = u32x2{pack_bf16x2(c0[nt][0], c0[nt][1]), pack_bf16x2(c0[nt][2], c0[nt][3])};
+                    bf16_t *gd = a.ga0 + saved_ga(blk, 0, lane);
                     *reinterpret_cast<u32x4 *>(gd) = u32x4{pack_bf16x2(g0[nt][0][0], g0[nt][0][1]), pack_bf16x2(g0[nt][0][2], g0[nt][0][3]),
                                                            pack_bf16x2(g0[nt][1][0], g0[nt][1][1]), pack_bf16x2(g0[nt][1][2], g0[nt][1][3])};
-                    *reinterpret_cast<u32x4 *>(gd + 8) = u32x4{pack_bf16x2(g0[nt][2][0], g0[nt][2][1]), pack_bf16x2(g0[nt][2][2], g0[nt][2][3]),
+                    *reinterpret_cast<u32x4 *>(gd + 512) = u32x4{pack_bf16x2(g0[nt][2][0], g0[nt][2][1]), pack_bf16x2(g0[nt][2][2], g0[nt][2][3]),
                                                                pack_bf16x2(g0[nt][3][0], g0[nt][3][1]), pack_bf16x2(g0[nt][3][2], g0[nt][3][3])};
                 }
                 if (do1) {
-                    const long row = (long)t1 * Bp + b;
-                    *reinterpret_cast<u32x2 *>(a.cs1 + row * H + u0) = u32x2{pack_bf16x2(c1[nt][0], c1[nt][1]), pack_bf16x2(c1[nt][2], c1[nt][3])};
-                    bf16_t *gd = a.ga1 + row * G + 4 * u0;
+                    const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t1, wave);
+                    *reinterpret_cast<u32x2 *>(a.cs1 + saved_cs(blk, lane)) = u32x2{pack_bf16x2(c1[nt][0], c1[nt][1]), pack_bf16x2(c1[nt][2], c1[nt][3])};
+                    bf16_t *gd = a.ga1 + saved_ga(blk, 0, lane);
                     *reinterpret_cast<u32x4 *>(gd) = u32x4{pack_bf16x2(g1[nt][0][0], g1[nt][0][1]), pack_bf16x2(g1[nt][0][2], g1[nt][0][3]),
                                                            pack_bf16x2(g1[nt][1][0], g1[nt][1][1]), pack_bf16x2(g1[nt][1][2], g1[nt][1][3])};
-                    *reinterpret_cast<u32x4 *>(gd + 8) = u32x4{pack_bf16x2(g1[nt][2][0], g1[nt][2][1]), pack_bf16x2(g1[nt][2][2], g1[nt][2][3]),
+                    *reinterpret_cast<u32x4 *>(gd + 512) = u32x4{pack_bf16x2(g1[nt][2][0], g1[nt][2][1]), pack_bf16x2(g1[nt][2][2], g1[nt][2][3]),
                                                                pack_bf16x2(g1[nt][3][0], g1[nt][3][1]), pack_bf16x2(g1[nt][3][2], g1[nt][3][3])};
                 }
             }
@@ -232,9 +230,44 @@ __device__ __forceinline__ void st_xchg_b128x2(const bool same_l2, const nsd_rsr
     }
 }
 
-// one layer's cell backward for a lane's 4 units of one trial; returns da (16 values, unit-major) packed + accumulates dbs
-__device__ __forceinline__ void cell_bwd4(const u32x4 gq0, const u32x4 gq1, const u32x2 cq, const u32x2 cpq, const float (&dh)[4], float (&dc)[4],
-                                          float (&dbs)[16], unsigned (&dw)[8]) {
+// ---- backward -------------------------------------------------------------------------------------------------------------
+// The recurrent terms are exchanged as a REDUCE-SCATTER of partial sums, not as an all-gather of da.  A workgroup owns the gate
+// columns of its 32 units (128 columns of da1 and of da0) and holds the rows of W_hh1^T, W_ih1^T, W_hh0^T for those columns and
+// ALL H units.  Per step it multiplies its own fresh da (K = 128, straight from LDS) into partial sums of dh for every unit
+// and sends each member of the group the 32 rows that member owns, as bf16; a member adds the P partials of its rows in fp32,
+// in member order.  Against the all-gather (every member reading the whole 2 x MG x 4H da tile: 128 KB per step at H = 256,
+// 64 B/clk from the L2 -> 2 000+ cycles, then a K-split reduction through 96 KB of LDS and a second barrier) a member now
+// reads 48 KB, the K reduction ends inside one wave, and nothing of the cell waits for LDS.  Rounding the partial sums to bf16
+// costs about what rounding da to bf16 already costs (both ~2^-9 relative on terms of the same sum); parity tests unchanged.
+//
+// ring slot of a group (step parity):  R16 [consumer member][producer member][nt][consumer wave 4][lane 64] x 16 B =
+//   {rec1 = W_hh1^T da1 (4 bf16) | din0 = W_ih1^T da1 (4 bf16)} of the lane's 4 units, R8 the same index x 8 B = rec0 = W_hh0^T da0.
+//   A producer wave's accumulator registers 4q..4q+3 of lane (trial, hh) ARE consumer wave q's lane (trial, hh) units, so
+//   every store / load instruction moves one contiguous 1-KB / 512-B block (whole lines, one producer each).
+template <int P, int NT>
+struct PartRing {
+    static constexpr long NBLK = (long)P * P * NT * 4, SLOT_BYTES = NBLK * (1024 + 512);
+    __device__ static __forceinline__ unsigned off16(const int cons, const int prod, const int nt, const int q) {
+        return (unsigned)(((((cons * P + prod) * NT + nt) * 4 + q)) << 10);
+    }
+    __device__ static __forceinline__ unsigned off8(const int cons, const int prod, const int nt, const int q) {
+        return (unsigned)(NBLK << 10) + (unsigned)(((((cons * P + prod) * NT + nt) * 4 + q)) << 9);
+    }
+};
+
+__device__ __forceinline__ u32x2 ld_sc1_b64(const nsd_rsrc r, const unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ void st_ring_b128(const bool same_l2, const nsd_rsrc rs, const unsigned off, const u32x4 v) {
+    if (same_l2) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, 0); else st_sc1_b128(rs, off, v);
+}
+__device__ __forceinline__ void st_ring_b64(const bool same_l2, const nsd_rsrc rs, const unsigned off, const u32x2 v) {
+    if (same_l2) __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, 0, 0); else st_sc1_b64(rs, off, v);
+}
+
+// What of a cell's backward does not depend on dh: computed from the saved activations BEFORE the wave polls for its partials
+struct CellFac { float A[4], Fi[4], Ff[4], Fg[4], Fo[4], fg[4]; };
+__device__ __forceinline__ void cell_factors(const u32x4 gq0, const u32x4 gq1, const u32x2 cq, const u32x2 cpq, CellFac &f) {
     const float cv[4] = {bf16_lo(cq[0]), bf16_hi(cq[0]), bf16_lo(cq[1]), bf16_hi(cq[1])};
     const float cp[4] = {bf16_lo(cpq[0]), bf16_hi(cpq[0]), bf16_lo(cpq[1]), bf16_hi(cpq[1])};
 #pragma unroll
@@ -242,12 +275,21 @@ __device__ __forceinline__ void cell_bwd4(const u32x4 gq0, const u32x4 gq1, cons
         const unsigned w0 = j < 2 ? gq0[2 * (j & 1)] : gq1[2 * (j & 1)], w1 = j < 2 ? gq0[2 * (j & 1) + 1] : gq1[2 * (j & 1) + 1];
         const float ig = bf16_lo(w0), fg = bf16_hi(w0), gg = bf16_lo(w1), og = bf16_hi(w1);
         const float tc = fast_tanh(cv[j]);
-        const float dct = fmaf(dh[j] * og, 1.f - tc * tc, dc[j]);
-        dc[j] = dct * fg;
-        const float dai = dct * gg * ig * (1.f - ig);
-        const float daf = dct * cp[j] * fg * (1.f - fg);
-        const float dag = dct * ig * (1.f - gg * gg);
-        const float dao = dh[j] * tc * og * (1.f - og);
+        f.A[j] = og * (1.f - tc * tc);                 // d c_t / d h_t (through tanh(c_t))
+        f.Fi[j] = gg * ig * (1.f - ig);
+        f.Ff[j] = cp[j] * fg * (1.f - fg);
+        f.Fg[j] = ig * (1.f - gg * gg);
+        f.Fo[j] = tc * og * (1.f - og);
+        f.fg[j] = fg;
+    }
+}
+// ... and what does: da (16 values, unit-major, packed), the carried dc, the bias-gradient sums
+__device__ __forceinline__ void cell_apply(const CellFac &f, const float (&dh)[4], float (&dc)[4], float (&dbs)[16], unsigned (&dw)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dct = fmaf(dh[j], f.A[j], dc[j]);
+        dc[j] = dct * f.fg[j];
+        const float dai = dct * f.Fi[j], daf = dct * f.Ff[j], dag = dct * f.Fg[j], dao = dh[j] * f.Fo[j];
         dw[2 * j] = pack_bf16x2(dai, daf);
         dw[2 * j + 1] = pack_bf16x2(dag, dao);
         dbs[4 * j] += dai; dbs[4 * j + 1] += daf; dbs[4 * j + 2] += dag; dbs[4 * j + 3] += dao;
@@ -256,29 +298,30 @@ __device__ __forceinline__ void cell_bwd4(const u32x4 gq0, const u32x4 gq1, cons
 
 template <int H, int NT>
 __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
-    constexpr int P = H / 32, MG = 32 * NT, G = 4 * H, KQ = G / 16 / 4;
-    constexpr int NX = P * NT * 2, NB = 2 * NX, NSLOT = 8, FA = 3;   // 1-KB blocks (= MFMA k-steps) of a wave's quarter: X, then Y
-    static_assert(NB >= NSLOT, "");
-    // partial tiles of the 4 waves: [buffer][wave][rec1 | din0 | rec0][tile][unit of the workgroup][trial]
-    __shared__ __align__(16) float red2[2][4][3][NT][32][32];
-    __shared__ __align__(16) bf16_t dring[4][NSLOT][512];      // per wave: LDS-DMA landing ring of 1-KB blocks
+    constexpr int P = H / 32, MG = 32 * NT, G = 4 * H, RT = P >= 4 ? P / 4 : 1, KS = 8;
+    using Ring = PartRing<P, NT>;
+    // the workgroup's own da of the step, as MFMA B operands: k-step 2*wave + half = the 1-KB lane-linear block producer wave
+    // `wave` writes with one ds_write_b128 (lane (trial, hh): columns 16hh + 8half + 0..7 of the wave's 32)
+    __shared__ __align__(16) bf16_t dab[2][2][KS][NT][512];      // [step parity][layer][k-step][nt][lane * 8]
     __shared__ int s_abort;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Member me = member_of(blockIdx.x, a.groups, P, a.spread_groups);
     const int b0 = (a.group0 + me.group) * MG;
     const int col = lane & 31, hh = lane >> 5;
+    const bool has_rows = wave < P;                              // (P < 4: only the first P waves own a consumer's row tile)
 
-    bf16x8 wq1[KQ], wqx[KQ], wq0[KQ];
-    {
-        // k-step ks = 2 * (gate tile) + half carries, in lane half hh, the columns 16hh + 8half + 0..7 of the gate tile: the order
-        // of the ring's 1-KB blocks (nsd_scan_common.h)
-        const long ro = (long)(32 * me.p + col) * G + wave * (G / 4) + 16 * hh;
+    // rows of W^T for the consumers r = wave + 4 ri (their 32 units), columns = this workgroup's 128 gate columns in k-step order
+    bf16x8 wq1[RT][KS], wqx[RT][KS], wq0[RT][KS];
 #pragma unroll
-        for (int ks = 0; ks < KQ; ++ks) {
+    for (int ri = 0; ri < RT; ++ri) {
+        const int r = (wave + 4 * ri) < P ? wave + 4 * ri : 0;
+        const long ro = (long)(32 * r + col) * G + 128 * me.p + 16 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
             const int co = 32 * (ks >> 1) + 8 * (ks & 1);
-            wq1[ks] = *reinterpret_cast<const bf16x8 *>(a.wb1 + ro + co);
-            wqx[ks] = *reinterpret_cast<const bf16x8 *>(a.wxt1 + ro + co);
-            wq0[ks] = *reinterpret_cast<const bf16x8 *>(a.wb0 + ro + co);
+            wq1[ri][ks] = *reinterpret_cast<const bf16x8 *>(a.wb1 + ro + co);
+            wqx[ri][ks] = *reinterpret_cast<const bf16x8 *>(a.wxt1 + ro + co);
+            wq0[ri][ks] = *reinterpret_cast<const bf16x8 *>(a.wb0 + ro + co);
         }
     }
     float dc1[NT][4], dc0[NT][4], dbs1[16], dbs0[16];
@@ -298,7 +341,6 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
     if (tid == 0 && me.p == 0) atomicAdd(a.status + (rv == 1 ? 2 : 3), 1);
-    const long Bp = a.Bp;
     const int T = a.T;
     const int u0 = 32 * me.p + 8 * wave + 4 * hh;
     float dpl[NT][4], aw[4];
@@ -308,15 +350,12 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dpl[nt][j] = a.dpooled[(long)(b0 + 32 * nt + col) * H + u0 + j];
-    bf16_t (*land)[512] = dring[wave];
-    const unsigned land_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(&dring[wave][0][0]));
-    constexpr long XB = (long)MG * G;                          // elements of one da block of the exchange ring
+    const char *ring0 = reinterpret_cast<const char *>(a.xch) + (long)(a.group0 + me.group) * Ring::SLOT_BYTES;
+    const long slot_stride = (long)a.groups_total * Ring::SLOT_BYTES;
 
     // Saved activations / upstream terms of a step (HBM reads, independent of the recurrence).  Vector memory returns in issue
-    // order, so an HBM read issued just before the flag poll or before the publishing drain puts its whole latency on the
-    // step (6 400 of 16 500 cycles when these loads sat at the top of the step).  The set of step s+1 is therefore requested in
-    // the middle of step s, right after the last staged tile has landed: ~5 000 cycles of MFMA, reduction and cell work follow
-    // before the wave waits on memory again.
+    // order: an HBM read issued just before the flag poll or before the publishing drain puts its whole latency on the step.
+    // The set of step s+1 is requested right after the barrier of step s: the MFMA phase (~1 800 cycles) follows.
     struct Saved {
         u32x4 q1[NT][2], q0[NT][2];
         u32x2 cq1[NT], cp1[NT], cq0[NT], cp0[NT];
@@ -329,164 +368,184 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int b = b0 + 32 * nt + col;
             if (d1) {
-                const long row = (long)x1 * Bp + b;
-                const bf16_t *gs = a.ga1 + row * G + 4 * u0;
-                v.q1[nt][0] = *reinterpret_cast<const u32x4 *>(gs); v.q1[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 8);
-                v.cq1[nt] = *reinterpret_cast<const u32x2 *>(a.cs1 + row * H + u0);
-                v.cp1[nt] = x1 == 0 ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs1 + ((long)(x1 - 1) * Bp + b) * H + u0);
+                const long row = seq_row(x1, b, T);
+                const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x1, wave);
+                const bf16_t *gs = a.ga1 + saved_ga(blk, 0, lane);
+                v.q1[nt][0] = *reinterpret_cast<const u32x4 *>(gs); v.q1[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 512);
+                v.cq1[nt] = *reinterpret_cast<const u32x2 *>(a.cs1 + saved_cs(blk, lane));
+                v.cp1[nt] = x1 == 0 ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs1 + saved_cs(blk - 4, lane));   // (step x1 - 1: 4 blocks back)
                 v.al[nt] = a.alpha[row]; v.ds[nt] = a.dscore[row];
             } else {
                 v.q1[nt][0] = u32x4{0u, 0u, 0u, 0u}; v.q1[nt][1] = u32x4{0u, 0u, 0u, 0u}; v.cq1[nt] = u32x2{0u, 0u}; v.cp1[nt] = u32x2{0u, 0u};
                 v.al[nt] = 0.f; v.ds[nt] = 0.f;
             }
             if (d0) {
-                const long row = (long)x0 * Bp + b;
-                const bf16_t *gs = a.ga0 + row * G + 4 * u0;
-                v.q0[nt][0] = *reinterpret_cast<const u32x4 *>(gs); v.q0[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 8);
-                v.cq0[nt] = *reinterpret_cast<const u32x2 *>(a.cs0 + row * H + u0);
-                v.cp0[nt] = x0 == 0 ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs0 + ((long)(x0 - 1) * Bp + b) * H + u0);
+                const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x0, wave);
+                const bf16_t *gs = a.ga0 + saved_ga(blk, 0, lane);
+                v.q0[nt][0] = *reinterpret_cast<const u32x4 *>(gs); v.q0[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 512);
+                v.cq0[nt] = *reinterpret_cast<const u32x2 *>(a.cs0 + saved_cs(blk, lane));
+                v.cp0[nt] = x0 == 0 ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs0 + saved_cs(blk - 4, lane));
             } else {
                 v.q0[nt][0] = u32x4{0u, 0u, 0u, 0u}; v.q0[nt][1] = u32x4{0u, 0u, 0u, 0u}; v.cq0[nt] = u32x2{0u, 0u}; v.cp0[nt] = u32x2{0u, 0u};
             }
         }
     };
-    Saved sv, svn;
+    Saved sv;
     load_saved(0, sv);
     Stamps stp;
     stp.start();
     for (int s = 0; s <= T; ++s) {
         const bool do1 = s < T, do0 = s >= 1;
         const int t1 = T - 1 - s, t0 = T - s;
+        // ---- ahead of the exchange: everything of the two cells that does not need dh
+        CellFac f1[NT], f0[NT];
         float dup1[NT][4], m0[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            cell_factors(sv.q1[nt][0], sv.q1[nt][1], sv.cq1[nt], sv.cp1[nt], f1[nt]);
+            cell_factors(sv.q0[nt][0], sv.q0[nt][1], sv.cq0[nt], sv.cp0[nt], f0[nt]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) dup1[nt][j] = do1 ? fmaf(sv.al[nt], dpl[nt][j], sv.ds[nt] * aw[j]) : 0.f;
             drop_mult4(a.rng, a.rng.on != 0 && do0, 0, a.B, T, b0 + 32 * nt + col, t0, H, u0, m0[nt]);
         }
-        if (s == 0 && T >= 1) load_saved(1, svn);              // (step 0 has no exchange phase to wait behind)
+        stp.mark(7);
         float drec1[NT][4], dinx[NT][4], drec0[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { drec1[nt][j] = 0.f; dinx[nt][j] = 0.f; drec0[nt][j] = 0.f; }
         if (s >= 1) {
-            float (*red)[3][NT][32][32] = red2[s & 1];
             if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
                 s_abort = 1;
                 atomicExch(a.status, ST2_BWD_TIMEOUT);
             }
             stp.mark(0);
-            f32x16 aR1[NT], aX0[NT], aR0[NT];
+            // the partial sums the P members sent this wave at step s-1, added in member order
+            const nsd_rsrc rr = make_rsrc(ring0 + (long)((s - 1) & 1) * slot_stride, (unsigned)Ring::SLOT_BYTES);
+            u32x4 v16[P][NT];
+            u32x2 v8[P][NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { aR1[nt] = zero16(); aX0[nt] = zero16(); aR0[nt] = zero16(); }
-            // the ring slot the group filled at step s-1: [X = da1_{t0} | Y = da0_{t0+1}].  X feeds the recurrent term of layer 1
-            // AND layer 1's input gradient (= layer 0's upstream term): the same fragment, two MFMAs; Y the recurrent term of
-            // layer 0 (zeros at s == 1: step 0 publishes them).  This wave's quarter of the columns is NX contiguous 1-KB blocks
-            // of each; they come by LDS-DMA, NSLOT in flight, the fragment read FA blocks ahead of its MFMA -- after the first
-            // block has landed the matrix pipe does not wait (register staging + ds_write cost 6 800 cycles of a 13 500-cycle
-            // step for 1 540 cycles of MFMA).
-            const bf16_t *ring = a.xch + ((long)((s - 1) & 1) * a.groups_total + a.group0 + me.group) * 2 * XB + ((long)wave * NX * 64 + lane) * 8;
-            auto src_of = [&](const int j) { return ring + (j < NX ? (long)j * 512 : XB + (long)(j - NX) * 512); };
-            auto frag_of = [&](const int j) { return *reinterpret_cast<const bf16x8 *>(&land[j % NSLOT][lane * 8]); };
+            for (int q = 0; q < P; ++q)
 #pragma unroll
-            for (int j = 0; j < NSLOT; ++j) dma_block_sc1(src_of(j), land_addr + 1024u * j);
-            bf16x8 fr[FA + 1];
-#pragma unroll
-            for (int j = 0; j < FA; ++j) { wait_vm(NSLOT - 1 - j); fr[j] = frag_of(j); }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (j + FA < NB) {
-                    const int issued = (NSLOT + j) < NB ? (NSLOT + j) : NB;
-                    wait_vm(issued - 1 - (j + FA));
-                    fr[(j + FA) % (FA + 1)] = frag_of(j + FA);
-                    // the last block has landed: request the next step's saved set (HBM) -- nothing of this step waits behind it
-                    if (j + FA == NB - 1 && s + 1 <= T) load_saved(s + 1, svn);
+                for (int nt = 0; nt < NT; ++nt) {
+                    v16[q][nt] = ld_sc1_b128(rr, Ring::off16(me.p, q, nt, wave) + 16u * lane);
+                    v8[q][nt] = ld_sc1_b64(rr, Ring::off8(me.p, q, nt, wave) + 8u * lane);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    const int jj = j < NX ? j : j - NX, half = jj & 1, nt = (jj >> 1) % NT, ks = 2 * (jj / (2 * NT)) + half;
-                    if (j < NX) {
-                        aR1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq1[ks], fr[j % (FA + 1)], aR1[nt], 0, 0, 0);
-                        aX0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqx[ks], fr[j % (FA + 1)], aX0[nt], 0, 0, 0);
-                    } else {
-                        aR0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq0[ks], fr[j % (FA + 1)], aR0[nt], 0, 0, 0);
-                    }
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    drec1[nt][0] += bf16_lo(v16[q][nt][0]); drec1[nt][1] += bf16_hi(v16[q][nt][0]);
+                    drec1[nt][2] += bf16_lo(v16[q][nt][1]); drec1[nt][3] += bf16_hi(v16[q][nt][1]);
+                    dinx[nt][0] += bf16_lo(v16[q][nt][2]); dinx[nt][1] += bf16_hi(v16[q][nt][2]);
+                    dinx[nt][2] += bf16_lo(v16[q][nt][3]); dinx[nt][3] += bf16_hi(v16[q][nt][3]);
+                    drec0[nt][0] += bf16_lo(v8[q][nt][0]); drec0[nt][1] += bf16_hi(v8[q][nt][0]);
+                    drec0[nt][2] += bf16_lo(v8[q][nt][1]); drec0[nt][3] += bf16_hi(v8[q][nt][1]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + NSLOT < NB) dma_block_sc1(src_of(j + NSLOT), land_addr + 1024u * (j % NSLOT));
-                if (j == NX - 1) stp.mark(1);
-            }
-            stp.mark(2);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = mfma32_row(r, lane);
-                    red[wave][0][nt][n][col] = aR1[nt][r];
-                    red[wave][1][nt][n][col] = aX0[nt][r];
-                    red[wave][2][nt][n][col] = aR0[nt][r];
-                }
-            stp.mark(3);
-            __syncthreads();
-            if (s_abort) break;
-            stp.mark(4);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = 8 * wave + 4 * hh + j;
-                    drec1[nt][j] = (red[0][0][nt][n][col] + red[1][0][nt][n][col]) + (red[2][0][nt][n][col] + red[3][0][nt][n][col]);
-                    dinx[nt][j] = (red[0][1][nt][n][col] + red[1][1][nt][n][col]) + (red[2][1][nt][n][col] + red[3][1][nt][n][col]);
-                    drec0[nt][j] = (red[0][2][nt][n][col] + red[1][2][nt][n][col]) + (red[2][2][nt][n][col] + red[3][2][nt][n][col]);
-                }
+            stp.mark(1);
         }
-        stp.mark<true>(5);                                       // (diagnostic build: + arrival of this step's saved activations)
-        // ---- cell backward of both layers; da1_{t1}, da0_{t0} -> ring slot of this step (exchange), row-major copies for the
-        // weight-gradient GEMMs behind the flag
+        // ---- the dh-dependent rest of both cells: da1_{t1}, da0_{t0}
         unsigned dw1[NT][8], dw0[NT][8];
-        bf16_t *slot = a.xch + ((long)(s & 1) * a.groups_total + a.group0 + me.group) * 2 * XB;
-        const int gtw = 4 * me.p + wave;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (do1) {
                 float dh[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dh[j] = dup1[nt][j] + drec1[nt][j];
-                cell_bwd4(sv.q1[nt][0], sv.q1[nt][1], sv.cq1[nt], sv.cp1[nt], dh, dc1[nt], dbs1, dw1[nt]);
-                ring_put_da(same_l2, slot, gtw, nt, NT, col, hh, dw1[nt]);
+                cell_apply(f1[nt], dh, dc1[nt], dbs1, dw1[nt]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dw1[nt][j] = 0u;
             }
             if (do0) {
                 float dh[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dh[j] = fmaf(dinx[nt][j], m0[nt][j], drec0[nt][j]);
-                cell_bwd4(sv.q0[nt][0], sv.q0[nt][1], sv.cq0[nt], sv.cp0[nt], dh, dc0[nt], dbs0, dw0[nt]);
+                cell_apply(f0[nt], dh, dc0[nt], dbs0, dw0[nt]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dw0[nt][j] = 0u;    // step 0: the Y block step 1 reads is da0_{T} = 0
+                for (int j = 0; j < 8; ++j) dw0[nt][j] = 0u;    // step 0: da0_{T} = 0 (its products are published as zeros)
             }
-            ring_put_da(same_l2, slot + XB, gtw, nt, NT, col, hh, dw0[nt]);
         }
-        stp.mark(6);
-        if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
-        stp.mark(7);
+        stp.mark(2);
+        if (s < T) {                                            // (after the last step nobody reads a partial sum)
+            const int par = s & 1;
+            if (NSD_SCAN_ABLATE & 64) load_saved(s + 1, sv);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    *reinterpret_cast<u32x4 *>(&dab[par][1][2 * wave + h][nt][lane * 8]) = u32x4{dw1[nt][4 * h], dw1[nt][4 * h + 1], dw1[nt][4 * h + 2], dw1[nt][4 * h + 3]};
+                    *reinterpret_cast<u32x4 *>(&dab[par][0][2 * wave + h][nt][lane * 8]) = u32x4{dw0[nt][4 * h], dw0[nt][4 * h + 1], dw0[nt][4 * h + 2], dw0[nt][4 * h + 3]};
+                }
+            __syncthreads();
+            if (s_abort) break;
+            stp.mark(3);
+            if (!(NSD_SCAN_ABLATE & (8 | 16 | 32 | 64))) load_saved(s + 1, sv);   // (its factors were taken at the top of the step: the registers are free)
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- partial sums of dh for every unit of the group from this workgroup's 128 + 128 columns, one consumer (row tile) at
+            // a time: its three accumulator tiles are converted and sent while the next consumer's MFMAs run
+            if (has_rows) {
+                const nsd_rsrc rw = make_rsrc(ring0 + (long)(s & 1) * slot_stride, (unsigned)Ring::SLOT_BYTES);
+                constexpr int NF = KS * NT, D = 3;
+                auto frag = [&](const int layer, const int i) { return *reinterpret_cast<const bf16x8 *>(&dab[par][layer][i / NT][i % NT][lane * 8]); };
+#pragma unroll
+                for (int ri = 0; ri < RT; ++ri) {
+                    const int r = wave + 4 * ri;
+                    f32x16 aR1[NT], aX0[NT], aR0[NT];
+                    bf16x8 g1[D], g0[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) { g1[i] = frag(1, i); g0[i] = frag(0, i); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) {
+                        const int ks = i / NT, nt = i % NT;
+                        if (ks == 0) { mfma_new_a(aR1[nt], wq1[ri][ks], g1[i % D]); mfma_new_a(aX0[nt], wqx[ri][ks], g1[i % D]); mfma_new_a(aR0[nt], wq0[ri][ks], g0[i % D]); }
+                        else { mfma_acc_a(aR1[nt], wq1[ri][ks], g1[i % D]); mfma_acc_a(aX0[nt], wqx[ri][ks], g1[i % D]); mfma_acc_a(aR0[nt], wq0[ri][ks], g0[i % D]); }
+                        if (i + D < NF) { g1[i % D] = frag(1, i + D); g0[i % D] = frag(0, i + D); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mfma_settle(aR1[nt], aX0[nt], aR0[nt]);
+                    if (ri == RT - 1) stp.mark(4);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const u32x4 o16 = {pack_bf16x2(aR1[nt][4 * q], aR1[nt][4 * q + 1]), pack_bf16x2(aR1[nt][4 * q + 2], aR1[nt][4 * q + 3]),
+                                               pack_bf16x2(aX0[nt][4 * q], aX0[nt][4 * q + 1]), pack_bf16x2(aX0[nt][4 * q + 2], aX0[nt][4 * q + 3])};
+                            const u32x2 o8 = {pack_bf16x2(aR0[nt][4 * q], aR0[nt][4 * q + 1]), pack_bf16x2(aR0[nt][4 * q + 2], aR0[nt][4 * q + 3])};
+                            st_ring_b128(same_l2, rw, Ring::off16(r, me.p, nt, q) + 16u * lane, o16);
+                            st_ring_b64(same_l2, rw, Ring::off8(r, me.p, nt, q) + 8u * lane, o8);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                stp.mark(4);
+            }
+            if (NSD_SCAN_ABLATE & 32) load_saved(s + 1, sv);
+            stp.mark(5);
+            if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
+            stp.mark(6);
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // (hipcc otherwise hoists these HBM-bound stores ahead of the ring stores)
+        if ((NSD_SCAN_ABLATE & 16) && s < T) load_saved(s + 1, sv);
+        // ---- row-major da for the weight-gradient GEMMs: behind the flag, nobody waits for it inside this launch
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const long rb = b0 + 32 * nt + col;
+            const int rb = b0 + 32 * nt + col;
             if (do1) {
-                bf16_t *d = a.da1 + ((long)t1 * Bp + rb) * G + 4 * u0;
+                bf16_t *d = a.da1 + seq_row(t1, rb, T) * G + 4 * u0;
                 *reinterpret_cast<u32x4 *>(d) = u32x4{dw1[nt][0], dw1[nt][1], dw1[nt][2], dw1[nt][3]};
                 *reinterpret_cast<u32x4 *>(d + 8) = u32x4{dw1[nt][4], dw1[nt][5], dw1[nt][6], dw1[nt][7]};
             }
             if (do0) {
-                bf16_t *d = a.da0 + ((long)t0 * Bp + rb) * G + 4 * u0;
+                bf16_t *d = a.da0 + seq_row(t0, rb, T) * G + 4 * u0;
                 *reinterpret_cast<u32x4 *>(d) = u32x4{dw0[nt][0], dw0[nt][1], dw0[nt][2], dw0[nt][3]};
                 *reinterpret_cast<u32x4 *>(d + 8) = u32x4{dw0[nt][4], dw0[nt][5], dw0[nt][6], dw0[nt][7]};
             }
         }
-        sv = svn;
     }
     stp.store(a.status, blockIdx.x == 0 && tid == 0);
     // ---- bias gradients of this batch tile, both layers
@@ -509,10 +568,10 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
 
 }  // namespace
 
-// LDS of the forward kernel: 2 x 3 tiles of MG x (H + 8) bf16; of the backward kernel: 96 KB x NT of partials + 32 KB of DMA landing rings
+// LDS of the forward kernel: 2 x 3 tiles of MG x (H + 8) bf16; of the backward kernel: 32 KB x NT (the workgroup's own da as B operands)
 bool nsd_scan2_supported(int H, int MG) {
     if (!(H == 64 || H == 128 || H == 256)) return false;
-    const long fwd = 2L * 3 * MG * (H + 8) * 2, bwd = 2L * 4 * 3 * (MG / 32) * 4096 + 4L * 8 * 1024;
+    const long fwd = 2L * 3 * MG * (H + 8) * 2, bwd = 2L * 2 * 8 * (MG / 32) * 1024;
     return fwd <= 150 * 1024 && bwd <= 150 * 1024;
 }
 

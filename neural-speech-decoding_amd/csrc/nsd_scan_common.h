@@ -133,6 +133,24 @@ __device__ __forceinline__ void mfma_rows(const bf16x8 *w, const bf16_t *tile, c
     }
 }
 
+// MFMA with the weight fragment (A operand) and the accumulator read straight from accumulation registers.  The scans keep
+// 128-192 weight registers per lane; hipcc parks most of them in AGPRs and copies each fragment back with four v_accvgpr_read
+// before its MFMA -- with one wave per SIMD those copies issue in the MFMA's own slot, and a 32-cycle MFMA gap became ~55
+// (2 900 cycles for 48 MFMAs).  As asm statements with "a" constraints the operands are used where they live.  hipcc knows
+// nothing about the latency of these statements: mfma_settle(accumulators) before any other instruction reads one (in-place
+// accumulation chains and independent accumulators need nothing, as in hipcc's own output).
+__device__ __forceinline__ void mfma_acc_a(f32x16 &acc, const bf16x8 &w, const bf16x8 &f) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(f));
+}
+__device__ __forceinline__ void mfma_new_a(f32x16 &acc, const bf16x8 &w, const bf16x8 &f) {       // acc = w . f
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(w), "v"(f));
+}
+// (the accumulators are operands of the statement: a register read of one cannot be scheduled above it)
+__device__ __forceinline__ void mfma_settle(f32x16 &a0) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0)); }
+__device__ __forceinline__ void mfma_settle(f32x16 &a0, f32x16 &a1) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0), "+a"(a1)); }
+__device__ __forceinline__ void mfma_settle(f32x16 &a0, f32x16 &a1, f32x16 &a2) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0), "+a"(a1), "+a"(a2)); }
+__device__ __forceinline__ void mfma_lead_in() { asm volatile("s_nop 7" ::: "memory"); }             // VALU-written accumulator -> first MFMA
+
 // Software-pipelined form for a whole step: NS operand streams (weight rows w[st], LDS tile tile[st]) feeding accumulators
 // chosen by acc_of(st, nt).  DEPTH fragments are in flight: the read of fragment i + DEPTH is issued right behind MFMA i, so
 // after the first DEPTH reads no MFMA waits for the LDS (mfma_rows exposes the LDS latency once per batch of 8: 48 MFMAs took
@@ -147,15 +165,19 @@ __device__ __forceinline__ void mfma_pipe(const bf16x8 *const (&w)[NS], const bf
     };
 #pragma unroll
     for (int i = 0; i < D; ++i) f[i] = rd(i);
+    mfma_lead_in();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int st = i / (NK * NT), k = (i / NT) % NK, nt = i % NT;
-        f32x16 &acc = acc_of(st, nt);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[st][k], f[i % D], acc, 0, 0, 0);
+        mfma_acc_a(acc_of(st, nt), w[st][k], f[i % D]);
         if (i + D < N) f[i % D] = rd(i + D);
         __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mfma_settle(acc_of(st, nt));   // (an accumulator fed by two streams is named twice: harmless)
 }
 
 // ---- exchange rings -------------------------------------------------------------------------------------------------------
@@ -237,6 +259,19 @@ struct DaChunk {
         }
     }
 };
+
+// ---- saved activations ----------------------------------------------------------------------------------------------------
+// cs / ga are private to a forward / backward pair of scans (lane (trial, hh) of wave w of member p owns the same 4 units in
+// both), so they are stored per owner instead of row-major: block (32-trial tile, member, step, wave) =
+//   gates [half 2][lane 64][16 B] = 2 KB (half 0: the lane's units 0,1 x 4 gates), cell state [lane 64][8 B] = 512 B.
+// Every store / load instruction then moves one contiguous KB.  (Row-major, a lane's 32 bytes sat in a row of their own: 64
+// line requests per instruction, ~2 400 per CU and step in the backward scan -- ISSUING the step's saved-activation loads took
+// ~2 500 cycles wherever they were placed.)
+__device__ __forceinline__ long saved_block(const int tile32, const int P, const int p, const int T, const int t, const int wave) {
+    return (((long)tile32 * P + p) * T + t) * 4 + wave;
+}
+__device__ __forceinline__ long saved_ga(const long block, const int half, const int lane) { return block * 1024 + half * 512 + lane * 8; }   // bf16 elements
+__device__ __forceinline__ long saved_cs(const long block, const int lane) { return block * 256 + lane * 4; }
 
 // dropout multipliers of 4 adjacent units of one (layer, trial, step): the product's counter stream (nsd_rand_u32, index
 // ((layer * B + b) * T + t) * ld + column); all 1 for padding trials or when the stream is off

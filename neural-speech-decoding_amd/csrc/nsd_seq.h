@@ -6,19 +6,25 @@
 // :14 (and `bidirectional=True` where :16-22 would take it) -- computed with bf16 GEMM operands and bf16 saved activations,
 // fp32 accumulation, fp32 cell state and gate arithmetic.
 //
-// Layout of the path, all time-major so that one time step of a batch tile is one contiguous block:
-//   rows r = t * Bp + b, Bp = B rounded up to the batch tile (padding trials carry zeros and produce zero gradients)
+// Layout of the path.  Rows are TILE-MAJOR: r = seq_row(t, b) = ((b / 32) * T + t) * 32 + b % 32 -- the 32 trials of a batch
+// tile are adjacent rows and the tile's T time steps follow one another, so every persistent workgroup walks ONE contiguous
+// region of each tensor.  (Time-major rows t * Bp + b put consecutive steps of a tile Bp rows apart -- 2 MB in ga at cfg3 --
+// and every step of every scan touched a fresh translation in each of ~8 tensors: issuing a step's saved-activation loads
+// cost ~3 000 cycles of a 13 000-cycle backward step.)  Bp = B rounded up to the batch tile (padding trials carry zeros and
+// produce zero gradients).  The GEMMs see [T*Bp][cols] matrices; the reduction over rows does not care about their order.
 //   xbf   [T*Bp][CP]        the EEG windows as bf16 (CP = C rounded up to 16)
 //   hs[l] [T*Bp][D*H]       h_t of layer l, direction d in columns d*H..        (recurrent exchange, dW_hh operand)
 //   lk[l] [T*Bp][D*H]       what layer l+1 and the head read: h * dropout multiplier (== hs[l] without dropout)
 //   cs    [T*Bp][H], ga [T*Bp][4H] per (l, d): cell state and activated gates (unit-major quads) for the backward pass
-//   xproj [T*Bp/32][4H/32][64][16] per d: input projection + bias as MFMA accumulator tiles (the scan's lanes load 32 bytes)
+//   xproj [T*Bp/32][4H/32][64][16] per d (row tile (b/32)*T + t): input projection + bias as MFMA accumulator tiles (the scan's lanes load 32 bytes)
 //   da    [T*Bp][D*4H]      gate pre-activation gradients of the layer in flight (unit-major columns c = 4u + g)
 //   din   [T*Bp][D*H] fp32  gradient w.r.t. the layer's output coming from the layer above
 #pragma once
 #include "nsd_bf16.h"
 
 #define NSD_SEQ_MAX_DIRS 2
+
+__host__ __device__ __forceinline__ long seq_row(const int t, const int b, const int T) { return ((long)(b >> 5) * T + t) * 32 + (b & 31); }
 #define NSD_SEQ_STATUS_WORDS 16
 
 struct SeqDims {

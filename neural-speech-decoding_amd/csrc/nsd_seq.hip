@@ -93,7 +93,12 @@ SeqWs make_ws(const SeqDims &s) {
     w.hb_stride = align_up(nsd_head_tm_row_floats((int)DH, s.F, s.K), 4);
     w.hb = take((int64_t)s.Bp * w.hb_stride * 4);
     w.dbp = take((int64_t)(s.D > 2 ? s.D : 2) * s.groups * G * 4);
-    w.xch = take(2LL * s.groups * 3 * s.MG * (s.D * 4LL * H) * 2);   // exchange rings of the scans (sized for the widest: da tiles)
+    {   // exchange rings of the scans, sized for the widest user: da tiles (single-layer backward) or the partial-sum blocks of the
+        // fused backward (nsd_scan2.hip, PartRing: P * P * NT * 4 blocks of 1.5 KB per group and step parity)
+        const int64_t tiles = 2LL * s.groups * 3 * s.MG * (s.D * 4LL * H) * 2, Pm = H / 32;
+        const int64_t parts = 2LL * s.groups * s.D * Pm * Pm * (s.MG / 32) * 4 * 1536;
+        w.xch = take(tiles > parts ? tiles : parts);
+    }
     w.parts = take(64LL * 1024 * 1024);                          // split-K partials of the weight-gradient GEMMs (<= 16 M floats)
     w.total = p;
     return w;
@@ -286,15 +291,16 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             memset(&g, 0, sizeof(g));
             g.A = da + (long)d * G; g.lda = ldda; g.a_kmajor = 1; g.b_kmajor = 1;
             g.C = parts; g.M = G; g.K = R; g.epi = GEMM_EPI_F32;
-            // recurrent weights: operand h_{t-1} of the direction (one time step = Bp rows away)
+            // recurrent weights: operand h_{t-1} of the direction: one time step = 32 rows away inside the batch tile's block of
+            // T * 32 rows (tile-major rows); the step before the first of a tile is zero
             g.B = at<bf16_t>(c.ws, c.w.hs[l]) + (long)d * H; g.ldb = DH; g.N = H; g.ldc = H;
-            g.b_shift = d == 0 ? -(long)s.Bp : (long)s.Bp;
+            g.b_shift = d == 0 ? -32 : 32; g.b_period = (long)s.T * 32;
             g.splits = split_count(G, H, R);
             if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
             hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * H + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, H, H,
                                grads + c.pl.w_hh[l][d]);
             // input weights
-            g.B = in; g.ldb = Kin; g.N = Kin; g.ldc = Kin; g.b_shift = 0;
+            g.B = in; g.ldb = Kin; g.N = Kin; g.ldc = Kin; g.b_shift = 0; g.b_period = 0;
             g.splits = split_count(G, Kin, R);
             if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
             hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * I + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, Kin, I,

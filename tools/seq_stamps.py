@@ -32,5 +32,5 @@ for _ in range(3):
 acc = ws[:128].cpu().numpy().view(np.int32)[4:20].view(np.uint64)
 tot = acc.sum()
 print(f"backward scan: total/step {tot / (T + 1):.0f}")
-for n, v in zip(["top: issue saved-activation loads + poll", "X tile: stage + 2x16 MFMA", "Y tile: stage + 16 MFMA", "partials -> LDS", "barrier", "reduce + wait for saved activations", "cells + ring stores", "drain + flag"], acc):
-    print(f"   {n:40s} {v / (T + 1):9.1f}  ({100.0 * v / max(tot, 1):5.1f} %)")
+for n, v in zip(["poll", "partial-sum loads + add", "cells (dh-dependent part)", "own da -> LDS + barrier", "MFMA (48) + saved-set request", "convert + ring stores", "drain + flag", "row-major stores + cell factors of the next step"], acc):
+    print(f"   {n:50s} {v / (T + 1):9.1f}  ({100.0 * v / max(tot, 1):5.1f} %)")
