@@ -255,25 +255,28 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int H, int NT>
 __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
-    constexpr int P = H / 32, MG = 32 * NT, G = 4 * H, KQ = G / 16 / 4;       // k steps of one wave's quarter of the contraction
-    // partial dh_rec tiles of the 4 waves, [unit of the workgroup][trial]; two sets alternate by step (one barrier per step)
-    __shared__ __align__(16) float red2[2][4][NT][32][32];
-    constexpr int CW = (G / 4) < 128 ? (G / 4) : 128;          // columns per staged chunk of a wave's quarter
-    constexpr int NCH = (G / 4) / CW, LDS_ = CW + 8;
-    __shared__ __align__(16) bf16_t stg[4][MG * LDS_];         // one private strip per wave
+    // The recurrent term dh_rec = W_hh^T da_{t+1} is exchanged as a reduce-scatter of bf16 partial sums (design and ring layout:
+    // nsd_scan2.hip, "backward"): the workgroup multiplies its OWN 128 gate columns of da (from LDS, K = 128) into partial dh
+    // rows for every unit of the layer and sends each member the 32 rows it owns; a member adds the P partials in fp32.
+    constexpr int P = H / 32, MG = 32 * NT, G = 4 * H, RT = P >= 4 ? P / 4 : 1, KS = 8;
+    constexpr long NBLK = (long)P * P * NT * 4, SLOT_BYTES = NBLK * 512;          // [consumer][producer][nt][consumer wave] x (64 lanes x 8 B)
+    __shared__ __align__(16) bf16_t dab[2][KS][NT][512];        // [step parity][k-step = 2 * wave + half][nt][lane * 8]
     __shared__ int s_abort;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Member me = member_of(blockIdx.x, a.groups, P, a.spread_groups);
     const int dir = me.dir;
     const int b0 = (a.group0 + me.group) * MG;
     const int col = lane & 31, hh = lane >> 5;
+    const bool has_rows = wave < P;
 
-    // W_hh^T rows = this workgroup's 32 units, k = this wave's quarter of the 4H gate columns
-    bf16x8 w[KQ];
-    {
-        const bf16_t *wrow = a.wb[dir] + (long)(32 * me.p + col) * G + wave * (G / 4) + 8 * hh;
+    // rows of W_hh^T for the consumers r = wave + 4 ri, columns = this workgroup's 128 gate columns in k-step order
+    bf16x8 wq[RT][KS];
 #pragma unroll
-        for (int ks = 0; ks < KQ; ++ks) w[ks] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ks);
+    for (int ri = 0; ri < RT; ++ri) {
+        const int r = (wave + 4 * ri) < P ? wave + 4 * ri : 0;
+        const bf16_t *wrow = a.wb[dir] + (long)(32 * r + col) * G + 128 * me.p + 16 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wq[ri][ks] = *reinterpret_cast<const bf16x8 *>(wrow + 32 * (ks >> 1) + 8 * (ks & 1));
     }
     float dc[NT][4];
 #pragma unroll
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
     if (tid == 0 && me.p == 0) atomicAdd(a.status + (rv == 1 ? 2 : 3), 1);
-    const long ld = a.ld, ldda = (long)a.D * G, tstride = (long)a.T * 32;
-    auto trow = [&](const int row) { return (row >> 5) * tstride + (row & 31); };
+    const long ld = a.ld, ldda = (long)a.D * G;
+    const int T = a.T;
     float dbs[16];                                             // bias gradient of this lane's 16 gate columns, summed over time and tiles
 #pragma unroll
     for (int k = 0; k < 16; ++k) dbs[k] = 0.f;
@@ -304,40 +307,60 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dpl[nt][j] = a.din ? 0.f : a.dpooled[(long)(b0 + 32 * nt + col) * ld + dir * H + u0 + j];
+    const char *ring0 = reinterpret_cast<const char *>(a.xch) + ((long)dir * a.groups_total + a.group0 + me.group) * SLOT_BYTES;
+    const long slot_stride = (long)a.D * a.groups_total * SLOT_BYTES;
+    auto blk_off = [&](const int cons, const int prod, const int nt, const int q) { return (unsigned)(((((cons * P + prod) * NT + nt) * 4 + q)) << 9); };
 
-    for (int s = 0; s < a.T; ++s) {
-        const int t = dir == 0 ? a.T - 1 - s : s;              // reverse of the forward order
-        const int tn = dir == 0 ? t + 1 : t - 1;               // the step processed just before (later in forward time)
-        const int tprev = dir == 0 ? t - 1 : t + 1;            // earlier in forward time: c_{t-1}
-        // saved activations and upstream gradient of this step: independent of the recurrence
+    // saved activations and upstream gradient of a step: independent of the recurrence, requested one step ahead (after the
+    // barrier of the step before: the MFMA phase follows)
+    struct Saved {
         u32x4 gq[NT][2];
         u32x2 cq[NT], cpq[NT];
+        f32x4 dv[NT];
+        float al[NT], ds[NT];
+    };
+    auto t_of = [&](const int s) { return dir == 0 ? T - 1 - s : s; };   // reverse of the forward order
+    auto load_saved = [&](const int s, Saved &v) {
+        const int t = t_of(s), tprev = dir == 0 ? t - 1 : t + 1;         // tprev: earlier in forward time (c_{t-1})
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int b = b0 + 32 * nt + col;
+            const long row = seq_row(t, b, T);
+            const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t, wave);
+            const bf16_t *gs = a.ga[dir] + saved_ga(blk, 0, lane);
+            v.gq[nt][0] = *reinterpret_cast<const u32x4 *>(gs);
+            v.gq[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 512);
+            v.cq[nt] = *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk, lane));
+            const bool first = dir == 0 ? t == 0 : t == T - 1;
+            v.cpq[nt] = first ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk + 4 * (tprev - t), lane));
+            if (a.din) { v.dv[nt] = *reinterpret_cast<const f32x4 *>(a.din + row * ld + dir * H + u0); v.al[nt] = 0.f; v.ds[nt] = 0.f; }
+            else { v.dv[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; v.al[nt] = a.alpha[row]; v.ds[nt] = a.dscore[row]; }
+        }
+    };
+    Saved sv;
+    load_saved(0, sv);
+    for (int s = 0; s < T; ++s) {
+        const int t = t_of(s);
+        // ---- ahead of the exchange: the upstream term and everything of the cell that does not need dh
+        CellFac fc[NT];
         float dup[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int b = b0 + 32 * nt + col;
-            const long row = seq_row(t, b, a.T);
-            const long blk = saved_block((b0 >> 5) + nt, P, me.p, a.T, t, wave);
-            const bf16_t *gs = a.ga[dir] + saved_ga(blk, 0, lane);
-            gq[nt][0] = *reinterpret_cast<const u32x4 *>(gs);
-            gq[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 512);
-            cq[nt] = *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk, lane));
-            const bool first = dir == 0 ? t == 0 : t == a.T - 1;
-            cpq[nt] = first ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk + 4 * (tprev - t), lane));
+            const long row = seq_row(t, b, T);
+            cell_factors(sv.gq[nt][0], sv.gq[nt][1], sv.cq[nt], sv.cpq[nt], fc[nt]);
             if (a.din) {
-                const f32x4 dv = *reinterpret_cast<const f32x4 *>(a.din + row * ld + dir * H + u0);
                 float m[4] = {1.f, 1.f, 1.f, 1.f};
                 if (a.rng.on && b < a.B) {
-                    const uint64_t base = (((uint64_t)a.layer * a.B + b) * a.T + t) * (uint64_t)ld + (uint64_t)(dir * H + u0);
+                    const uint64_t base = (((uint64_t)a.layer * a.B + b) * T + t) * (uint64_t)ld + (uint64_t)(dir * H + u0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) m[j] = nsd_rand_u32(a.rng.seed, a.rng.base, base + j) >= a.rng.thr_lstm ? a.rng.keep_lstm : 0.f;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dup[nt][j] = dv[j] * m[j];
+                for (int j = 0; j < 4; ++j) dup[nt][j] = sv.dv[nt][j] * m[j];
             } else {
-                const float al = a.alpha[row], ds = a.dscore[row];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dup[nt][j] = fmaf(al, dpl[nt][j], ds * aw[j]);
+                for (int j = 0; j < 4; ++j) dup[nt][j] = fmaf(sv.al[nt], dpl[nt][j], sv.ds[nt] * aw[j]);
             }
             if (a.dres) *reinterpret_cast<f32x4 *>(a.dres + row * ld + dir * H + u0) = f32x4{dup[nt][0], dup[nt][1], dup[nt][2], dup[nt][3]};
         }
@@ -347,91 +370,86 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) drec[nt][j] = 0.f;
         if (s > 0) {
-            float (*red)[NT][32][32] = red2[s & 1];
             if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
                 s_abort = 1;
                 atomicExch(a.status, ST_BWD_TIMEOUT);
             }
-            // dh_rec partial: rows = this workgroup's 32 units, columns = trials, k = this wave's quarter of da_{t+1}'s columns.
-            // The wave stages its quarter of the tile through its PRIVATE LDS strip in chunks of CW columns: the global loads
-            // are whole 128-byte lines (16 lanes per row) instead of 32-byte fragments -- 4x fewer L2 requests, which is what
-            // bounds this kernel -- and no other wave touches the strip, so only the wave's own counters order it.
-            f32x16 acc[NT];
+            // the partial sums the P members sent this wave at step s-1, added in member order
+            const nsd_rsrc rr = make_rsrc(ring0 + (long)((s - 1) & 1) * slot_stride, (unsigned)SLOT_BYTES);
+            u32x2 v8[P][NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
-            const nsd_rsrc rd = make_rsrc(a.da + seq_row(tn, b0, a.T) * ldda + dir * G + wave * (G / 4), (unsigned)(((NT - 1) * tstride + 32) * ldda * 2));
-            bf16_t *strip = stg[wave];
-            constexpr int LPI = CW / 8;                          // lanes per row of a chunk (16-byte pieces)
-            constexpr int RPI = 64 / LPI;                        // rows per load instruction
-            constexpr int NLD = MG / RPI;                        // load instructions per chunk
-            const int lrow = lane / LPI, lpc = lane % LPI;
-            u32x4 pv[NLD];
+            for (int q = 0; q < P; ++q)
 #pragma unroll
-            for (int i = 0; i < NLD; ++i)
-                pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}
-                                              : ld_sc1_b128(rd, (unsigned)((trow(lrow + RPI * i) * ldda + 8 * lpc) * 2));
+                for (int nt = 0; nt < NT; ++nt) v8[q][nt] = ld_sc1_b64(rr, blk_off(me.p, q, nt, wave) + 8u * lane);
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
+            for (int q = 0; q < P; ++q)
 #pragma unroll
-                for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4 *>(strip + (lrow + RPI * i) * LDS_ + 8 * lpc) = pv[i];
-                if (ch + 1 < NCH) {
-#pragma unroll
-                    for (int i = 0; i < NLD; ++i)
-                        pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}
-                                                      : ld_sc1_b128(rd, (unsigned)((trow(lrow + RPI * i) * ldda + CW * (ch + 1) + 8 * lpc) * 2));
-                }
-                mfma_rows<NT, CW / 16, LDS_>(w + ch * (CW / 16), strip, col, hh, acc);
-                // (the compiler orders the next chunk's ds_write behind these ds_reads: same wave, same LDS object)
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[wave][nt][mfma32_row(r, lane)][col] = acc[nt][r];
-            __syncthreads();
-            if (s_abort) break;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = 8 * wave + 4 * hh + j;
-                    drec[nt][j] = (red[0][nt][n][col] + red[1][nt][n][col]) + (red[2][nt][n][col] + red[3][nt][n][col]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    drec[nt][0] += bf16_lo(v8[q][nt][0]); drec[nt][1] += bf16_hi(v8[q][nt][0]);
+                    drec[nt][2] += bf16_lo(v8[q][nt][1]); drec[nt][3] += bf16_hi(v8[q][nt][1]);
                 }
         }
-        // ---- cell backward for (trial, 4 units); da_t -> exchange + saved for the weight-gradient GEMMs
+        // ---- the dh-dependent rest of the cell: da_t
+        unsigned dw[NT][8];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            unsigned dw[8];
-            const float cv[4] = {bf16_lo(cq[nt][0]), bf16_hi(cq[nt][0]), bf16_lo(cq[nt][1]), bf16_hi(cq[nt][1])};
-            const float cp[4] = {bf16_lo(cpq[nt][0]), bf16_hi(cpq[nt][0]), bf16_lo(cpq[nt][1]), bf16_hi(cpq[nt][1])};
+            float dh[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned w0 = gq[nt][j >> 1][2 * (j & 1)], w1 = gq[nt][j >> 1][2 * (j & 1) + 1];
-                const float ig = bf16_lo(w0), fg = bf16_hi(w0), gg = bf16_lo(w1), og = bf16_hi(w1);
-                const float tc = fast_tanh(cv[j]);
-                const float dh = dup[nt][j] + drec[nt][j];
-                const float dct = fmaf(dh * og, 1.f - tc * tc, dc[nt][j]);
-                dc[nt][j] = dct * fg;
-                const float dai = dct * gg * ig * (1.f - ig);
-                const float daf = dct * cp[j] * fg * (1.f - fg);
-                const float dag = dct * ig * (1.f - gg * gg);
-                const float dao = dh * tc * og * (1.f - og);
-                dw[2 * j] = pack_bf16x2(dai, daf);
-                dw[2 * j + 1] = pack_bf16x2(dag, dao);
-                dbs[4 * j] += dai; dbs[4 * j + 1] += daf; dbs[4 * j + 2] += dag; dbs[4 * j + 3] += dao;
-            }
-            // (descriptor base wave-uniform, the lane's position in the offset)
-            const nsd_rsrc rs = make_rsrc(a.da + seq_row(t, b0, a.T) * ldda + dir * G, (unsigned)(((NT - 1) * tstride + 32) * ldda * 2));
-            const unsigned off = (unsigned)((trow(32 * nt + col) * ldda + 4 * u0) * 2);
-            if (same_l2) {
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[0], dw[1], dw[2], dw[3]}, rs, (int)off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[4], dw[5], dw[6], dw[7]}, rs, (int)off + 16, 0, 0);
-            } else {
-                st_sc1_b128(rs, off, u32x4{dw[0], dw[1], dw[2], dw[3]});
-                st_sc1_b128(rs, off + 16u, u32x4{dw[4], dw[5], dw[6], dw[7]});
-            }
+            for (int j = 0; j < 4; ++j) dh[j] = dup[nt][j] + drec[nt][j];
+            cell_apply(fc[nt], dh, dc[nt], dbs, dw[nt]);
         }
-        if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
+        if (s + 1 < T) {                                        // (after the last step nobody reads a partial sum)
+            const int par = s & 1;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    *reinterpret_cast<u32x4 *>(&dab[par][2 * wave + h][nt][lane * 8]) = u32x4{dw[nt][4 * h], dw[nt][4 * h + 1], dw[nt][4 * h + 2], dw[nt][4 * h + 3]};
+            __syncthreads();
+            if (s_abort) break;
+            load_saved(s + 1, sv);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_rows) {
+                const nsd_rsrc rw = make_rsrc(ring0 + (long)(s & 1) * slot_stride, (unsigned)SLOT_BYTES);
+                constexpr int NF = KS * NT, D = NF < 4 ? NF : 4;
+                auto frag = [&](const int i) { return *reinterpret_cast<const bf16x8 *>(&dab[par][i / NT][i % NT][lane * 8]); };
+#pragma unroll
+                for (int ri = 0; ri < RT; ++ri) {
+                    const int r = wave + 4 * ri;
+                    f32x16 acc[NT];
+                    bf16x8 g[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) g[i] = frag(i);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) {
+                        const int ks = i / NT, nt = i % NT;
+                        if (ks == 0) mfma_new_a(acc[nt], wq[ri][ks], g[i % D]); else mfma_acc_a(acc[nt], wq[ri][ks], g[i % D]);
+                        if (i + D < NF) g[i % D] = frag(i + D);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mfma_settle(acc[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            st_ring_b64(same_l2, rw, blk_off(r, me.p, nt, q) + 8u * lane,
+                                        u32x2{pack_bf16x2(acc[nt][4 * q], acc[nt][4 * q + 1]), pack_bf16x2(acc[nt][4 * q + 2], acc[nt][4 * q + 3])});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- row-major da_t for the weight-gradient / input-gradient GEMMs: behind the flag
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16_t *d = a.da + seq_row(t, b0 + 32 * nt + col, T) * ldda + dir * G + 4 * u0;
+            *reinterpret_cast<u32x4 *>(d) = u32x4{dw[nt][0], dw[nt][1], dw[nt][2], dw[nt][3]};
+            *reinterpret_cast<u32x4 *>(d + 8) = u32x4{dw[nt][4], dw[nt][5], dw[nt][6], dw[nt][7]};
+        }
     }
     // ---- bias gradients of this batch tile: sum over the 32 trials of each half-wave, one row of dbp per (direction, tile)
 #pragma unroll

@@ -255,47 +255,6 @@ struct PartRing {
     }
 };
 
-__device__ __forceinline__ u32x2 ld_sc1_b64(const nsd_rsrc r, const unsigned byte_off) {
-    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 16);
-}
-__device__ __forceinline__ void st_ring_b128(const bool same_l2, const nsd_rsrc rs, const unsigned off, const u32x4 v) {
-    if (same_l2) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, 0); else st_sc1_b128(rs, off, v);
-}
-__device__ __forceinline__ void st_ring_b64(const bool same_l2, const nsd_rsrc rs, const unsigned off, const u32x2 v) {
-    if (same_l2) __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, 0, 0); else st_sc1_b64(rs, off, v);
-}
-
-// What of a cell's backward does not depend on dh: computed from the saved activations BEFORE the wave polls for its partials
-struct CellFac { float A[4], Fi[4], Ff[4], Fg[4], Fo[4], fg[4]; };
-__device__ __forceinline__ void cell_factors(const u32x4 gq0, const u32x4 gq1, const u32x2 cq, const u32x2 cpq, CellFac &f) {
-    const float cv[4] = {bf16_lo(cq[0]), bf16_hi(cq[0]), bf16_lo(cq[1]), bf16_hi(cq[1])};
-    const float cp[4] = {bf16_lo(cpq[0]), bf16_hi(cpq[0]), bf16_lo(cpq[1]), bf16_hi(cpq[1])};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned w0 = j < 2 ? gq0[2 * (j & 1)] : gq1[2 * (j & 1)], w1 = j < 2 ? gq0[2 * (j & 1) + 1] : gq1[2 * (j & 1) + 1];
-        const float ig = bf16_lo(w0), fg = bf16_hi(w0), gg = bf16_lo(w1), og = bf16_hi(w1);
-        const float tc = fast_tanh(cv[j]);
-        f.A[j] = og * (1.f - tc * tc);                 // d c_t / d h_t (through tanh(c_t))
-        f.Fi[j] = gg * ig * (1.f - ig);
-        f.Ff[j] = cp[j] * fg * (1.f - fg);
-        f.Fg[j] = ig * (1.f - gg * gg);
-        f.Fo[j] = tc * og * (1.f - og);
-        f.fg[j] = fg;
-    }
-}
-// ... and what does: da (16 values, unit-major, packed), the carried dc, the bias-gradient sums
-__device__ __forceinline__ void cell_apply(const CellFac &f, const float (&dh)[4], float (&dc)[4], float (&dbs)[16], unsigned (&dw)[8]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float dct = fmaf(dh[j], f.A[j], dc[j]);
-        dc[j] = dct * f.fg[j];
-        const float dai = dct * f.Fi[j], daf = dct * f.Ff[j], dag = dct * f.Fg[j], dao = dh[j] * f.Fo[j];
-        dw[2 * j] = pack_bf16x2(dai, daf);
-        dw[2 * j + 1] = pack_bf16x2(dag, dao);
-        dbs[4 * j] += dai; dbs[4 * j + 1] += daf; dbs[4 * j + 2] += dag; dbs[4 * j + 3] += dao;
-    }
-}
-
 template <int H, int NT>
 __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
     constexpr int P = H / 32, MG = 32 * NT, G = 4 * H, RT = P >= 4 ? P / 4 : 1, KS = 8;

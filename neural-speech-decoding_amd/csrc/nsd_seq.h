@@ -77,6 +77,7 @@ struct ScanBwdArgs {
     const bf16_t *cs[NSD_SEQ_MAX_DIRS], *ga[NSD_SEQ_MAX_DIRS];
     bf16_t *da;                              // [T*Bp][D*4H]
     float *dbp;                              // [D][groups_total][4H] bias-gradient partials, one row per batch tile (unit-major columns)
+    bf16_t *xch;                             // partial-sum ring [2][D][groups_total][P][P][NT][4][64 x 8 B] (nsd_scan.hip)
     const float *din;                        // [T*Bp][ld] gradient w.r.t. this layer's (multiplied) output, or null (top layer)
     float *dres;                             // [T*Bp][ld] residual extension: d(linked output) * multiplier, added to the input gradient; or null
     const float *alpha, *dscore;             // [T*Bp] (top layer)

@@ -351,7 +351,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             a.alpha = at<float>(c.ws, c.w.alpha); a.dscore = at<float>(c.ws, c.w.dscore); a.dpooled = at<float>(c.ws, c.w.dpooled);
             a.attn_w = c.params + c.pl.attn_w;
             a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)(s.L + l) * s.D * s.groups + (long)g0 * s.D) * 128;
-            a.dbp = at<float>(c.ws, c.w.dbp); a.groups_total = s.groups;
+            a.dbp = at<float>(c.ws, c.w.dbp); a.groups_total = s.groups; a.xch = at<bf16_t>(c.ws, c.w.xch);
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
             a.rng = rng;
