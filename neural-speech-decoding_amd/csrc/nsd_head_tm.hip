@@ -38,7 +38,9 @@ __device__ __forceinline__ float lane_bcast(const float v, const int src) { retu
 
 template <int VPL, bool TRAIN>
 __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
-    constexpr int DH = 64 * VPL, U = 4;
+    // U rows of the trial in flight per lane: the passes over the sequence are latency-bound (one wave per trial, 4 waves per CU at
+    // B = 1024), so the bytes in flight set the rate -- 4 rows gave 1.3 TB/s
+    constexpr int DH = 64 * VPL, U = VPL >= 16 ? 4 : (VPL >= 8 ? 8 : 16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     if (b >= a.B) return;                                       // whole waves leave; nothing below needs the workgroup
@@ -63,18 +65,19 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            if (t0 + q >= T) break;
-            float part = 0.f;
+            if (t0 + q < T) {                                   // (a guard, not a break: the loop must unroll for hv[q] to stay in registers)
+                float part = 0.f;
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) part = fmaf(hv[q][v], aw[v], part);
-            const float s = wave_sum(part) + ab;
-            if (TRAIN && lane == 0) a.alpha[arow + 32L * (t0 + q)] = s;          // raw score; normalised below
-            const float mn = fmaxf(m, s);
-            const float sc = __expf(m - mn), e = __expf(s - mn);
-            l = fmaf(l, sc, e);
+                for (int v = 0; v < VPL; ++v) part = fmaf(hv[q][v], aw[v], part);
+                const float s = wave_sum(part) + ab;
+                if (TRAIN && lane == 0) a.alpha[arow + 32L * (t0 + q)] = s;          // raw score; normalised below
+                const float mn = fmaxf(m, s);
+                const float sc = __expf(m - mn), e = __expf(s - mn);
+                l = fmaf(l, sc, e);
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) acc[v] = fmaf(acc[v], sc, e * hv[q][v]);
-            m = mn;
+                for (int v = 0; v < VPL; ++v) acc[v] = fmaf(acc[v], sc, e * hv[q][v]);
+                m = mn;
+            }
         }
     }
     const float inv_l = 1.f / l;
@@ -196,20 +199,21 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            if (t0 + q >= T) break;
-            float part = 0.f;
+            if (t0 + q < T) {
+                float part = 0.f;
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) part = fmaf(hv[q][v], dpool[v], part);
-            const float qd = wave_sum(part);
-            const float al = __expf(sraw[q] - m) * inv_l;
-            const float ds = al * (qd - dp_pooled);
-            if (lane == 0) {
-                a.alpha[arow + 32L * (t0 + q)] = al;
-                a.dscore[arow + 32L * (t0 + q)] = ds;
+                for (int v = 0; v < VPL; ++v) part = fmaf(hv[q][v], dpool[v], part);
+                const float qd = wave_sum(part);
+                const float al = __expf(sraw[q] - m) * inv_l;
+                const float ds = al * (qd - dp_pooled);
+                if (lane == 0) {
+                    a.alpha[arow + 32L * (t0 + q)] = al;
+                    a.dscore[arow + 32L * (t0 + q)] = ds;
+                }
+                dsum += ds;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) dattn[v] = fmaf(ds, hv[q][v], dattn[v]);
             }
-            dsum += ds;
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) dattn[v] = fmaf(ds, hv[q][v], dattn[v]);
         }
     }
 #pragma unroll

@@ -52,6 +52,55 @@ __global__ __launch_bounds__(256) void k(const bf16x8 *wsrc, float *out, long lo
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// MODE 4: the fused backward's MFMA phase: weights + accumulators in AGPRs (asm), 3 accumulators, 2 x 24 MFMAs, 16 fragment reads each
+template <int NW>
+__global__ __launch_bounds__(256) void k4(const bf16x8 *wsrc, float *out, long long *cyc, int iters) {
+    __shared__ __align__(16) __bf16 dab[2][8][512];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 2 * 8 * 512; i += 256) (&dab[0][0][0])[i] = (__bf16)(0.001f * (i % 97));
+    bf16x8 w[2][3][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[r][p][i] = wsrc[((r * 3 + p) * 8 + i) * 64 % 4096 + lane];
+    __syncthreads();
+    float s = 0;
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri) {
+            f32x16 a0, a1, a2;
+            constexpr int D = 3;
+            bf16x8 g1[D], g0[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { g1[i] = *reinterpret_cast<const bf16x8 *>(&dab[1][i][lane * 8]); g0[i] = *reinterpret_cast<const bf16x8 *>(&dab[0][i][lane * 8]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i == 0) {
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(a0) : "a"(w[ri][0][i]), "v"(g1[i % D]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(a1) : "a"(w[ri][1][i]), "v"(g1[i % D]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(a2) : "a"(w[ri][2][i]), "v"(g0[i % D]));
+                } else {
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(a0) : "a"(w[ri][0][i]), "v"(g1[i % D]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(a1) : "a"(w[ri][1][i]), "v"(g1[i % D]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(a2) : "a"(w[ri][2][i]), "v"(g0[i % D]));
+                }
+                if (i + D < 8) { g1[i % D] = *reinterpret_cast<const bf16x8 *>(&dab[1][i + D][lane * 8]); g0[i % D] = *reinterpret_cast<const bf16x8 *>(&dab[0][i + D][lane * 8]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0), "+a"(a1), "+a"(a2));
+            s += a0[0] + a1[3] + a2[7];
+        }
+        __syncthreads();
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + tid] = s;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 template <int MODE, int NW>
 void run(const char *name, const bf16x8 *w, float *out, long long *cyc, int grid) {
     const int iters = 200;
@@ -77,6 +126,13 @@ int main() {
         run<1, 16>("mfma + ds_read_b128/gap, 16 weight frags", w, out, cyc, grid);
         run<1, 48>("mfma + ds_read_b128/gap, 48 weight frags", w, out, cyc, grid);
         run<3, 16>("ds_read_b128 only (48 per step)", w, out, cyc, grid);
+        {
+            hipLaunchKernelGGL((k4<0>), dim3(grid), dim3(256), 0, 0, w, out, cyc, 200);
+            hipDeviceSynchronize();
+            std::vector<long long> h(grid);
+            hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
+            printf("%-46s grid %3d: %8.1f cycles / 48-MFMA step (wg 0), %7.1f per MFMA\n", "asm mfma, AGPR weights, 3 accs, 2x24 + settle", grid, (double)h[0] / 200, (double)h[0] / 200 / 48);
+        }
     }
     return 0;
 }
