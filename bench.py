@@ -64,7 +64,8 @@ CONFIGS = {
 # sources whose hash ties a recorded PMC traffic file to the kernels it was measured on
 KERNEL_SOURCES = {
     "fp32": ["nsd_lstm2_fwd48.hip", "nsd_lstm2_bwd48.hip", "nsd_common.h", "nsd_args.h", "nsd_prof.h"],
-    "bf16": ["nsd_scan.hip", "nsd_gemm_bf16.hip", "nsd_head_tm.hip", "nsd_seq.hip", "nsd_seq.h", "nsd_bf16.h", "nsd_common.h"],
+    "bf16": ["nsd_scan.hip", "nsd_scan2.hip", "nsd_scan_common.h", "nsd_gemm_bf16.hip", "nsd_head_tm.hip", "nsd_seq.hip", "nsd_seq.h", "nsd_bf16.h",
+             "nsd_common.h"],
 }
 
 
@@ -109,10 +110,22 @@ def algorithmic(cfg, B, T):
     out = {"flop_train": 3 * fwd_flop * B, "bytes_train": (2 * x_bytes + 2 * hc + K * 4) * B}
     if cfg["precision"] == "fp32":                          # one launch = both layers, all steps
         out.update(fwd_flop=fwd_flop * B, bwd_flop=2 * fwd_flop * B, fwd_bytes=(x_bytes + hc) * B, bwd_bytes=(x_bytes + hc) * B)
+    elif fused_scans(cfg):                                  # one scan launch = BOTH layers of a unidirectional 2-layer stack:
+        rec = 2 * T * 4 * H * H                             #   W_hh0, W_ih1, W_hh1 products (forward) / their transposes (backward)
+        out.update(fwd_flop=3 * rec * B, bwd_flop=3 * rec * B, fwd_bytes=2 * T * 2 * H * s_a * B, bwd_bytes=2 * T * 2 * H * s_a * B)
     else:                                                   # one scan launch = one layer (all directions): the recurrent product
         rec = 2 * T * D * 4 * H * H
         out.update(fwd_flop=rec * B, bwd_flop=rec * B, fwd_bytes=D * T * 2 * H * s_a * B, bwd_bytes=D * T * 2 * H * s_a * B)
     return out
+
+
+def fused_scans(cfg) -> bool:
+    """The sequence-batched path runs a unidirectional two-layer stack as ONE forward and ONE backward launch (nsd_scan2.hip)."""
+    return cfg["precision"] == "bf16" and not cfg["bidirectional"] and cfg["L"] == 2 and cfg["H"] in (64, 128, 256)
+
+
+def scan_kernel_names(cfg):
+    return ("scan2_fwd_kernel", "scan2_bwd_kernel") if fused_scans(cfg) else ("scan_fwd_kernel", "scan_bwd_kernel")
 
 
 class KernelTimer:
@@ -290,11 +303,12 @@ def main():
                        "take 71 us = 18 % of 8 TB/s for its algorithmic bytes): see `hbm` for the measured HBM view")
             else:
                 fwd_key, bwd_key = "scan_fwd", "scan_bwd"
-                names = {fwd_key: "scan_fwd_kernel", bwd_key: "scan_bwd_kernel"}
+                names = dict(zip((fwd_key, bwd_key), scan_kernel_names(cfg)))
                 bound = "mfma"
-                why = ("bf16 path: peak = 2.5 PFLOP/s dense bf16 MFMA; the scan kernels hold the recurrent weights in registers and "
-                       "are bound by the per-time-step exchange latency between the workgroups of a batch tile (T serial steps per "
-                       "launch), not by the matrix pipe or HBM: both fractions are printed")
+                why = ("bf16 path: peak = 2.5 PFLOP/s dense bf16 MFMA; the persistent scan kernels hold the recurrent weights in registers "
+                       "and are bound by the chain of one time step (flag poll -> exchange loads through the L2 -> cell -> LDS -> 48-64 "
+                       "MFMAs -> exchange stores -> drain -> flag; T + 1 serial steps per launch), not by the matrix pipe or HBM: both "
+                       "fractions are printed; a step of the fused backward scan is ~11 000 cycles of which the MFMAs need 1 540")
             dom = max((fwd_key, bwd_key), key=lambda n: kern_us[n])
             t_s = kern_us[dom] * 1e-6
             fl = alg["fwd_flop"] if dom == fwd_key else alg["bwd_flop"]

@@ -25,7 +25,7 @@ alg = bench.algorithmic(cfg, cfg["B"], cfg["T"])
 if cfg["precision"] == "fp32":
     ALG = {"lstm2_fwd48_kernel": alg["fwd_bytes"], "lstm2_bwd48_kernel": alg["bwd_bytes"]}
 else:
-    ALG = {"scan_fwd_kernel": alg["fwd_bytes"], "scan_bwd_kernel": alg["bwd_bytes"]}
+    ALG = dict(zip(bench.scan_kernel_names(cfg), (alg["fwd_bytes"], alg["bwd_bytes"])))
 
 
 def counters(sub, name):

@@ -52,4 +52,4 @@ for phase in ("infer", "fwd", "step"):
             step(i + 1)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print(f"{phase:6s} median {1e3 * np.median(ts):8.3f} ms  min {1e3 * min(ts):8.3f} ms   -> {B / np.median(ts):10.0f} trials/s", flush=True)
-print("status:", ops.seq_status(ws), " finite grads:", bool(torch.isfinite(g).all()), flush=True)
+print("status (code, groups on one XCD, groups spread over XCDs):", ops.seq_status(ws, detail=True), " finite grads:", bool(torch.isfinite(g).all()), flush=True)
