@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             // s == T the layer-0 product feeds nothing (its cell is guarded by do0)
             const bf16x8 *const ws3[3] = {w0, wx, w1};
             const bf16_t *const ts3[3] = {TA, TB, TC};
-            mfma_pipe<NT, KS, LDB, 3, 12>(ws3, ts3, col, hh, [&](const int st, const int nt) -> f32x16 & { return st == 0 ? acc0[nt] : acc1[nt]; });
+            if (!(NSD_SCAN_ABLATE & 256)) mfma_pipe<NT, KS, LDB, 3, 12>(ws3, ts3, col, hh, [&](const int st, const int nt) -> f32x16 & { return st == 0 ? acc0[nt] : acc1[nt]; });
         }
         stp.mark(2);
         // ---- the two cells; registers 4j..4j+3 = gates i,f,g,o of unit u0 + j for trial b0 + 32nt + col
