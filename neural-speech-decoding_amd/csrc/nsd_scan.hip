@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
     if (tid == 0 && me.p == 0) atomicAdd(a.status + (rv == 1 ? 2 : 3), 1);     // diagnostics: groups on one XCD / spread over several
-    const long ld = a.ld, tstride = (long)a.T * 32;            // rows between the 32-trial halves of a 64-trial tile (tile-major rows)
-    auto trow = [&](const int row) { return (row >> 5) * tstride + (row & 31); };
+    const long ld = a.ld;
+    constexpr long XB = (long)MG * H;                           // elements of a batch tile's block of the exchange ring
+    auto ring_of = [&](const int step) { return a.xch + (((long)(step & 1) * a.D + dir) * a.groups_total + a.group0 + me.group) * XB; };
     const int u0 = 8 * gt + 4 * hh;                            // first of this lane's 4 units
     const bool train = a.cs[0] != nullptr;
 
@@ -149,7 +150,6 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     load_xp(dir == 0 ? 0 : a.T - 1, xp);
     for (int s = 0; s < a.T; ++s) {
         const int t = dir == 0 ? s : a.T - 1 - s;
-        const int tp = dir == 0 ? t - 1 : t + 1;
         const int tnx = dir == 0 ? t + 1 : t - 1;              // next step's time index
         f32x16 acc[NT];
         if (s > 0) {
@@ -158,18 +158,20 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 s_abort = 1;                                    // (the wave still walks to the barrier below: the exit is uniform)
                 atomicExch(a.status, ST_FWD_TIMEOUT);
             }
-            // gather h_{t-1} of the whole tile (all H units): sc1 loads, 16 bytes each
-            const nsd_rsrc rh = make_rsrc(a.hs + seq_row(tp, b0, a.T) * ld + dir * H, (unsigned)(((NT - 1) * tstride + 32) * ld * 2));
+            // gather h_{t-1} of the whole tile (all H units) from the exchange ring: the block of a batch tile is laid out [gate tile
+            // = 4p + wave][nt][trial][8 units] -- every producer wave writes whole 128-byte lines with one store instruction, and a
+            // consumer's 16-byte pieces are linear in the block (piece e = (unit group) * MG + trial).  Exchanging through hs[t]
+            // itself (8-byte pieces of a line shared by 8 producer waves) makes every gather load wait for lines that are merged
+            // from partial writes beyond the L2.
+            const nsd_rsrc rh = make_rsrc(ring_of(s - 1), (unsigned)(XB * 2));
             constexpr int PIECES = MG * (H / 8) / 256;
             u32x4 pv[PIECES];
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i) {
-                const int e = tid + 256 * i, row = e / (H / 8), pc = e % (H / 8);
-                pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u} : ld_sc1_b128(rh, (unsigned)((trow(row) * ld + 8 * pc) * 2));
-            }
+            for (int i = 0; i < PIECES; ++i)
+                pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u} : ld_sc1_b128(rh, (unsigned)((tid + 256 * i) * 16));
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
-                const int e = tid + 256 * i, row = e / (H / 8), pc = e % (H / 8);
+                const int e = tid + 256 * i, pc = e / MG, row = e % MG;
                 *reinterpret_cast<u32x4 *>(Bt + row * LDB + 8 * pc) = pv[i];
             }
             __syncthreads();
@@ -200,14 +202,16 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 c[nt][j] = fmaf(gf[nt][j], c[nt][j], gi[nt][j] * gg[nt][j]);
                 hv[nt][j] = go[nt][j] * fast_tanh(c[nt][j]);
             }
-        // ---- publish h_t: write-through stores, drain, this wave's flag
+        // ---- publish h_t into the ring slot of this step, drain, this wave's flag; the row-major copy goes out behind the flag
         unsigned hw[NT][2];
+        {
+            bf16_t *slot = ring_of(s);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            hw[nt][0] = pack_bf16x2(hv[nt][0], hv[nt][1]);
-            hw[nt][1] = pack_bf16x2(hv[nt][2], hv[nt][3]);
-            const long row = seq_row(t, b0 + 32 * nt + col, a.T);
-            st_xchg_u64(same_l2, a.hs + row * ld + dir * H + u0, ((unsigned long long)hw[nt][1] << 32) | hw[nt][0]);
+            for (int nt = 0; nt < NT; ++nt) {
+                hw[nt][0] = pack_bf16x2(hv[nt][0], hv[nt][1]);
+                hw[nt][1] = pack_bf16x2(hv[nt][2], hv[nt][3]);
+                st_xchg_u64(same_l2, slot + ring_h_off(gt, nt, NT, col, hh), ((unsigned long long)hw[nt][1] << 32) | hw[nt][0]);
+            }
         }
         if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int b = b0 + 32 * nt + col;
             const long row = seq_row(t, b, a.T);
+            *reinterpret_cast<u32x2 *>(a.hs + row * ld + dir * H + u0) = u32x2{hw[nt][0], hw[nt][1]};
             if (a.lk) {
                 float m[4] = {1.f, 1.f, 1.f, 1.f};
                 if (a.rng.on && b < a.B) {

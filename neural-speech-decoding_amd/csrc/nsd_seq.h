@@ -61,6 +61,8 @@ struct ScanFwdArgs {
     const bf16_t *wf[NSD_SEQ_MAX_DIRS];      // [4H][H] recurrent weights, rows in accumulator-tile order
     const bf16_t *xproj[NSD_SEQ_MAX_DIRS];   // accumulator tiles, bias included
     bf16_t *hs;                              // [T*Bp][ld]
+    bf16_t *xch;                             // exchange ring [2][D][groups_total][MG*H] in gate-tile blocks (whole lines per producer wave)
+    int groups_total;
     bf16_t *lk;                              // [T*Bp][ld] linked output (h [+ res]) * multiplier, or null (== h: readers use hs)
     const bf16_t *res;                       // [T*Bp][ld] residual input added to h (extension; the layer's own input) or null
     bf16_t *cs[NSD_SEQ_MAX_DIRS];            // [T*Bp][H] or null (inference)

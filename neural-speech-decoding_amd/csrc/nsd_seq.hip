@@ -245,7 +245,7 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
                 a.cs[d] = train ? at<bf16_t>(c.ws, c.w.cs[l][d]) : nullptr;
                 a.ga[d] = train ? at<bf16_t>(c.ws, c.w.ga[l][d]) : nullptr;
             }
-            a.hs = at<bf16_t>(c.ws, c.w.hs[l]);
+            a.hs = at<bf16_t>(c.ws, c.w.hs[l]); a.xch = at<bf16_t>(c.ws, c.w.xch); a.groups_total = s.groups;
             a.lk = writes_lk(s, l, lstm_drop) ? at<bf16_t>(c.ws, c.w.lk[l]) : nullptr;
             a.res = (s.residual && l >= 1) ? in : nullptr;
             a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)l * s.D * s.groups + (long)g0 * s.D) * 128;   // disjoint per chunk
