@@ -314,7 +314,10 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
         for (int j = 0; j < 4; ++j) dpl[nt][j] = a.din ? 0.f : a.dpooled[(long)(b0 + 32 * nt + col) * ld + dir * H + u0 + j];
     const char *ring0 = reinterpret_cast<const char *>(a.xch) + ((long)dir * a.groups_total + a.group0 + me.group) * SLOT_BYTES;
     const long slot_stride = (long)a.D * a.groups_total * SLOT_BYTES;
-    auto blk_off = [&](const int cons, const int prod, const int nt, const int q) { return (unsigned)(((((cons * P + prod) * NT + nt) * 4 + q)) << 9); };
+    // block (consumer, producer, nt, consumer wave) of 64 lanes x 8 B; with NT == 2 the two halves share one block of 64 lanes x 16 B
+    auto blk_off = [&](const int cons, const int prod, const int nt, const int q) {
+        return NT == 2 ? (unsigned)((((cons * P + prod) * 4 + q)) << 10) : (unsigned)(((((cons * P + prod) * NT + nt) * 4 + q)) << 9);
+    };
 
     // saved activations and upstream gradient of a step: independent of the recurrence, requested one step ahead (after the
     // barrier of the step before: the MFMA phase follows)
@@ -381,18 +384,31 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             }
             // the partial sums the P members sent this wave at step s-1, added in member order
             const nsd_rsrc rr = make_rsrc(ring0 + (long)((s - 1) & 1) * slot_stride, (unsigned)SLOT_BYTES);
-            u32x2 v8[P][NT];
+            if constexpr (NT == 2) {                             // both 32-trial halves of a lane in ONE 16-byte piece (half the instructions)
+                u32x4 v16[P];
 #pragma unroll
-            for (int q = 0; q < P; ++q)
+                for (int q = 0; q < P; ++q) v16[q] = ld_sc1_b128(rr, blk_off(me.p, q, 0, wave) + 16u * lane);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) v8[q][nt] = ld_sc1_b64(rr, blk_off(me.p, q, nt, wave) + 8u * lane);
+                for (int q = 0; q < P; ++q)
 #pragma unroll
-            for (int q = 0; q < P; ++q)
+                    for (int nt = 0; nt < 2; ++nt) {
+                        drec[nt][0] += bf16_lo(v16[q][2 * nt]); drec[nt][1] += bf16_hi(v16[q][2 * nt]);
+                        drec[nt][2] += bf16_lo(v16[q][2 * nt + 1]); drec[nt][3] += bf16_hi(v16[q][2 * nt + 1]);
+                    }
+            } else {
+                u32x2 v8[P][NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    drec[nt][0] += bf16_lo(v8[q][nt][0]); drec[nt][1] += bf16_hi(v8[q][nt][0]);
-                    drec[nt][2] += bf16_lo(v8[q][nt][1]); drec[nt][3] += bf16_hi(v8[q][nt][1]);
-                }
+                for (int q = 0; q < P; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) v8[q][nt] = ld_sc1_b64(rr, blk_off(me.p, q, nt, wave) + 8u * lane);
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        drec[nt][0] += bf16_lo(v8[q][nt][0]); drec[nt][1] += bf16_hi(v8[q][nt][0]);
+                        drec[nt][2] += bf16_lo(v8[q][nt][1]); drec[nt][3] += bf16_hi(v8[q][nt][1]);
+                    }
+            }
         }
         // ---- the dh-dependent rest of the cell: da_t
         unsigned dw[NT][8];
@@ -435,12 +451,20 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) mfma_settle(acc[nt]);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                    if constexpr (NT == 2) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            st_ring_b64(same_l2, rw, blk_off(r, me.p, nt, q) + 8u * lane,
-                                        u32x2{pack_bf16x2(acc[nt][4 * q], acc[nt][4 * q + 1]), pack_bf16x2(acc[nt][4 * q + 2], acc[nt][4 * q + 3])});
+                            st_ring_b128(same_l2, rw, blk_off(r, me.p, 0, q) + 16u * lane,
+                                         u32x4{pack_bf16x2(acc[0][4 * q], acc[0][4 * q + 1]), pack_bf16x2(acc[0][4 * q + 2], acc[0][4 * q + 3]),
+                                               pack_bf16x2(acc[1][4 * q], acc[1][4 * q + 1]), pack_bf16x2(acc[1][4 * q + 2], acc[1][4 * q + 3])});
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                st_ring_b64(same_l2, rw, blk_off(r, me.p, nt, q) + 8u * lane,
+                                            u32x2{pack_bf16x2(acc[nt][4 * q], acc[nt][4 * q + 1]), pack_bf16x2(acc[nt][4 * q + 2], acc[nt][4 * q + 3])});
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
