@@ -258,7 +258,10 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // backward scan
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int H, int NT>
+// TOP: the layer under the head (upstream term from alpha / dscore / dpooled) or a lower layer (from din).  A template parameter,
+// not a run-time branch: with the branch inside load_saved hipcc merges the two arms through copies and guards them with
+// vmcnt(2) right behind the loads -- a full HBM latency per 32-trial half and step (11 500 of 20 000 cycles at H = 512).
+template <int H, int NT, bool TOP>
 __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     // The recurrent term dh_rec = W_hh^T da_{t+1} is exchanged as a reduce-scatter of bf16 partial sums (design and ring layout:
     // nsd_scan2.hip, "backward"): the workgroup multiplies its OWN 128 gate columns of da (from LDS, K = 128) into partial dh
@@ -307,11 +310,11 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     // loop invariants of the top layer: d out_t = alpha_t * dpooled + dscore_t * attn_w
     float dpl[NT][4], aw[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) aw[j] = a.din ? 0.f : a.attn_w[dir * H + u0 + j];
+    for (int j = 0; j < 4; ++j) aw[j] = TOP ? a.attn_w[dir * H + u0 + j] : 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dpl[nt][j] = a.din ? 0.f : a.dpooled[(long)(b0 + 32 * nt + col) * ld + dir * H + u0 + j];
+        for (int j = 0; j < 4; ++j) dpl[nt][j] = TOP ? a.dpooled[(long)(b0 + 32 * nt + col) * ld + dir * H + u0 + j] : 0.f;
     const char *ring0 = reinterpret_cast<const char *>(a.xch) + ((long)dir * a.groups_total + a.group0 + me.group) * SLOT_BYTES;
     const long slot_stride = (long)a.D * a.groups_total * SLOT_BYTES;
     // block (consumer, producer, nt, consumer wave) of 64 lanes x 8 B; with NT == 2 the two halves share one block of 64 lanes x 16 B
@@ -341,12 +344,14 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             v.cq[nt] = *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk, lane));
             const bool first = dir == 0 ? t == 0 : t == T - 1;
             v.cpq[nt] = first ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk + 4 * (tprev - t), lane));
-            if (a.din) { v.dv[nt] = *reinterpret_cast<const f32x4 *>(a.din + row * ld + dir * H + u0); v.al[nt] = 0.f; v.ds[nt] = 0.f; }
-            else { v.dv[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; v.al[nt] = a.alpha[row]; v.ds[nt] = a.dscore[row]; }
+            if constexpr (TOP) { v.al[nt] = a.alpha[row]; v.ds[nt] = a.dscore[row]; }
+            else v.dv[nt] = *reinterpret_cast<const f32x4 *>(a.din + row * ld + dir * H + u0);
         }
     };
     Saved sv;
     load_saved(0, sv);
+    Stamps stp;
+    stp.start();
     for (int s = 0; s < T; ++s) {
         const int t = t_of(s);
         // ---- ahead of the exchange: the upstream term and everything of the cell that does not need dh
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             const int b = b0 + 32 * nt + col;
             const long row = seq_row(t, b, T);
             cell_factors(sv.gq[nt][0], sv.gq[nt][1], sv.cq[nt], sv.cpq[nt], fc[nt]);
-            if (a.din) {
+            if constexpr (!TOP) {
                 float m[4] = {1.f, 1.f, 1.f, 1.f};
                 if (a.rng.on && b < a.B) {
                     const uint64_t base = (((uint64_t)a.layer * a.B + b) * T + t) * (uint64_t)ld + (uint64_t)(dir * H + u0);
@@ -372,6 +377,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             }
             if (a.dres) *reinterpret_cast<f32x4 *>(a.dres + row * ld + dir * H + u0) = f32x4{dup[nt][0], dup[nt][1], dup[nt][2], dup[nt][3]};
         }
+        stp.mark(7);
         float drec[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -382,6 +388,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                 s_abort = 1;
                 atomicExch(a.status, ST_BWD_TIMEOUT);
             }
+            stp.mark(0);
             // the partial sums the P members sent this wave at step s-1, added in member order
             const nsd_rsrc rr = make_rsrc(ring0 + (long)((s - 1) & 1) * slot_stride, (unsigned)SLOT_BYTES);
             if constexpr (NT == 2) {                             // both 32-trial halves of a lane in ONE 16-byte piece (half the instructions)
@@ -410,6 +417,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                     }
             }
         }
+        stp.mark(1);
         // ---- the dh-dependent rest of the cell: da_t
         unsigned dw[NT][8];
 #pragma unroll
@@ -419,6 +427,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             for (int j = 0; j < 4; ++j) dh[j] = dup[nt][j] + drec[nt][j];
             cell_apply(fc[nt], dh, dc[nt], dbs, dw[nt]);
         }
+        stp.mark(2);
         if (s + 1 < T) {                                        // (after the last step nobody reads a partial sum)
             const int par = s & 1;
 #pragma unroll
@@ -428,6 +437,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                     *reinterpret_cast<u32x4 *>(&dab[par][2 * wave + h][nt][lane * 8]) = u32x4{dw[nt][4 * h], dw[nt][4 * h + 1], dw[nt][4 * h + 2], dw[nt][4 * h + 3]};
             __syncthreads();
             if (s_abort) break;
+            stp.mark(3);
             load_saved(s + 1, sv);
             __builtin_amdgcn_sched_barrier(0);
             if (has_rows) {
@@ -468,8 +478,10 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            stp.mark(4);
             if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
+            stp.mark(6);
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- row-major da_t for the weight-gradient / input-gradient GEMMs: behind the flag
@@ -480,6 +492,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             *reinterpret_cast<u32x4 *>(d + 8) = u32x4{dw[nt][4], dw[nt][5], dw[nt][6], dw[nt][7]};
         }
     }
+    stp.store(a.status, blockIdx.x == 0 && tid == 0);
     // ---- bias gradients of this batch tile: sum over the 32 trials of each half-wave, one row of dbp per (direction, tile)
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -504,8 +517,13 @@ int launch_fwd_h(const ScanFwdArgs &a, int MG, const dim3 grid, hipStream_t st) 
 }
 template <int H>
 int launch_bwd_h(const ScanBwdArgs &a, int MG, const dim3 grid, hipStream_t st) {
-    if (MG == 32) hipLaunchKernelGGL((scan_bwd_kernel<H, 1>), grid, dim3(256), 0, st, a);
-    else          hipLaunchKernelGGL((scan_bwd_kernel<H, 2>), grid, dim3(256), 0, st, a);
+    if (a.din == nullptr) {
+        if (MG == 32) hipLaunchKernelGGL((scan_bwd_kernel<H, 1, true>), grid, dim3(256), 0, st, a);
+        else          hipLaunchKernelGGL((scan_bwd_kernel<H, 2, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (MG == 32) hipLaunchKernelGGL((scan_bwd_kernel<H, 1, false>), grid, dim3(256), 0, st, a);
+        else          hipLaunchKernelGGL((scan_bwd_kernel<H, 2, false>), grid, dim3(256), 0, st, a);
+    }
     NSD_CHECK_LAUNCH("scan_bwd_kernel");
     return NSD_OK;
 }

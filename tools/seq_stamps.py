@@ -34,3 +34,21 @@ tot = acc.sum()
 print(f"backward scan: total/step {tot / (T + 1):.0f}")
 for n, v in zip(["poll", "partial-sum loads + add", "cells (dh-dependent part)", "own da -> LDS + barrier", "MFMA (48) + saved-set request", "convert + ring stores", "drain + flag", "row-major stores + cell factors of the next step"], acc):
     print(f"   {n:50s} {v / (T + 1):9.1f}  ({100.0 * v / max(tot, 1):5.1f} %)")
+
+# ---- single-layer kernels (cfg5 shape: H = 512, bidirectional, 64-trial tiles): backward scan of the LAST launch (layer 0)
+if "--cfg5" in sys.argv:
+    spec, B, T = ops.ModelSpec(C=64, H=512, L=1 if "--top" in sys.argv else 2, K=5, D=2), 512, 1000     # --top: a one-layer model (the top layer's upstream term: alpha / dscore instead of din)
+    flat = (torch.rand(spec.param_count, device=dev) * 2 - 1) / 22
+    x = 2.7 * torch.randn(B, T, 64, device=dev)
+    y = torch.randint(0, 5, (B,), device=dev, dtype=torch.int32)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    g = torch.zeros(spec.param_count, device=dev)
+    for _ in range(2):
+        ops.seq_train_fwd(spec, flat, x, y, ws, rng=dict(seed=1, base_stream=4, p_lstm=0.6, p_head=0.6))
+        ops.seq_train_bwd(spec, flat, ws, B, T, rng=dict(seed=1, base_stream=4, p_lstm=0.6, p_head=0.6), grads=g)
+        torch.cuda.synchronize()
+    acc = ws[:128].cpu().numpy().view(np.int32)[4:20].view(np.uint64)
+    tot = acc.sum()
+    print(f"cfg5 backward scan (layer 0, workgroup 0 wave 0): total/step {tot / T:.0f}")
+    for n, v in zip(["poll", "partial-sum loads + add", "cell (dh-dependent part)", "own da -> LDS + barrier", "saved-set request + 64 MFMAs + convert + ring stores", "-", "drain + flag", "row-major stores + upstream term + cell factors of the next step"], acc):
+        print(f"   {n:66s} {v / T:9.1f}  ({100.0 * v / max(tot, 1):5.1f} %)")
