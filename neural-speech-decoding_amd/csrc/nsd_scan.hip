@@ -376,6 +376,9 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                 for (int j = 0; j < 4; ++j) dup[nt][j] = fmaf(sv.al[nt], dpl[nt][j], sv.ds[nt] * aw[j]);
             }
             if (a.dres) *reinterpret_cast<f32x4 *>(a.dres + row * ld + dir * H + u0) = f32x4{dup[nt][0], dup[nt][1], dup[nt][2], dup[nt][3]};
+            pin(fc[nt]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pin(dup[nt][j]);
         }
         stp.mark(7);
         float drec[NT][4];

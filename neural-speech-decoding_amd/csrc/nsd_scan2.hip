@@ -366,6 +366,9 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) dup1[nt][j] = do1 ? fmaf(sv.al[nt], dpl[nt][j], sv.ds[nt] * aw[j]) : 0.f;
             drop_mult4(a.rng, a.rng.on != 0 && do0, 0, a.B, T, b0 + 32 * nt + col, t0, H, u0, m0[nt]);
+            pin(f1[nt]); pin(f0[nt]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pin(dup1[nt][j]); pin(m0[nt][j]); }
         }
         stp.mark(7);
         float drec1[NT][4], dinx[NT][4], drec0[NT][4];

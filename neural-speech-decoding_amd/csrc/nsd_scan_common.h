@@ -302,6 +302,14 @@ __device__ __forceinline__ void cell_factors(const u32x4 gq0, const u32x4 gq1, c
         f.fg[j] = fg;
     }
 }
+// The factors are computed AHEAD of the exchange on purpose.  Where their only use sits inside a conditional block behind the
+// poll, the optimizer sinks the whole computation (tanh, the products, the dropout stream) into that block -- onto the critical
+// path (1 100 of the fused backward's 11 100 cycles).  An empty asm statement that "modifies" a value pins it where it is.
+__device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(CellFac &f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { pin(f.A[j]); pin(f.Fi[j]); pin(f.Ff[j]); pin(f.Fg[j]); pin(f.Fo[j]); pin(f.fg[j]); }
+}
 // ... and what does: da (16 values, unit-major, packed), the carried dc, the bias-gradient sums
 __device__ __forceinline__ void cell_apply(const CellFac &f, const float (&dh)[4], float (&dc)[4], float (&dbs)[16], unsigned (&dw)[8]) {
 #pragma unroll
