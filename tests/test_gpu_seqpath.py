@@ -518,3 +518,59 @@ def test_bidirectional_training_with_dropout_streams_vs_torch(nsd, dev):
         got = g[offs[k]:offs[k] + ref.size]
         tol = 1e-4 if k == "attn.bias" else SEQ_GRAD_RTOL * max(np.abs(ref).max(), 1e-6) + 1e-6
         assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+# ---- 64-trial batch tiles (the NT = 2 instantiations) --------------------------------------------------------------------------
+# The path switches to 64-trial tiles only when 32-trial tiles do not fit the machine at once (B > 32 * CUs / (P * D)): cfg5's
+# H = 512 bidirectional at B > 256, H = 256 unidirectional at B > 1024.  Those kernels have code of their own (two accumulator
+# sets per lane, 16-byte partial-sum pieces, tile halves T * 32 rows apart), so they get parity cases of their own at few steps.
+def test_seq_64_trial_tiles_unidirectional_vs_oracle(nsd, dev):
+    from nsd_amd import ops
+    H, L, K, B, T = 256, 2, 5, 1030, 3                      # 33 tiles of 32 > 32 resident groups -> 17 tiles of 64, layer-by-layer scans
+    d = orc.Dims(C=8, H=H, L=L, K=K)
+    spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+    assert spec.dims(B, T) is not None
+    st = synth_params(8, H, L, K, seed=77)
+    x, y = synth_x(B, T, seed=5), synth_labels(B, K, seed=5)
+    flat_np = orc.flatten_state(st, d)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, d)
+    flat = torch.from_numpy(flat_np).to(dev)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    logits = ops.seq_train_fwd(spec, flat, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), ws)
+    g = ops.seq_train_bwd(spec, flat, ws, B, T)
+    st_code, one_xcd, spread = ops.seq_status(ws, detail=True)
+    assert st_code == 0 and one_xcd + spread == 2 * 2 * 17, (st_code, one_xcd, spread)     # 2 layers x (forward + backward) x 17 tiles
+    assert np.abs(logits.cpu().numpy() - fw["logits"]).max() < SEQ_LOGIT_TOL
+    assert abs(float(ops.seq_loss_sum(spec, ws, B, T).item()) / B - loss_ref) < 2e-2
+    _grad_check(g.cpu().numpy(), g_ref, d)
+
+
+def test_seq_64_trial_tiles_bidirectional_h512_vs_torch(nsd, dev):
+    """cfg5's kernels (H = 512, two directions, 64-trial tiles, 16 workgroups per group) against the torch composition."""
+    from nsd_amd import ops
+    from oracle.torch_ref import TorchRefEEG
+    C, H, L, K, B, T = 64, 512, 2, 5, 264, 4               # 9 tiles of 32 > 8 resident groups per direction -> 5 tiles of 64
+    st = synth_params(C, H, L, K, seed=91, D=2)
+    spec = ops.ModelSpec(C=C, H=H, L=L, K=K, D=2)
+    flat = _flat_from_state(spec, st, dev)
+    x, y = synth_x(B, T, C=C, seed=17), synth_labels(B, K, seed=17)
+    m = TorchRefEEG(C, H, L, K, bidirectional=True).eval()
+    m.load_reference_state({k: torch.from_numpy(v) for k, v in st.items()})
+    lg_ref = m(torch.from_numpy(x))
+    torch.nn.functional.cross_entropy(lg_ref, torch.from_numpy(y.astype(np.int64))).backward()
+    g_ref = m.reference_named_grads()
+    ws = ops.seq_workspace(spec, B, T, dev)
+    logits = ops.seq_train_fwd(spec, flat, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), ws)
+    g = ops.seq_train_bwd(spec, flat, ws, B, T).cpu().numpy()
+    st_code, one_xcd, spread = ops.seq_status(ws, detail=True)
+    assert st_code == 0 and one_xcd + spread == 2 * 2 * 2 * 5, (st_code, one_xcd, spread)  # layers x passes x directions x tiles
+    assert np.abs(logits.cpu().numpy() - lg_ref.detach().numpy()).max() < SEQ_LOGIT_TOL
+    offs = spec.offsets()
+    for k in spec.names():
+        ref = g_ref[k].numpy().ravel()
+        got = g[offs[k]:offs[k] + ref.size]
+        # fc.* see the eval-mode RReLU kink: a pre-activation within the bf16 error of zero takes the other slope (a handful of
+        # the 264 x 32 units), which moves single elements of these two tensors by more than the smooth error: twice the bound
+        rt = 2 * SEQ_GRAD_RTOL if k.startswith("fc.") else SEQ_GRAD_RTOL
+        tol = 1e-4 if k == "attn.bias" else rt * max(np.abs(ref).max(), 1e-6) + 1e-6
+        assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())
