@@ -18,7 +18,7 @@ constexpr int ST2_FWD_TIMEOUT = 1, ST2_BWD_TIMEOUT = 2;
 
 template <int H, int NT>
 __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
-    constexpr int KS = H / 16, P = H / 32, MG = 32 * NT, LDB = H + 8, G = 4 * H;
+    constexpr int KS = H / 16, P = H / 32, MG = 32 * NT, LDB = H + 8;
     constexpr int PIECES = MG * (H / 8) / 256;
     // [buffer s & 1][h0_{s-1} | in1_{s-1} (multiplied h0) | h1_{s-2}][trial][unit]: one barrier per step (see nsd_scan.hip)
     __shared__ __align__(16) bf16_t tiles[2][3][MG * LDB];
@@ -39,9 +39,16 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             w1[ks] = *reinterpret_cast<const bf16x8 *>(a.wf1 + ro + 16 * ks);
         }
     }
-    float bias1[16];
+    float bias1[16], bias0[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bias1[r] = a.bsum1[32 * gt + mfma32_row(r, lane)];
+    for (int r = 0; r < 16; ++r) { bias1[r] = a.bsum1[32 * gt + mfma32_row(r, lane)]; bias0[r] = a.bsum0[32 * gt + mfma32_row(r, lane)]; }
+    // the layer-0 input projection rides in the scan: K = CP (the channels, padded to 16) is 1 to 4 k-steps
+    const int CP = a.CP, ks0 = CP >> 4;
+    bf16x8 wx0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        wx0[k] = *reinterpret_cast<const bf16x8 *>(a.wx0 + (long)(32 * gt + col) * CP + 16 * (k < ks0 ? k : 0) + 8 * hh);
+    }
     float c0[NT][4], c1[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -62,20 +69,25 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     const bool train = a.cs0 != nullptr, masked = a.lk0 != nullptr;
     const int T = a.T;
 
-    // layer-0 input projection tiles: the one of step s+1 is requested AFTER the gather of step s has landed (vector memory
-    // returns in issue order: an HBM read issued ahead of the gather would put its latency on every step's critical path) and
-    // AFTER the tile of step s has been unpacked into the accumulators -- requested before, hipcc guards the unpack with
-    // vmcnt(0) and the wave sits out the whole HBM latency every step (2 300 of 9 200 cycles)
-    u32x4 xp[NT][2];
-    auto load_xp = [&](const int t, u32x4 (&dst)[NT][2]) {
+    // x_t of the tile as MFMA B fragments (lane (trial, hh): channels 16k + 8hh .. + 7: the wave reads one contiguous KB of xbf per
+    // k-step).  The fragments of step s+1 are requested AFTER the gather of step s has landed (vector memory returns in issue
+    // order: an HBM read issued ahead of the gather would put its latency on the step) and AFTER the MFMAs that read the current
+    // ones have been issued.
+    bf16x8 xf[NT][4];
+    auto load_x = [&](const int t) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const bf16_t *src = a.xproj0 + ((((long)((b0 >> 5) + nt) * T + t) * (G >> 5) + gt) * 64 + lane) * 16;
-            dst[nt][0] = *reinterpret_cast<const u32x4 *>(src);
-            dst[nt][1] = *reinterpret_cast<const u32x4 *>(src + 8);
+            const bf16_t *src = a.xbf + seq_row(t, b0 + 32 * nt + col, T) * CP + 8 * hh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < ks0) xf[nt][k] = *reinterpret_cast<const bf16x8 *>(src + 16 * k);
         }
     };
-    load_xp(0, xp);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xf[nt][k] = wx0[0];        // (defined values in the unused k-steps)
+    load_x(0);
     Stamps stp;
     stp.start();
     for (int s = 0; s <= T; ++s) {
@@ -123,13 +135,20 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         }
         f32x16 acc0[NT], acc1[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc0[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[nt][r] = bias1[r];
+            for (int r = 0; r < 16; ++r) { acc0[nt][r] = bias0[r]; acc1[nt][r] = bias1[r]; }
+        if (do0) {
+            mfma_lead_in();
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < ks0) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mfma_acc_a(acc0[nt], wx0[k], xf[nt][k]);
+                }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < T) load_xp(s + 1, xp);
+        if (s + 1 < T) load_x(s + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (s >= 1) {
             // all three products every step, branch-free: at s == 1 the h1 tile is the zero state the buffers start with, at

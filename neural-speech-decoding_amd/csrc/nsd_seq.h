@@ -96,7 +96,10 @@ struct ScanBwdArgs {
 struct Scan2FwdArgs {
     const bf16_t *wf0, *wx1, *wf1;           // [4H][H] each, rows in accumulator-tile order: W_hh0, W_ih1, W_hh1
     const float *bsum1;                      // [4H] b_ih1 + b_hh1, tile order
-    const bf16_t *xproj0;                    // layer-0 input projection tiles (bias included)
+    const bf16_t *wx0;                       // [4H][CP] W_ih0, rows in accumulator-tile order: the layer-0 projection rides in the scan (K = CP <= 64)
+    const float *bsum0;                      // [4H] b_ih0 + b_hh0, tile order
+    const bf16_t *xbf;                       // [T*Bp][CP] the windows as bf16 (tile-major rows)
+    int CP;
     bf16_t *hs0, *lk0, *hs1;                 // [T*Bp][H]; lk0 = h0 * multiplier or null
     bf16_t *xch;                             // exchange ring [2][groups_total][3][MG*H]
     int groups_total;

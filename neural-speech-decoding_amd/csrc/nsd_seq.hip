@@ -48,7 +48,7 @@ int derive(const nsd_dims *d, uint32_t flags, SeqDims *o) {
     s.Bp = (int)align_up(s.B > 0 ? s.B : 1, s.MG);
     s.groups = s.Bp / s.MG;
     // two unidirectional layers: one launch advances both, layer 1 a step behind layer 0 (nsd_scan2.hip)
-    s.fused2 = (s.D == 1 && s.L == 2 && !s.residual && !(flags & NSD_FLAG_NO_FUSED_LAYERS) && nsd_scan2_supported(s.H, s.MG)) ? 1 : 0;
+    s.fused2 = (s.D == 1 && s.L == 2 && !s.residual && !(flags & NSD_FLAG_NO_FUSED_LAYERS) && s.CP <= 64 && nsd_scan2_supported(s.H, s.MG)) ? 1 : 0;
     *o = s;
     return NSD_OK;
 }
@@ -189,20 +189,13 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
     delete prep;
     if (s.fused2) {
         const bool lstm_drop = train && rng.on && rng.thr_lstm != 0;
-        {
-            GemmArgs g;
-            memset(&g, 0, sizeof(g));
-            g.A = at<bf16_t>(c.ws, c.w.wx[0][0]); g.lda = s.CP; g.B = at<bf16_t>(c.ws, c.w.xbf); g.ldb = s.CP;
-            g.C = at<bf16_t>(c.ws, c.w.xproj[0]); g.bias = at<float>(c.ws, c.w.bsum[0][0]);
-            g.M = G; g.N = (int)R; g.K = s.CP; g.splits = 1; g.epi = GEMM_EPI_TILE_BF16;
-            ProfScope ps(PK_GEMM_XPROJ, c.st);
-            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
-        }
+        // (no projection GEMM: W_ih0 . x_t is CP / 16 <= 4 MFMAs per step inside the scan -- one launch and a 1-GB tile round trip less)
         for (int g0 = 0; g0 < s.groups; g0 += c.cap) {
             Scan2FwdArgs a;
             memset(&a, 0, sizeof(a));
             a.wf0 = at<bf16_t>(c.ws, c.w.wf[0][0]); a.wx1 = at<bf16_t>(c.ws, c.w.wx[1][0]); a.wf1 = at<bf16_t>(c.ws, c.w.wf[1][0]);
-            a.bsum1 = at<float>(c.ws, c.w.bsum[1][0]); a.xproj0 = at<bf16_t>(c.ws, c.w.xproj[0]);
+            a.bsum1 = at<float>(c.ws, c.w.bsum[1][0]);
+            a.wx0 = at<bf16_t>(c.ws, c.w.wx[0][0]); a.bsum0 = at<float>(c.ws, c.w.bsum[0][0]); a.xbf = at<bf16_t>(c.ws, c.w.xbf); a.CP = s.CP;
             a.hs0 = at<bf16_t>(c.ws, c.w.hs[0]); a.lk0 = lstm_drop ? at<bf16_t>(c.ws, c.w.lk[0]) : nullptr; a.hs1 = at<bf16_t>(c.ws, c.w.hs[1]);
             a.xch = at<bf16_t>(c.ws, c.w.xch); a.groups_total = s.groups;
             if (train) {

@@ -108,7 +108,10 @@ def _flat(state, d, dev):
     return torch.from_numpy(orc.flatten_state(state, d)).to(dev)
 
 
-def _grad_check(got, ref, d, rtol=SEQ_GRAD_RTOL):
+def _grad_check(got, ref, d, rtol=SEQ_GRAD_RTOL, fc_rtol=None):
+    """fc_rtol: bound for fc.* where given.  Those tensors see the eval-mode RReLU kink directly: a pre-activation within the bf16
+    error of zero takes the other slope, which moves single elements by more than the smooth error (most visibly the
+    cancelling sums of fc.0.bias)."""
     g, r = orc.unflatten(got, d), orc.unflatten(ref, d)
     worst = {}
     for k in orc.param_names(d):
@@ -118,7 +121,8 @@ def _grad_check(got, ref, d, rtol=SEQ_GRAD_RTOL):
         if k == "attn.bias":
             assert err < 1e-4, (k, err)                 # analytically zero
         else:
-            assert err <= rtol * scale + 1e-6, (k, err, scale)
+            rt = fc_rtol if (fc_rtol is not None and k.startswith("fc.")) else rtol
+            assert err <= rt * scale + 1e-6, (k, err, scale)
     return worst
 
 
@@ -574,3 +578,27 @@ def test_seq_64_trial_tiles_bidirectional_h512_vs_torch(nsd, dev):
         rt = 2 * SEQ_GRAD_RTOL if k.startswith("fc.") else SEQ_GRAD_RTOL
         tol = 1e-4 if k == "attn.bias" else rt * max(np.abs(ref).max(), 1e-6) + 1e-6
         assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("C", [40, 64])
+def test_fused_stack_projects_wide_inputs_inside_the_scan(nsd, dev, C):
+    """The two-layer launch computes W_ih0 . x_t itself (1 to 4 k-steps of 16 channels): C = 40 pads to 48 (3 k-steps), C = 64
+    uses all 4."""
+    from nsd_amd import ops
+    H, L, K, B, T = 64, 2, 3, 200, 7                       # (a large batch: single RReLU-kink flips of the head move a small batch's
+    d = orc.Dims(C=C, H=H, L=L, K=K)                         #  gradients by several percent -- see the residual test)
+    spec = ops.ModelSpec(C=C, H=H, L=L, K=K)
+    st = synth_params(C, H, L, K, seed=1000 + C)
+    x, y = synth_x(B, T, C=C, seed=C), synth_labels(B, K, seed=C)
+    flat_np = orc.flatten_state(st, d)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, d)
+    flat = torch.from_numpy(flat_np).to(dev)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    logits = ops.seq_train_fwd(spec, flat, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), ws)
+    g = ops.seq_train_bwd(spec, flat, ws, B, T)
+    st_code, one_xcd, spread = ops.seq_status(ws, detail=True)
+    assert st_code == 0 and one_xcd + spread == 2 * 7, (st_code, one_xcd, spread)          # ONE forward + ONE backward launch, 7 tiles each
+    assert np.abs(logits.cpu().numpy() - fw["logits"]).max() < SEQ_LOGIT_TOL
+    _grad_check(g.cpu().numpy(), g_ref, d, fc_rtol=2 * SEQ_GRAD_RTOL)
+    lg, _ = ops.seq_infer(spec, flat, torch.from_numpy(x).to(dev))
+    assert np.abs(lg.cpu().numpy() - fw["logits"]).max() < SEQ_LOGIT_TOL
