@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void seq_xbf_kernel(const float *x, bf16_t *xb
 // ---------------------------------------------------------------------------------------------------------------------------
 // forward scan
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int H, int NT>
+// INPROJ: the input projection is computed in the scan from xbf (layer 0, CP <= 64) instead of read as accumulator tiles
+template <int H, int NT, bool INPROJ>
 __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     constexpr int KS = H / 16, P = H / 32, MG = 32 * NT, LDB = H + 8, G = 4 * H;
     // h_{t-1} of the batch tile, [trial][unit]; two buffers alternate by step so that ONE barrier per step is enough (a wave
@@ -136,18 +137,43 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     const int u0 = 8 * gt + 4 * hh;                            // first of this lane's 4 units
     const bool train = a.cs[0] != nullptr;
 
-    // input projection tiles: the one of step s+1 is requested AFTER the tile gather of step s has landed (vector memory
-    // returns in issue order: an HBM read issued ahead of the gather would put its latency on every step's critical path)
+    // input projection: accumulator tiles from the hoisted GEMM, or (INPROJ) x_t of the tile as MFMA B fragments (lane (trial,
+    // hh): channels 16k + 8hh .. + 7).  Either way the data of step s+1 is requested AFTER the tile gather of step s has landed
+    // (vector memory returns in issue order: an HBM read issued ahead of the gather would put its latency on every step's
+    // critical path) and after the data of step s has been consumed.
     u32x4 xp[NT][2];
-    auto load_xp = [&](const int t, u32x4 (&dst)[NT][2]) {
+    bf16x8 xf[NT][4], wx0[4];
+    float bias0[16];
+    const int CP = INPROJ ? a.CP : 16, ks0 = CP >> 4;
+    auto load_xp = [&](const int t) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const bf16_t *src = a.xproj[dir] + ((((long)((b0 >> 5) + nt) * a.T + t) * (G >> 5) + gt) * 64 + lane) * 16;
-            dst[nt][0] = *reinterpret_cast<const u32x4 *>(src);
-            dst[nt][1] = *reinterpret_cast<const u32x4 *>(src + 8);
+            if constexpr (INPROJ) {
+                const bf16_t *src = a.xbf + seq_row(t, b0 + 32 * nt + col, a.T) * CP + 8 * hh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < ks0) xf[nt][k] = *reinterpret_cast<const bf16x8 *>(src + 16 * k);
+            } else {
+                const bf16_t *src = a.xproj[dir] + ((((long)((b0 >> 5) + nt) * a.T + t) * (G >> 5) + gt) * 64 + lane) * 16;
+                xp[nt][0] = *reinterpret_cast<const u32x4 *>(src);
+                xp[nt][1] = *reinterpret_cast<const u32x4 *>(src + 8);
+            }
         }
     };
-    load_xp(dir == 0 ? 0 : a.T - 1, xp);
+    if constexpr (INPROJ) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                           // (k-steps beyond the padded channel count: zero weights)
+            const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(a.wx0[dir] + (long)(32 * gt + col) * CP + 16 * (k < ks0 ? k : 0) + 8 * hh);
+            wx0[k] = k < ks0 ? wv : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias0[r] = a.bsum0[dir][32 * gt + mfma32_row(r, lane)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xf[nt][k] = wx0[0];    // (defined values in the unused k-steps)
+    }
+    load_xp(dir == 0 ? 0 : a.T - 1);
     for (int s = 0; s < a.T; ++s) {
         const int t = dir == 0 ? s : a.T - 1 - s;
         const int tnx = dir == 0 ? t + 1 : t - 1;              // next step's time index
@@ -179,10 +205,27 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
         }
         // the next step's projection tile is requested only AFTER this step's has been unpacked: requested before, hipcc guards
         // the unpack with vmcnt(0) and the wave sits out the HBM latency of the new request every step
+        if constexpr (INPROJ) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = bias0[r];
+            // All four k-steps, unconditionally (zero weights beyond the channel count), and settled before any control flow: the
+            // accumulators of asm MFMAs are ordinary values to hipcc, and around a run-time branch it copies them (AGPR -> VGPR) at
+            // once -- reading a result the matrix pipe has not written yet (found as wrong logits with 64-trial tiles).
+            mfma_lead_in();
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mfma_acc_v(acc[nt], wx0[k], xf[nt][k]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mfma_settle(acc[nt]);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = unpack_tile(xp[nt][0], xp[nt][1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < a.T) load_xp(tnx, xp);
+        if (s + 1 < a.T) load_xp(tnx);
         __builtin_amdgcn_sched_barrier(0);
         if (s > 0) {
             const bf16x8 *const ws1[1] = {w};
@@ -513,8 +556,13 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 
 template <int H>
 int launch_fwd_h(const ScanFwdArgs &a, int MG, const dim3 grid, hipStream_t st) {
-    if (MG == 32) hipLaunchKernelGGL((scan_fwd_kernel<H, 1>), grid, dim3(256), 0, st, a);
-    else          hipLaunchKernelGGL((scan_fwd_kernel<H, 2>), grid, dim3(256), 0, st, a);
+    if (a.wx0[0] != nullptr) {
+        if (MG == 32) hipLaunchKernelGGL((scan_fwd_kernel<H, 1, true>), grid, dim3(256), 0, st, a);
+        else          hipLaunchKernelGGL((scan_fwd_kernel<H, 2, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (MG == 32) hipLaunchKernelGGL((scan_fwd_kernel<H, 1, false>), grid, dim3(256), 0, st, a);
+        else          hipLaunchKernelGGL((scan_fwd_kernel<H, 2, false>), grid, dim3(256), 0, st, a);
+    }
     NSD_CHECK_LAUNCH("scan_fwd_kernel");
     return NSD_OK;
 }

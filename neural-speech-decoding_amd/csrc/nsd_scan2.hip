@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     bf16x8 wx0[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        wx0[k] = *reinterpret_cast<const bf16x8 *>(a.wx0 + (long)(32 * gt + col) * CP + 16 * (k < ks0 ? k : 0) + 8 * hh);
+        const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(a.wx0 + (long)(32 * gt + col) * CP + 16 * (k < ks0 ? k : 0) + 8 * hh);
+        wx0[k] = k < ks0 ? wv : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};             // (k-steps beyond the padded channel count: zero weights)
     }
     float c0[NT][4], c1[NT][4];
 #pragma unroll
@@ -138,15 +139,16 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[nt][r] = bias0[r]; acc1[nt][r] = bias1[r]; }
-        if (do0) {
-            mfma_lead_in();
+        // All four k-steps, unconditionally (zero weights beyond the channel count; at s == T the result feeds nothing), and settled
+        // before any control flow: the accumulators of asm MFMAs are ordinary values to hipcc, and around a run-time branch it copies
+        // them (AGPR -> VGPR) at once -- reading a result the matrix pipe has not written yet.
+        mfma_lead_in();
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < ks0) {
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mfma_acc_a(acc0[nt], wx0[k], xf[nt][k]);
-                }
-        }
+            for (int nt = 0; nt < NT; ++nt) mfma_acc_v(acc0[nt], wx0[k], xf[nt][k]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mfma_settle(acc0[nt]);
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < T) load_x(s + 1);
         __builtin_amdgcn_sched_barrier(0);

@@ -139,11 +139,18 @@ __device__ __forceinline__ void mfma_rows(const bf16x8 *w, const bf16_t *tile, c
 // (2 900 cycles for 48 MFMAs).  As asm statements with "a" constraints the operands are used where they live.  hipcc knows
 // nothing about the latency of these statements: mfma_settle(accumulators) before any other instruction reads one (in-place
 // accumulation chains and independent accumulators need nothing, as in hipcc's own output).
+// (the s_nop in front: hipcc may satisfy an "a" operand by copying it from a VGPR right before the statement, and it does not
+// know that the statement is an MFMA reading that copy -- VALU write -> MFMA read needs wait states, found as NaNs when four
+// rarely used fragments were copied in that way.  It is free when MFMAs follow each other: the pipe is busy 32 cycles anyway.)
 __device__ __forceinline__ void mfma_acc_a(f32x16 &acc, const bf16x8 &w, const bf16x8 &f) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(f));
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(f));
+}
+// (A operand in a VGPR: for the few fragments of the in-scan input projection, which hipcc keeps in VGPRs anyway)
+__device__ __forceinline__ void mfma_acc_v(f32x16 &acc, const bf16x8 &w, const bf16x8 &f) {
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(f));
 }
 __device__ __forceinline__ void mfma_new_a(f32x16 &acc, const bf16x8 &w, const bf16x8 &f) {       // acc = w . f
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(w), "v"(f));
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(w), "v"(f));
 }
 // (the accumulators are operands of the statement: a register read of one cannot be scheduled above it)
 __device__ __forceinline__ void mfma_settle(f32x16 &a0) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0)); }

@@ -59,7 +59,12 @@ struct SeqWs {
 // ---- recurrence kernels (nsd_scan.hip) ----------------------------------------------------------------------------------
 struct ScanFwdArgs {
     const bf16_t *wf[NSD_SEQ_MAX_DIRS];      // [4H][H] recurrent weights, rows in accumulator-tile order
-    const bf16_t *xproj[NSD_SEQ_MAX_DIRS];   // accumulator tiles, bias included
+    const bf16_t *xproj[NSD_SEQ_MAX_DIRS];   // accumulator tiles, bias included (layers whose input is a hidden sequence)
+    // layer 0 with at most 64 channels: the projection rides in the scan instead (CP / 16 <= 4 MFMAs per step; xproj unused)
+    const bf16_t *wx0[NSD_SEQ_MAX_DIRS];     // [4H][CP] W_ih, rows in accumulator-tile order, or null
+    const float *bsum0[NSD_SEQ_MAX_DIRS];    // [4H] b_ih + b_hh, tile order
+    const bf16_t *xbf;                       // [T*Bp][CP]
+    int CP;
     bf16_t *hs;                              // [T*Bp][ld]
     bf16_t *xch;                             // exchange ring [2][D][groups_total][MG*H] in gate-tile blocks (whole lines per producer wave)
     int groups_total;

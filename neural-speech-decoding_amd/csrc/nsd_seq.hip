@@ -219,7 +219,9 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
         const bool masked = lstm_drop && l < s.L - 1;
         const bf16_t *in = l == 0 ? at<bf16_t>(c.ws, c.w.xbf) : out_of(c, l - 1, lstm_drop);
         const int Kin = l == 0 ? s.CP : DH;
-        for (int d = 0; d < s.D; ++d) {
+        // layer 0 with at most 64 channels: W_ih . x_t is CP / 16 <= 4 MFMAs per step inside the scan (no GEMM, no tile round trip)
+        const bool inproj = l == 0 && s.CP <= 64;
+        for (int d = 0; d < s.D && !inproj; ++d) {
             GemmArgs g;
             memset(&g, 0, sizeof(g));
             g.A = at<bf16_t>(c.ws, c.w.wx[l][d]); g.lda = Kin; g.B = in; g.ldb = Kin;
@@ -235,10 +237,12 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             for (int d = 0; d < s.D; ++d) {
                 a.wf[d] = at<bf16_t>(c.ws, c.w.wf[l][d]);
                 a.xproj[d] = at<bf16_t>(c.ws, c.w.xproj[d]);
+                if (inproj) { a.wx0[d] = at<bf16_t>(c.ws, c.w.wx[0][d]); a.bsum0[d] = at<float>(c.ws, c.w.bsum[0][d]); }
                 a.cs[d] = train ? at<bf16_t>(c.ws, c.w.cs[l][d]) : nullptr;
                 a.ga[d] = train ? at<bf16_t>(c.ws, c.w.ga[l][d]) : nullptr;
             }
             a.hs = at<bf16_t>(c.ws, c.w.hs[l]); a.xch = at<bf16_t>(c.ws, c.w.xch); a.groups_total = s.groups;
+            a.xbf = at<bf16_t>(c.ws, c.w.xbf); a.CP = s.CP;
             a.lk = writes_lk(s, l, lstm_drop) ? at<bf16_t>(c.ws, c.w.lk[l]) : nullptr;
             a.res = (s.residual && l >= 1) ? in : nullptr;
             a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)l * s.D * s.groups + (long)g0 * s.D) * 128;   // disjoint per chunk
