@@ -156,6 +156,176 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA tiles), LDS double-buffered, ONE barrier per K chunk.
+// Why a second kernel: the 128 x 128 tile moves 32 KB from the L2 per 128 x 128 x 64 MACs = 64 FLOP per byte, and a CU takes
+// 64 bytes per clock from the L2 -- 4 096 FLOP per clock, exactly the CU's bf16 MFMA peak: the small tile sits ON the L2
+// bandwidth roof (measured 0.5-0.9 PFLOP/s).  The 256 x 256 tile needs half the bytes per FLOP.  One workgroup per CU (8 waves,
+// 144 KB of LDS), so the overlap of loads and MFMAs comes from the double buffer, not from co-resident workgroups.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace big {
+constexpr int TM = 256, TN = 256, NTH = 512;
+constexpr int LDTB = 256 + 32;                                  // halves per LDS row, k-major image (16 dwords mod 64, as LDT)
+constexpr int OPB = (TM * LDR > GK * LDTB ? TM * LDR : GK * LDTB) * 2;     // bytes of one operand image
+
+__device__ __forceinline__ Pieces load_rowmajor_b(const bf16_t *P, const long ld, const int r0, const int nrows, const long k0, const long k_hi,
+                                                const int tid) {
+    Pieces p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + NTH * i, row = e >> 3, kc = e & 7;
+        const long k = k0 + 8 * kc;
+        const bool ok = r0 + row < nrows && k < k_hi;
+        p.v[i] = ok ? *reinterpret_cast<const u32x4 *>(P + (long)(r0 + row) * ld + k) : u32x4{0u, 0u, 0u, 0u};
+    }
+    return p;
+}
+__device__ __forceinline__ void store_rowmajor_b(bf16_t *S, const Pieces &p, const int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + NTH * i, row = e >> 3, kc = e & 7;
+        *reinterpret_cast<u32x4 *>(S + row * LDR + 8 * kc) = p.v[i];
+    }
+}
+__device__ __forceinline__ Pieces load_kmajor_b(const bf16_t *P, const long ld, const int c0, const int ncols, const long k0, const long k_hi,
+                                              const long shift, const long period, const long K, const int tid) {
+    Pieces p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + NTH * i, kr = e >> 5, cc = e & 31;
+        const long k = k0 + kr, ks = k + shift;
+        bool ok = k < k_hi && ks >= 0 && ks < K && c0 + 8 * cc < ncols;
+        if (period > 0 && shift != 0) {
+            const long kin = (long)((unsigned)k % (unsigned)period) + shift;
+            ok = ok && kin >= 0 && kin < period;
+        }
+        p.v[i] = ok ? *reinterpret_cast<const u32x4 *>(P + ks * ld + c0 + 8 * cc) : u32x4{0u, 0u, 0u, 0u};
+    }
+    return p;
+}
+__device__ __forceinline__ void store_kmajor_b(bf16_t *S, const Pieces &p, const int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + NTH * i, kr = e >> 5, cc = e & 31;
+        *reinterpret_cast<u32x4 *>(S + kr * LDTB + 8 * cc) = p.v[i];
+    }
+}
+__device__ __forceinline__ bf16x8 frag_kmajor_b(const bf16_t *S, const int base, const int ks, const int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    const bf16_t *a = S + (16 * ks + 8 * (g >> 1) + q) * LDTB + base + 16 * (g & 1) + 4 * p;
+    return cat_tr(lds_read_tr16(a), lds_read_tr16(a + 4 * LDTB));
+}
+
+template <bool AK, bool BK, int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
+    extern __shared__ __align__(16) unsigned char smem[];       // [2 buffers][A image | B image]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;                    // wave tile: rows 128 wm .., columns 64 wn ..
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const long nchunks = (g.K + GK - 1) / GK;
+    const long per = (nchunks + g.splits - 1) / g.splits;
+    const long c_lo = (long)blockIdx.z * per, c_hi = (c_lo + per < nchunks) ? c_lo + per : nchunks;
+    const long k_lo = c_lo * GK, k_hi = (c_hi * GK < g.K) ? c_hi * GK : g.K;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+
+    auto lda_ = [&](long k0) { return AK ? load_kmajor_b(g.A, g.lda, m0, g.M, k0, k_hi, 0, 0, g.K, tid) : load_rowmajor_b(g.A, g.lda, m0, g.M, k0, k_hi, tid); };
+    auto ldb_ = [&](long k0) { return BK ? load_kmajor_b(g.B, g.ldb, n0, g.N, k0, k_hi, g.b_shift, g.b_period, g.K, tid) : load_rowmajor_b(g.B, g.ldb, n0, g.N, k0, k_hi, tid); };
+    auto put = [&](const int buf, const Pieces &pa, const Pieces &pb) {
+        bf16_t *As = reinterpret_cast<bf16_t *>(smem + (size_t)buf * 2 * OPB), *Bs = reinterpret_cast<bf16_t *>(smem + (size_t)buf * 2 * OPB + OPB);
+        if (AK) store_kmajor_b(As, pa, tid); else store_rowmajor_b(As, pa, tid);
+        if (BK) store_kmajor_b(Bs, pb, tid); else store_rowmajor_b(Bs, pb, tid);
+    };
+    if (k_lo < k_hi) {
+        Pieces pa = lda_(k_lo), pb = ldb_(k_lo);
+        put(0, pa, pb);
+        __syncthreads();
+        int buf = 0;
+        for (long k0 = k_lo; k0 < k_hi; k0 += GK, buf ^= 1) {
+            const bool more = k0 + GK < k_hi;
+            if (more) { pa = lda_(k0 + GK); pb = ldb_(k0 + GK); }              // in flight during the MFMAs of this chunk
+            const bf16_t *As = reinterpret_cast<const bf16_t *>(smem + (size_t)buf * 2 * OPB), *Bs = reinterpret_cast<const bf16_t *>(smem + (size_t)buf * 2 * OPB + OPB);
+#pragma unroll
+            for (int ks = 0; ks < GK / 16; ++ks) {
+                bf16x8 a[4], b[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = AK ? frag_kmajor_b(As, 128 * wm + 32 * i, ks, lane) : frag_rowmajor(As, 128 * wm + 32 * i, ks, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = BK ? frag_kmajor_b(Bs, 64 * wn + 32 * j, ks, lane) : frag_rowmajor(Bs, 64 * wn + 32 * j, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) put(buf ^ 1, pa, pb);                     // the other buffer: its last readers passed the barrier of the previous chunk
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int mb = m0 + 128 * wm + 32 * i, nb = n0 + 64 * wn + 32 * j;
+            const int n = nb + (lane & 31);
+            if (EPI == GEMM_EPI_TILE_BF16) {
+                if (mb + 32 <= g.M && nb + 32 <= g.N) {
+                    unsigned w[8];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float b0 = g.bias ? g.bias[mb + mfma32_row(r, lane)] : 0.f;
+                        const float b1 = g.bias ? g.bias[mb + mfma32_row(r + 1, lane)] : 0.f;
+                        w[r >> 1] = pack_bf16x2(acc[i][j][r] + b0, acc[i][j][r + 1] + b1);
+                    }
+                    bf16_t *dst = reinterpret_cast<bf16_t *>(g.C) + (((long)(nb >> 5) * (g.M >> 5) + (mb >> 5)) * 64 + lane) * 16;
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{w[0], w[1], w[2], w[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 8) = u32x4{w[4], w[5], w[6], w[7]};
+                }
+            } else {
+                if (n >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + mfma32_row(r, lane);
+                    if (m >= g.M) continue;
+                    if (EPI == GEMM_EPI_F32)
+                        (reinterpret_cast<float *>(g.C) + (long)blockIdx.z * g.M * g.ldc)[(long)m * g.ldc + n] =
+                            acc[i][j][r] + (g.add ? g.add[(long)m * g.ldc + n] : 0.f);
+                    else
+                        reinterpret_cast<bf16_t *>(g.C)[(long)m * g.ldc + n] = (bf16_t)acc[i][j][r];
+                }
+            }
+        }
+}
+
+template <bool AK, bool BK, int EPI>
+int launch_one(const GemmArgs &g, const dim3 grid, hipStream_t st) {
+    static bool once = false;                                   // 144 KB of dynamic LDS needs the opt-in (per kernel, once per process)
+    auto *kp = &gemm_bf16_big_kernel<AK, BK, EPI>;
+    if (!once) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * OPB) != hipSuccess) {
+            nsd_set_error("gemm_bf16: cannot reserve %d bytes of LDS", 4 * OPB);
+            return NSD_E_INVALID;
+        }
+        once = true;
+    }
+    hipLaunchKernelGGL(kp, grid, dim3(NTH), 4 * OPB, st, g);
+    NSD_CHECK_LAUNCH("gemm_bf16_big_kernel");
+    return NSD_OK;
+}
+template <bool AK, bool BK>
+int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
+    switch (g.epi) {
+    case GEMM_EPI_F32: return launch_one<AK, BK, GEMM_EPI_F32>(g, grid, st);
+    case GEMM_EPI_BF16: return launch_one<AK, BK, GEMM_EPI_BF16>(g, grid, st);
+    case GEMM_EPI_TILE_BF16: return launch_one<AK, BK, GEMM_EPI_TILE_BF16>(g, grid, st);
+    default: nsd_set_error("gemm_bf16: unknown epilogue %d", g.epi); return NSD_E_INVALID;
+    }
+}
+}  // namespace big
+
 template <bool AK, bool BK>
 int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
     switch (g.epi) {
@@ -169,6 +339,9 @@ int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
 }
 
 }  // namespace
+
+// test hook: NSD_GEMM_SMALL_TILES=1 forces the 128 x 128 kernel (both kernels must give the same numbers)
+static bool getenv_small_tiles() { static const bool v = [] { const char *e = getenv("NSD_GEMM_SMALL_TILES"); return e && e[0] == '1'; }(); return v; }
 
 int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
     if (!g.A || !g.B || !g.C || g.M < 1 || g.N < 1 || g.K < 1) { nsd_set_error("gemm_bf16: null pointer or empty problem"); return NSD_E_INVALID; }
@@ -185,6 +358,13 @@ int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
     if (g.add && (g.epi != GEMM_EPI_F32 || splits != 1)) { nsd_set_error("gemm_bf16: addend needs the fp32 epilogue without split-K"); return NSD_E_INVALID; }
     GemmArgs a = g;
     a.splits = splits;
+    // the 256 x 256 kernel where it fills the machine: at least one workgroup per CU (split-K included)
+    const long big_wgs = (long)((g.N + big::TN - 1) / big::TN) * ((g.M + big::TM - 1) / big::TM) * splits;
+    if (g.M >= big::TM && g.N >= big::TN && big_wgs >= nsd_num_cus() && !getenv_small_tiles()) {
+        const dim3 bgrid((g.N + big::TN - 1) / big::TN, (g.M + big::TM - 1) / big::TM, splits);
+        if (g.a_kmajor) return g.b_kmajor ? big::launch_epi<true, true>(a, bgrid, st) : big::launch_epi<true, false>(a, bgrid, st);
+        return g.b_kmajor ? big::launch_epi<false, true>(a, bgrid, st) : big::launch_epi<false, false>(a, bgrid, st);
+    }
     const dim3 grid((g.N + GN - 1) / GN, (g.M + GM - 1) / GM, splits);
     if (g.a_kmajor) return g.b_kmajor ? launch_epi<true, true>(a, grid, st) : launch_epi<true, false>(a, grid, st);
     return g.b_kmajor ? launch_epi<false, true>(a, grid, st) : launch_epi<false, false>(a, grid, st);

@@ -53,6 +53,8 @@ int derive(const nsd_dims *d, uint32_t flags, SeqDims *o) {
     return NSD_OK;
 }
 
+constexpr long PARTS_FLOATS = 18L * 1024 * 1024;               // 64 splits of cfg3's 1024 x 256 weight gradient
+
 SeqWs make_ws(const SeqDims &s) {
     SeqWs w;
     memset(&w, 0, sizeof(w));
@@ -99,7 +101,7 @@ SeqWs make_ws(const SeqDims &s) {
         const int64_t parts = 2LL * s.groups * s.D * Pm * Pm * (s.MG / 32) * 4 * 1536;
         w.xch = take(tiles > parts ? tiles : parts);
     }
-    w.parts = take(64LL * 1024 * 1024);                          // split-K partials of the weight-gradient GEMMs (<= 16 M floats)
+    w.parts = take(PARTS_FLOATS * 4);                            // split-K partials of the weight-gradient GEMMs
     w.total = p;
     return w;
 }
@@ -153,12 +155,14 @@ struct Ctx {
 };
 
 int split_count(int M, int N, long K) {
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int S = 512 / (tiles > 0 ? tiles : 1);
+    // the 256 x 256 kernel (nsd_gemm_bf16.hip) wants at least one workgroup per CU, the 128 x 128 kernel about two
+    const bool big = M >= 256 && N >= 256;
+    const int tiles = big ? ((M + 255) / 256) * ((N + 255) / 256) : ((M + 127) / 128) * ((N + 127) / 128);
+    int S = big ? (nsd_num_cus() + tiles - 1) / (tiles > 0 ? tiles : 1) : 512 / (tiles > 0 ? tiles : 1);
     if (S < 1) S = 1;
     if (S > 64) S = 64;
     while (S > 1 && K / S < 256) --S;
-    while ((long)S * M * N > 16L * 1024 * 1024 && S > 1) --S;
+    while ((long)S * M * N > PARTS_FLOATS && S > 1) --S;
     return S;
 }
 

@@ -92,6 +92,57 @@ def test_gemm_bf16_split_k_shift_and_tile_epilogue(nsd, dev):
             assert np.abs(tiles[nt, mt] - want).max() <= 2 ** -8 * np.abs(want).max() + 1e-3
 
 
+@pytest.mark.parametrize("a_kmajor,b_kmajor", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_bf16_large_tile_kernel(nsd, dev, a_kmajor, b_kmajor):
+    """Problems with at least one 256 x 256 tile per CU run the double-buffered 256 x 256 kernel: ragged edges in M, N and K, all
+    four operand layouts, all three epilogues."""
+    from nsd_amd import ops
+    M, N, K = 4096 + 72, 4096 - 56, 200                     # 17 x 16 = 272 workgroups >= 256 CUs; K: three chunks and a tail of 8
+    rs = np.random.RandomState(11)
+    a = _bf(rs.standard_normal((K, M) if a_kmajor else (M, K)).astype(np.float32), dev)
+    b = _bf(rs.standard_normal((K, N) if b_kmajor else (N, K)).astype(np.float32), dev)
+    am = a.float().t() if a_kmajor else a.float()
+    bm = b.float() if b_kmajor else b.float().t()
+    ref = am @ bm                                            # (fp32 on the GPU: exact bf16 products, fp32 sums in another order)
+    c = ops.gemm_bf16(a, b, a_kmajor=a_kmajor, b_kmajor=b_kmajor)
+    assert (c - ref).abs().max().item() < 2e-5 * K ** 0.5 * 4, (c - ref).abs().max().item()
+    c16 = ops.gemm_bf16(a, b, a_kmajor=a_kmajor, b_kmajor=b_kmajor, epilogue=1)
+    assert (c16.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-3
+    if not a_kmajor and not b_kmajor:                        # accumulator tiles + bias (M, N multiples of 32)
+        M2, N2 = 4096, 4032
+        bias = torch.from_numpy(rs.standard_normal(M2).astype(np.float32)).to(dev)
+        tiles = ops.gemm_bf16(a[:M2].contiguous(), b[:N2].contiguous(), epilogue=2, bias=bias).float()          # [N/32, M/32, 64, 16]
+        want = (ref[:M2, :N2] + bias[:, None])
+        lane = torch.arange(64, device=dev)[:, None]
+        r = torch.arange(16, device=dev)[None, :]
+        rows = 8 * (r // 4) + 4 * (lane >> 5) + (r % 4)
+        cols = (lane & 31).expand_as(rows)
+        for nt, mt in ((0, 0), (5, 77), (125, 127), (64, 3)):
+            w = want[32 * mt + rows, 32 * nt + cols]
+            assert (tiles[nt, mt] - w).abs().max().item() <= 2 ** -8 * w.abs().max().item() + 1e-3
+
+
+def test_gemm_bf16_large_tile_split_k_shift_period(nsd, dev):
+    """The weight-gradient shape on the 256 x 256 kernel: split-K over many rows, operand B shifted by one time step inside each
+    batch tile's block of rows (b_shift = -+32, period = T * 32 in the path; here through the public b_shift only: whole matrix)."""
+    from nsd_amd import ops
+    rs = np.random.RandomState(12)
+    R, G, Hh = 64 * 640, 1024, 256                           # 4 x 1 tiles x 64 splits = 256 workgroups
+    da = _bf(rs.standard_normal((R, G)).astype(np.float32), dev)
+    h = _bf(rs.standard_normal((R, Hh)).astype(np.float32), dev)
+    for shift in (-32, 32, 0):
+        hs = torch.zeros_like(h)
+        if shift < 0:
+            hs[-shift:] = h[:shift]
+        elif shift > 0:
+            hs[:-shift] = h[shift:]
+        else:
+            hs = h
+        ref = da.float().t() @ hs.float()
+        c = ops.gemm_bf16(da, h, a_kmajor=True, b_kmajor=True, b_shift=shift, splits=64)
+        assert (c - ref).abs().max().item() < 2e-5 * R ** 0.5 * 4, (shift, (c - ref).abs().max().item())
+
+
 # ---------------------------------------------------------------------------------------------------
 # the path itself against the fp32 oracle (unidirectional): inference, training gradients, dropout streams
 # ---------------------------------------------------------------------------------------------------
