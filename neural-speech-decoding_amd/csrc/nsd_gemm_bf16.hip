@@ -221,7 +221,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];       // [2 buffers][A image | B image]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;                    // wave tile: rows 128 wm .., columns 64 wn ..
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    // XCD-aware tile order.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2: with the natural (x, y) order the
+    // workgroups that share an operand tile land on different L2s and the tile is fetched from memory once per XCD (the
+    // layer-1 projection at cfg5 re-read its 1-GB activation matrix 8 times).  Here XCD k = id % 8 takes a CONTIGUOUS range of the
+    // tile sequence, and the sequence walks groups of up to 8 M-tiles (M fastest) before it moves along N: the ~32 tiles an
+    // XCD works on at a time are an 8 x 4 block sharing 8 A tiles and 4 B tiles.
+    const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nt = tiles_m * tiles_n, tpx = (nt + 7) / 8;
+    const int q = (int)(blockIdx.x & 7) * tpx + (int)(blockIdx.x >> 3);
+    if (q >= nt) return;                                        // (the grid is padded to 8 * tpx; whole workgroups leave)
+    const int GH = tiles_m < 8 ? tiles_m : 8, per_group = GH * tiles_n, grp = q / per_group, rr = q - grp * per_group;
+    const int gh = (grp + 1) * GH <= tiles_m ? GH : tiles_m - grp * GH;          // (last group of a ragged M)
+    const int tile_m = grp * GH + rr % gh, tile_n = rr / gh;
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
     const long nchunks = (g.K + GK - 1) / GK;
     const long per = (nchunks + g.splits - 1) / g.splits;
     const long c_lo = (long)blockIdx.z * per, c_hi = (c_lo + per < nchunks) ? c_lo + per : nchunks;
@@ -361,7 +372,8 @@ int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
     // the 256 x 256 kernel where it fills the machine: at least one workgroup per CU (split-K included)
     const long big_wgs = (long)((g.N + big::TN - 1) / big::TN) * ((g.M + big::TM - 1) / big::TM) * splits;
     if (g.M >= big::TM && g.N >= big::TN && big_wgs >= nsd_num_cus() && !getenv_small_tiles()) {
-        const dim3 bgrid((g.N + big::TN - 1) / big::TN, (g.M + big::TM - 1) / big::TM, splits);
+        const int tiles = ((g.N + big::TN - 1) / big::TN) * ((g.M + big::TM - 1) / big::TM);
+        const dim3 bgrid(8 * ((tiles + 7) / 8), 1, splits);     // 1-D, padded to a multiple of 8: the kernel maps ids to tiles (XCD-aware)
         if (g.a_kmajor) return g.b_kmajor ? big::launch_epi<true, true>(a, bgrid, st) : big::launch_epi<true, false>(a, bgrid, st);
         return g.b_kmajor ? big::launch_epi<false, true>(a, bgrid, st) : big::launch_epi<false, false>(a, bgrid, st);
     }
