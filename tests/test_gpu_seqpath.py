@@ -287,6 +287,37 @@ def test_seq_exchange_modes_agree(nsd, dev):
     assert placement[2][1] == n_groups                          # spread really means spread: the write-through path carried the run
 
 
+def test_seq_exchange_modes_agree_layer_by_layer_kernels(nsd, dev):
+    """The same three placements for the general kernels (one layer per launch, here bidirectional with dropout streams):
+    forward ring, backward partial-sum ring, in-scan projection of layer 0 -- same bits whatever carried the exchange."""
+    from nsd_amd import ops
+    C, H, L, K, B, T = 24, 128, 2, 3, 96, 9
+    st = synth_params(C, H, L, K, seed=44, D=2)
+    spec = ops.ModelSpec(C=C, H=H, L=L, K=K, D=2)
+    flat = _flat_from_state(spec, st, dev)
+    xt = torch.from_numpy(synth_x(B, T, C=C, seed=3)).to(dev)
+    yt = torch.from_numpy(synth_labels(B, K, seed=3)).to(dev)
+    rng = dict(seed=99, base_stream=8, p_lstm=0.5, p_head=0.5)
+    out, placement = [], []
+    for on, spread in ((True, False), (False, False), (True, True)):
+        ops.set_seq_l2_exchange(on, spread)
+        try:
+            ws = ops.seq_workspace(spec, B, T, dev)
+            lg = ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng).clone()
+            g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
+            stt, one_xcd, spread_n = ops.seq_status(ws, detail=True)
+            assert stt == 0
+            placement.append((one_xcd, spread_n))
+            out.append((lg, g))
+        finally:
+            ops.set_seq_l2_exchange(True, False)
+    for lg, g in out[1:]:
+        assert torch.equal(out[0][0], lg) and torch.equal(out[0][1], g)
+    n_groups = 2 * 2 * 2 * 3                                    # layers x passes x directions x batch tiles
+    assert all(a + b == n_groups for a, b in placement), placement
+    assert torch.isfinite(out[0][1]).all()
+
+
 def test_two_layer_skewed_launch_vs_layer_by_layer(nsd, dev):
     """L = 2 unidirectional runs as ONE launch with layer 1 a step behind layer 0 (its input projection and input gradient ride
     in the scans); the diagnostic flag restores the general route (scan + GEMM per layer).  Same model, same streams: the
