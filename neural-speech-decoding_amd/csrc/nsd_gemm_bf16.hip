@@ -227,8 +227,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
     // tile sequence, and the sequence walks groups of up to 8 M-tiles (M fastest) before it moves along N: the ~32 tiles an
     // XCD works on at a time are an 8 x 4 block sharing 8 A tiles and 4 B tiles.
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nt = tiles_m * tiles_n, tpx = (nt + 7) / 8;
-    const int q = (int)(blockIdx.x & 7) * tpx + (int)(blockIdx.x >> 3);
-    if (q >= nt) return;                                        // (the grid is padded to 8 * tpx; whole workgroups leave)
+    // (only where there are tiles to share: with a handful of tiles per split-K slice the ids keep their natural order -- the
+    // padded, remapped grid of fewer than 8 tiles would park every real tile of every slice on the same few XCDs)
+    const bool remap = gridDim.x == (unsigned)(8 * tpx) && nt >= 16;
+    const int q = remap ? (int)(blockIdx.x & 7) * tpx + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (q >= nt) return;                                        // (a remapped grid is padded to 8 * tpx; whole workgroups leave)
     const int GH = tiles_m < 8 ? tiles_m : 8, per_group = GH * tiles_n, grp = q / per_group, rr = q - grp * per_group;
     const int gh = (grp + 1) * GH <= tiles_m ? GH : tiles_m - grp * GH;          // (last group of a ragged M)
     const int tile_m = grp * GH + rr % gh, tile_n = rr / gh;
@@ -260,19 +263,37 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
             const bool more = k0 + GK < k_hi;
             if (more) { pa = lda_(k0 + GK); pb = ldb_(k0 + GK); }              // in flight during the MFMAs of this chunk
             const bf16_t *As = reinterpret_cast<const bf16_t *>(smem + (size_t)buf * 2 * OPB), *Bs = reinterpret_cast<const bf16_t *>(smem + (size_t)buf * 2 * OPB + OPB);
-#pragma unroll
-            for (int ks = 0; ks < GK / 16; ++ks) {
-                bf16x8 a[4], b[2];
+            // fragments of k-step ks+1 are requested before the MFMAs of k-step ks are issued (two register sets): the LDS latency
+            // of a k-step hides behind the 8 MFMAs of the one before instead of being paid in front of each MFMA pair
+            bf16x8 fa[2][4], fb[2][2];
+            auto frags = [&](const int ks, bf16x8 (&a)[4], bf16x8 (&b)[2]) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[i] = AK ? frag_kmajor_b(As, 128 * wm + 32 * i, ks, lane) : frag_rowmajor(As, 128 * wm + 32 * i, ks, lane);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[j] = BK ? frag_kmajor_b(Bs, 64 * wn + 32 * j, ks, lane) : frag_rowmajor(Bs, 64 * wn + 32 * j, ks, lane);
+            };
+            // (with both operands k-major a fragment is two transposing reads and the second register set spills: one set there)
+            constexpr bool TWO_SETS = !(AK && BK);
+            frags(0, fa[0], fb[0]);
+#pragma unroll
+            for (int ks = 0; ks < GK / 16; ++ks) {
+                if (TWO_SETS) {
+                    if (ks + 1 < GK / 16) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (ks > 0) {
+                    frags(ks, fa[0], fb[0]);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TWO_SETS ? (ks & 1) : 0][i], fb[TWO_SETS ? (ks & 1) : 0][j], acc[i][j], 0, 0, 0);
+                if (TWO_SETS) __builtin_amdgcn_sched_barrier(0);
+                // the next chunk goes to the OTHER buffer (its last readers passed the barrier of the previous chunk) in the middle of
+                // this chunk's MFMAs: the wait for the loads and the ds_writes then overlap the partner wave's MFMAs instead of
+                // both waves of a SIMD meeting at the barrier with their stores still to do
+                if (ks == 1 && more) put(buf ^ 1, pa, pb);
             }
-            if (more) put(buf ^ 1, pa, pb);                     // the other buffer: its last readers passed the barrier of the previous chunk
             __syncthreads();
         }
     }
@@ -373,7 +394,7 @@ int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
     const long big_wgs = (long)((g.N + big::TN - 1) / big::TN) * ((g.M + big::TM - 1) / big::TM) * splits;
     if (g.M >= big::TM && g.N >= big::TN && big_wgs >= nsd_num_cus() && !getenv_small_tiles()) {
         const int tiles = ((g.N + big::TN - 1) / big::TN) * ((g.M + big::TM - 1) / big::TM);
-        const dim3 bgrid(8 * ((tiles + 7) / 8), 1, splits);     // 1-D, padded to a multiple of 8: the kernel maps ids to tiles (XCD-aware)
+        const dim3 bgrid(tiles >= 16 ? 8 * ((tiles + 7) / 8) : tiles, 1, splits);   // 1-D; >= 16 tiles: padded to a multiple of 8, ids mapped XCD-aware
         if (g.a_kmajor) return g.b_kmajor ? big::launch_epi<true, true>(a, bgrid, st) : big::launch_epi<true, false>(a, bgrid, st);
         return g.b_kmajor ? big::launch_epi<false, true>(a, bgrid, st) : big::launch_epi<false, false>(a, bgrid, st);
     }
