@@ -6,8 +6,9 @@
 //   weight gradients                 dW[4H, I | H]   = da[T*B, 4H]^T . {in | h_prev}[T*B, .]  (both operands k-major: the
 //                                                       contraction runs over the rows -> transposed LDS reads, split-K)
 // (torch.nn.LSTM of Neuro-Alpha-App/Utilities/lstm_eeg_model.py:16-22,34 and autograd through it, for the layers whose
-// input is a full sequence).  One kernel: 128x128 tile, K chunks of 64, 4 waves as 2x2, each wave 2x2 v_mfma_f32_32x32x16_bf16
-// tiles; operands staged global -> registers -> LDS with the next chunk's loads in flight during the MFMAs.
+// input is a full sequence).  Two kernels: 128x128 tile, K chunks of 64, 4 waves as 2x2, each wave 2x2 v_mfma_f32_32x32x16_bf16
+// tiles, operands staged global -> registers -> LDS with the next chunk's loads in flight during the MFMAs; and, where the
+// problem has at least one 256x256 tile per CU, the double-buffered 256x256 kernel further down (namespace big).
 // LDS images: k-contiguous operand [128 rows][64 k + 8 pad] (ds_read_b128 fragments, conflict-free), k-major operand
 // [64 k][128 + 32 pad] (ds_read_b64_tr_b16 fragments: row stride = 16 dwords mod 64 keeps the 4 k-rows x 2 column blocks of
 // a 32-lane half on disjoint banks).

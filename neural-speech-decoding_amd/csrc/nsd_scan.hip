@@ -12,23 +12,25 @@
 // owns are adjacent in memory (8-byte stores).
 //
 // Exchange.  Each step every workgroup needs h_{t-1} of ALL H units of its batch tile: the members of a group exchange their
-// 32-unit slices through the saved sequence itself (hs[t] is written anyway for the backward pass): write-through (sc1)
-// stores, the storing wave drains vmcnt and publishes the step count in ITS OWN flag word (4 words per workgroup, no
-// workgroup barrier on the publishing side); every consuming wave polls all 4P words of its group with sc1 loads (one
-// word per lane) and only then issues its sc1 loads of the tile -- a tile row is complete before anybody reads any part
-// of it (guide: Guideline 16 R1 with sc1 loads in place of the acquire fence; every handed-off byte is stored and loaded
-// sc1, every flag follows the drain of the stores it stands for).
+// 32-unit slices through a small ring (two slots, step parity) in which every producer wave owns whole 128-byte lines
+// (nsd_scan_common.h); hs[t] itself is written row-major behind the flag for the GEMMs and the head.  The storing wave drains
+// vmcnt and publishes the step count in ITS OWN flag word (4 words per workgroup, no workgroup barrier on the publishing side);
+// every consuming wave polls all 4P words of its group with sc1 loads (one word per lane) and only then issues its sc1 loads
+// of the tile (guide: Guideline 16 R1 with sc1 loads in place of the acquire fence; every handed-off byte is stored and loaded
+// sc1 in the write-through mode, every flag follows the drain of the stores it stands for).
 // Same-XCD shortcut: before the first step the members of a group exchange their XCC ids (HW_REG_XCC_ID) through the slow
 // protocol -- which doubles as a start barrier: nobody enters the time loop before every member is resident.  When all ids
 // are equal the group shares ONE L2, and the exchange switches to plain stores (kept in that L2; vmcnt is acknowledged by
 // the L2) read by the same L1-bypassing loads: an L2 round trip per hop instead of a memory round trip.  Which mode a
 // group runs in is decided from what the hardware reports at run time, identically by all its members; a group spread
-// over XCDs simply keeps the write-through protocol.  Results are the same in both modes.  Groups are independent of each other: no grid-wide barrier exists.  Every spin is bounded: a member that
-// does not see its group for ~1 s sets the status word and leaves (the others of the group then time out the same way).
+// over XCDs simply keeps the write-through protocol.  Results are the same in both modes.  Groups are independent of each
+// other: no grid-wide barrier exists.  Every spin is bounded: a member that does not see its group for ~1 s sets the status
+// word and leaves (the others of the group then time out the same way).
+// Layer 0 with at most 64 channels computes its input projection in the scan (INPROJ: 4 MFMAs per step from xbf).
 //
-// Backward.  Same grouping; per step the group exchanges da_t [trials, 4H] (written for the weight-gradient GEMMs anyway),
-// workgroup p computes dh_rec for its 32 units as W_hh^T[32, 4H] . da_t^T with the contraction split over its 4 waves (B
-// fragments straight from global memory -- each 16-byte piece is needed by exactly one wave), partial tiles meet in LDS.
+// Backward.  Same grouping and ownership; the recurrent term is a REDUCE-SCATTER of bf16 partial sums: a workgroup multiplies its
+// own 128 gate columns of da_t (from LDS) into partial dh rows for every unit of the layer and sends each member the 32 rows
+// it owns; a member adds the P partials in fp32 (design, ring layout and measurements: nsd_scan2.hip and DESIGN.md 4.3b).
 #include "nsd_scan_common.h"
 
 namespace {

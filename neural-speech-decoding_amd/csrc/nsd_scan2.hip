@@ -6,9 +6,11 @@
 //    published at the end of step s - 1 (h0_{s-1}, its multiplied copy when dropout is on, h1_{s-2}), so the stack costs
 //    T + 1 exchanges instead of 2 T, and layer 1's input projection W_ih1 . in1_t runs inside the scan (no GEMM, no
 //    accumulator-tile round trip through HBM).
-//  * backward: layer 1 works on t = T-1-s, layer 0 on t = T-s.  The tile da1_{t+1} the group exchanges serves twice: the
-//    recurrent term of layer 1 (W_hh1^T) and the input gradient of layer 1 (W_ih1^T), which is layer 0's upstream gradient
-//    -- the same B fragments feed two MFMAs; no input-gradient GEMM, no din round trip.
+//  * backward: layer 1 works on t = T-1-s, layer 0 on t = T-s.  What a workgroup needs from the group at step s -- W_hh1^T da1
+//    (recurrent term of layer 1), W_ih1^T da1 (input gradient of layer 1 = layer 0's upstream gradient) and W_hh0^T da0 -- all
+//    derive from what the members computed at step s-1, and is exchanged as partial sums (see "backward" below): no
+//    input-gradient GEMM, no din round trip.
+//  * the layer-0 input projection W_ih0 x_t (K = channels padded to 16, at most 64) is one to four MFMAs per step inside the scan.
 // Semantics as everywhere: torch.nn.LSTM(num_layers=2, dropout=p) of Neuro-Alpha-App/Utilities/lstm_eeg_model.py:16-22,34.
 #include "nsd_scan_common.h"
 

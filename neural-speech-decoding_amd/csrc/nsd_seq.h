@@ -119,7 +119,7 @@ struct Scan2BwdArgs {
     const bf16_t *wb0, *wb1, *wxt1;          // [H][4H] each: W_hh0^T, W_hh1^T, W_ih1^T (k = unit-major gate column)
     const bf16_t *cs0, *ga0, *cs1, *ga1;
     bf16_t *da0, *da1;                       // [T*Bp][4H]
-    bf16_t *xch;                             // exchange ring [2][groups_total][2][MG*4H]
+    bf16_t *xch;                             // partial-sum ring [2][groups_total][P][P][NT][4][64 lanes x (16 + 8) B] (PartRing, nsd_scan2.hip)
     float *dbp0, *dbp1;                      // [groups_total][4H]
     const float *alpha, *dscore, *dpooled, *attn_w;
     unsigned *flags;
