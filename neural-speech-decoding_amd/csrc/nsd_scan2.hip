@@ -243,16 +243,6 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     stp.store(a.status, blockIdx.x == 0 && tid == 0);
 }
 
-__device__ __forceinline__ void st_xchg_b128x2(const bool same_l2, const nsd_rsrc rs, const unsigned off, const unsigned (&dw)[8]) {
-    if (same_l2) {
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[0], dw[1], dw[2], dw[3]}, rs, (int)off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[4], dw[5], dw[6], dw[7]}, rs, (int)off + 16, 0, 0);
-    } else {
-        st_sc1_b128(rs, off, u32x4{dw[0], dw[1], dw[2], dw[3]});
-        st_sc1_b128(rs, off + 16u, u32x4{dw[4], dw[5], dw[6], dw[7]});
-    }
-}
-
 // ---- backward -------------------------------------------------------------------------------------------------------------
 // The recurrent terms are exchanged as a REDUCE-SCATTER of partial sums, not as an all-gather of da.  A workgroup owns the gate
 // columns of its 32 units (128 columns of da1 and of da0) and holds the rows of W_hh1^T, W_ih1^T, W_hh0^T for those columns and

@@ -111,28 +111,6 @@ __device__ __forceinline__ f32x16 unpack_tile(const u32x4 lo, const u32x4 hi) {
 }
 
 
-// acc[nt] += W[k0 .. k0+NK) . tile: the B fragments of FB k steps are read from LDS into DISTINCT registers first, then the
-// MFMAs issue back to back.  (Left to itself hipcc reuses one fragment register set: ds_read -> lgkmcnt(0) -> mfma, 48 times
-// a step -- the LDS latency, not the matrix pipe, then sets the pace: 4.8 us of a 6.7 us fused step.)
-template <int NT, int NK, int LD>
-__device__ __forceinline__ void mfma_rows(const bf16x8 *w, const bf16_t *tile, const int col, const int hh, f32x16 (&acc)[NT]) {
-    constexpr int FB = NK < 8 ? NK : 8;
-#pragma unroll
-    for (int k0 = 0; k0 < NK; k0 += FB) {
-        bf16x8 b[NT][FB];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int k = 0; k < FB; ++k) b[nt][k] = *reinterpret_cast<const bf16x8 *>(tile + (32 * nt + col) * LD + 16 * (k0 + k) + 8 * hh);
-        __builtin_amdgcn_sched_barrier(0);          // keep the batch of reads ahead of the batch of MFMAs (the scheduler sinks them otherwise)
-#pragma unroll
-        for (int k = 0; k < FB; ++k)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[k0 + k], b[nt][k], acc[nt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // MFMA with the weight fragment (A operand) and the accumulator read straight from accumulation registers.  The scans keep
 // 128-192 weight registers per lane; hipcc parks most of them in AGPRs and copies each fragment back with four v_accvgpr_read
 // before its MFMA -- with one wave per SIMD those copies issue in the MFMA's own slot, and a 32-cycle MFMA gap became ~55
@@ -160,7 +138,7 @@ __device__ __forceinline__ void mfma_lead_in() { asm volatile("s_nop 7" ::: "mem
 
 // Software-pipelined form for a whole step: NS operand streams (weight rows w[st], LDS tile tile[st]) feeding accumulators
 // chosen by acc_of(st, nt).  DEPTH fragments are in flight: the read of fragment i + DEPTH is issued right behind MFMA i, so
-// after the first DEPTH reads no MFMA waits for the LDS (mfma_rows exposes the LDS latency once per batch of 8: 48 MFMAs took
+// after the first DEPTH reads no MFMA waits for the LDS (reading a batch of 8 fragments and then issuing 8 MFMAs exposes the LDS latency once per batch: 48 MFMAs took
 // 4 400 cycles of a 9 600-cycle step where the matrix pipe needs 1 540).  One ds_read_b128 per MFMA gap is free (guide, LDS).
 template <int NT, int NK, int LD, int NS, int DEPTH, typename AccOf>
 __device__ __forceinline__ void mfma_pipe(const bf16x8 *const (&w)[NS], const bf16_t *const (&tile)[NS], const int col, const int hh, AccOf acc_of) {
@@ -193,80 +171,13 @@ __device__ __forceinline__ void mfma_pipe(const bf16x8 *const (&w)[NS], const bf
 // -- every gather load then waited ~5 000 cycles (in-kernel stamps).  They exchange through small rings (two slots, step
 // parity) in which every producer wave owns whole lines and writes them with ONE store instruction each:
 //   h  block of a batch tile, MG*H bf16:   [gate tile gt = 4p + wave][nt][trial 32][8 units]           lane (trial, hh): 8 bytes at hh*8
-//   da block of a batch tile, MG*4H bf16:  [gate tile][nt][half 2][hh 2][trial 32][8 columns]          lane: 16 bytes per half
-//      (half 0: the lane's units 4hh+0,1; half 1: units 4hh+2,3 -- each of a wave's two 16-byte stores is one lane-linear KB,
-//      which is also the B operand of one 32x32x16 MFMA k-step: lane (trial, hh) holds the 8 columns 16hh + 8half + 0..7 of
-//      the gate tile, so a consumer moves the KB to LDS by DMA and reads its fragment at lane*16 -- see scan2_bwd_kernel)
+//   (the backward scans exchange partial sums of dh instead of da: their ring is described in nsd_scan2.hip, "backward")
 // Two slots are enough: a member publishes step s only after it has gathered step s-1 from every member, i.e. after every
 // member has finished reading slot (s & 1) for step s-2.  The row-major tensors are still written (plain stores, behind the
 // flag) for the GEMMs and the head that read them after the scan.
 __device__ __forceinline__ long ring_h_off(const int gt, const int nt, const int NT, const int col, const int hh) {
     return ((long)(gt * NT + nt) * 32 + col) * 8 + 4 * hh;
 }
-__device__ __forceinline__ void ring_put_da(const bool same_l2, bf16_t *block, const int gt, const int nt, const int NT, const int col,
-                                            const int hh, const unsigned (&dw)[8]) {
-    const int lane = 32 * hh + col;
-    bf16_t *p0 = block + (((long)(gt * NT + nt) * 2 + 0) * 64 + lane) * 8;
-    bf16_t *p1 = block + (((long)(gt * NT + nt) * 2 + 1) * 64 + lane) * 8;
-    if (same_l2) {
-        *reinterpret_cast<u32x4 *>(p0) = u32x4{dw[0], dw[1], dw[2], dw[3]};
-        *reinterpret_cast<u32x4 *>(p1) = u32x4{dw[4], dw[5], dw[6], dw[7]};
-    } else {
-        const nsd_rsrc r0 = make_rsrc(block, 0x7fffffffu);
-        st_sc1_b128(r0, (unsigned)((p0 - block) * 2), u32x4{dw[0], dw[1], dw[2], dw[3]});
-        st_sc1_b128(r0, (unsigned)((p1 - block) * 2), u32x4{dw[4], dw[5], dw[6], dw[7]});
-    }
-}
-// LDS-DMA of one 1-KB block (64 lanes x 16 bytes, per-lane source address, wave-uniform LDS destination; agent-scope load): the
-// consumer side of the da ring -- no staging registers, no ds_write, and the block is lane-linear for the ds_read_b128 that
-// follows.  Written as an asm statement on purpose: through the builtin hipcc guards SOME dependent LDS reads with vmcnt(0)
-// (draining every block in flight) and degrades every fragment wait to lgkmcnt(0); as asm the operation is invisible to its
-// counters and the reader counts the blocks itself (wait_vm).  hipcc's own vmcnt waits stay safe: an operation it does not
-// know about only makes a counted wait stricter.  M0 (the LDS destination) is saved and restored inside the statement.
-__device__ __forceinline__ unsigned lds_addr_of(const void *shared_ptr) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)shared_ptr;
-}
-__device__ __forceinline__ void dma_block_sc1(const bf16_t *src_of_lane, const unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src_of_lane), "s"(lds_byte_addr) : "memory");
-}
-// s_waitcnt vmcnt(n): all but the wave's n youngest vector-memory operations have completed (n constant after unrolling)
-__device__ __forceinline__ void wait_vm(const int n) {
-    switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-// one chunk (CW columns = CW/32 gate tiles starting at gt0) of a da block -> registers (NLD = (CW/32) * NT * 2 pieces per lane,
-// each load instruction reads one contiguous KB) and -> the wave's LDS strip [MG rows][CW + 8], columns in unit-major order
-template <int NT, int CW>
-struct DaChunk {
-    static constexpr int TPC = CW / 32, NLD = TPC * NT * 2, LDS_ = CW + 8;
-    u32x4 v[NLD];
-    __device__ __forceinline__ void load(const nsd_rsrc r, const int gt0, const int lane) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int gtl = i / (2 * NT), rr = i % (2 * NT), nt = rr >> 1, half = rr & 1;
-            v[i] = ld_sc1_b128(r, (unsigned)((((((long)(gt0 + gtl) * NT + nt) * 2 + half) * 64 + lane) * 8) * 2));
-        }
-    }
-    __device__ __forceinline__ void to_strip(bf16_t *strip, const int lane) const {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int gtl = i / (2 * NT), rr = i % (2 * NT), nt = rr >> 1, half = rr & 1;
-            *reinterpret_cast<u32x4 *>(strip + (32 * nt + (lane >> 1)) * LDS_ + 32 * gtl + 16 * (lane & 1) + 8 * half) = v[i];
-        }
-    }
-};
-
 // ---- saved activations ----------------------------------------------------------------------------------------------------
 // cs / ga are private to a forward / backward pair of scans (lane (trial, hh) of wave w of member p owns the same 4 units in
 // both), so they are stored per owner instead of row-major: block (32-trial tile, member, step, wave) =
