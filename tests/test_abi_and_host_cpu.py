@@ -255,3 +255,20 @@ def test_default_model_path_is_checked_before_use(tmp_path, monkeypatch):
     monkeypatch.setenv("NSD_MODEL_PATH", str(p))
     assert tester.resolve_model_path(tester.DEFAULT_MODEL) == str(p)      # the default can be redirected
     assert tester.resolve_model_path(str(p)) == str(p)
+
+
+def test_bench_accounting_of_the_sequence_batched_configs():
+    """The roofline figures bench.py prints are algorithmic FLOP / bytes per launch of the dominant kernel: for cfg3 one launch of
+    the fused two-layer scan carries THREE H x 4H products per time step and trial (W_hh0, W_ih1, W_hh1), for cfg5 one launch
+    carries one layer's recurrent product in both directions."""
+    import bench
+    c3, c5 = bench.CONFIGS["cfg3"], bench.CONFIGS["cfg5"]
+    assert bench.fused_scans(c3) and bench.scan_kernel_names(c3) == ("scan2_fwd_kernel", "scan2_bwd_kernel")
+    assert not bench.fused_scans(c5) and bench.scan_kernel_names(c5) == ("scan_fwd_kernel", "scan_bwd_kernel")
+    a3 = bench.algorithmic(c3, c3["B"], c3["T"])
+    assert a3["bwd_flop"] == 3 * 2 * 250 * 4 * 256 * 256 * 1024 == 402653184000
+    assert a3["bwd_bytes"] == 2 * 250 * 2 * 256 * 2 * 1024          # h and c of both layers, bf16
+    a5 = bench.algorithmic(c5, c5["B"], c5["T"])
+    assert a5["bwd_flop"] == 2 * 1000 * 2 * 4 * 512 * 512 * 512
+    # the kernel-source hash that keys the recorded PMC traffic covers every file of the path
+    assert {"nsd_scan.hip", "nsd_scan2.hip", "nsd_scan_common.h", "nsd_gemm_bf16.hip", "nsd_seq.hip"} <= set(bench.KERNEL_SOURCES["bf16"])
