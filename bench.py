@@ -15,7 +15,12 @@ gradient is summed with ONE RCCL all-reduce per step):
   cfg3  5-class model, H=256, 1024 trials/GPU, bf16 operands / fp32 accumulation (BASELINE configs[2])
   cfg5  64 channels x 1000 steps, 2-layer bidirectional LSTM, H=512, 512 trials/GPU, bf16 (BASELINE configs[4] per GPU)
 
+`--gpus N` with N > 1 outside a torchrun environment starts the N ranks ITSELF: the parent process (which never touches a GPU)
+spawns one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and waits for them; rank 0 prints the line.
+
 ONE JSON line on rank 0.  Besides the driver's contract it carries
+  other_configs (default run only: cfg2 on one GPU) the same measurement -- value, ms_per_step, roofline, kernels_us -- for cfg3,
+                cfg4's per-GPU share and cfg5's per-GPU share, a few steps each, so that every BASELINE config is driver-timed
   preheat_steps untimed steps run before the W warm-up steps (GPU clock ramp)
   step_ms_events    median / min of the per-step duration measured with HIP events on the launch stream (second loop)
   roofline      dominant kernel (longest average launch): algorithmic FLOP per launch / its launch time measured live with
@@ -159,62 +164,77 @@ def event_times_ms(fn, n):
     return [a.elapsed_time(b) for a, b in evs]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch-per-gpu", type=int, default=None)
-    ap.add_argument("--T", type=int, default=None)
-    ap.add_argument("--preheat-steps", type=int, default=None, help="untimed steps before the warm-up steps (GPU clock ramp)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events and the extra points")
-    ap.add_argument("--no-extras", action="store_true", help="skip the inference / T=625 points")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+class _StubTrainer:
+    """NSD_BENCH_STUB=1 (CPU test of the launcher / rendezvous / timing / reporting code, tests/test_ddp_gloo_cpu.py): the step
+    is one small all-reduce over the process group and nothing else.  The line it produces says "data": "stub"."""
+
+    def __init__(self, world):
+        self.t = torch.zeros(1024)
+        self.world = world
+
+    def step(self, x, y):
+        if self.world > 1:
+            dist.all_reduce(self.t)
+        time.sleep(0.001)
+
+    def scan_status(self):
+        return 0
+
+    def last_loss(self):
+        return 0.0
+
+
+def _sync(stub):
+    if not stub:
+        torch.cuda.synchronize()
+
+
+def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extras, cpu_baseline, stub=False):
+    """Measure one config; returns the output dict on rank 0 (None elsewhere).  Raises SystemExit(3) on EVERY rank when a scan
+    group timed out on any rank."""
+    cfg = CONFIGS[name]
     small = cfg["precision"] == "fp32"
-    steps = args.steps if args.steps is not None else (200 if small else 20)
-    warmup = args.warmup if args.warmup is not None else (50 if small else 5)
-    preheat = args.preheat_steps if args.preheat_steps is not None else (500 if small else 10)
-
     import nsd_amd
-    from nsd_amd import ops
-    from nsd_amd.trainer import Trainer, init_distributed
-
-    rank, local, world = init_distributed()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    if os.environ.get("NSD_BENCH_ONE_GPU"):      # rehearsal only: all ranks on GPU 0 (with NSD_DIST_BACKEND=gloo)
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    nsd_amd.load_library()
+    from nsd_amd import _lib, ops
+    from nsd_amd.trainer import Trainer
 
     B, T = args.batch_per_gpu or cfg["B"], args.T or cfg["T"]
     C, H, L, K = cfg["C"], cfg["H"], cfg["L"], cfg["K"]
-    torch.manual_seed(4321)                       # identical initial weights on every rank (the Trainer broadcasts rank 0's anyway)
-    model = nsd_amd.EEG_LSTM(C, H, L, K, dropout=0.60, precision=cfg["precision"], bidirectional=cfg["bidirectional"])
-    wpath = os.path.join(ROOT, "tests", "golden", "weights_3class.npz")
-    weights = "seeded default init (torch.manual_seed(4321))"
-    if args.config in ("cfg2", "cfg4") and os.path.exists(wpath):
-        w = np.load(wpath)
-        model.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files}, strict=True)
-        weights = "reference checkpoint"
-    model.to(dev).train()
-    trainer = Trainer(model, lr=1e-3, seed=1234, stochastic=True)
-
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    x = (2.7 * torch.randn(B, T, C, generator=g)).to(dev)
-    y = torch.randint(0, K, (B,), generator=g).to(torch.int32).to(dev)
+    weights = "seeded default init (torch.manual_seed(4321))"
+    if stub:
+        model, trainer, x, y = None, _StubTrainer(world), None, None
+    else:
+        torch.manual_seed(4321)                   # identical initial weights on every rank (the Trainer broadcasts rank 0's anyway)
+        model = nsd_amd.EEG_LSTM(C, H, L, K, dropout=0.60, precision=cfg["precision"], bidirectional=cfg["bidirectional"])
+        wpath = os.path.join(ROOT, "tests", "golden", "weights_3class.npz")
+        if name in ("cfg2", "cfg4") and os.path.exists(wpath):
+            w = np.load(wpath)
+            model.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files}, strict=True)
+            weights = "reference checkpoint"
+        model.to(dev).train()
+        trainer = Trainer(model, lr=1e-3, seed=1234, stochastic=True)
+        x = (2.7 * torch.randn(B, T, C, generator=g)).to(dev)
+        y = torch.randint(0, K, (B,), generator=g).to(torch.int32).to(dev)
 
     def note(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    def check_status(where):
+        """A scan time-out on ANY rank ends the run on EVERY rank (the ranks agree on the status before anyone leaves)."""
+        st = int(trainer.scan_status())
+        if world > 1:
+            t = torch.tensor([st], dtype=torch.int32, device=dev if not stub else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            st = int(t.item())
+        if st != 0:
+            if rank == 0:
+                print(f"bench.py: scan status {st} {where} (a scan group timed out on some rank): results invalid", file=sys.stderr)
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            raise SystemExit(3)
 
     do_step = lambda: trainer.step(x, y)
     # clock ramp: the GPU reaches its sustained clock only after some tens of milliseconds of load; run the same step untimed
@@ -222,20 +242,18 @@ def main():
     # a time budget: with more than one rank every step contains a collective, so all ranks must run the same number of them.
     for _ in range(max(preheat, 0)):
         do_step()
-    torch.cuda.synchronize()
-    note(f"{args.config}: warm-up {warmup} steps of B={B}/GPU T={T} on {world} GPU(s)")
+    _sync(stub)
+    note(f"{name}: warm-up {warmup} steps of B={B}/GPU T={T} on {world} GPU(s)")
     for _ in range(max(warmup, 1)):
         do_step()
-    torch.cuda.synchronize()
-    if trainer.scan_status() != 0:
-        print(f"bench.py: scan status {trainer.scan_status()} (a scan group timed out): results invalid", file=sys.stderr)
-        sys.exit(3)
+    _sync(stub)
+    check_status("after the warm-up")
     note("timing")
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync(stub)
 
     barrier()
     t0 = time.perf_counter()
@@ -243,12 +261,13 @@ def main():
         do_step()
     barrier()
     dt = time.perf_counter() - t0
+    check_status("after the timed loop")
     loss = trainer.last_loss()
 
     # second loop of the same K steps: per-step HIP events + per-kernel HIP events on the launch stream (kept out of the
     # timed region so that recording does not perturb `value`); profiles/ holds the rocprofv3 summary of the same command
     step_ms, kern_us = None, {}
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and not stub:
         step_ms = event_times_ms(do_step, steps)
         if small:
             timer = KernelTimer(["nsd_lstm_head_train_rng", "nsd_lstm_head_train", "nsd_lstm_fwd", "nsd_lstm_bwd_rng", "nsd_lstm_bwd",
@@ -260,29 +279,38 @@ def main():
             ops.set_launch_hook(None)
             kern_us = {k: v for k, v in timer.mean_us().items() if v is not None}
         else:
-            ops.seq_profile(True)
-            for _ in range(steps):
-                do_step()
-            torch.cuda.synchronize()
-            kern_us = {k: 1e3 * ms / n for k, (ms, n) in ops.seq_profile_read().items() if n}
-            ops.seq_profile(False)
+            # the sequence-batched path issues many kernels per C call: their per-launch HIP events live in the DIAGNOSTIC twin of
+            # the library (csrc/nsd_diag.h: same objects, orchestration compiled with -DNSD_DIAG=1) -- this loop, outside the
+            # timed region, runs through it; profiles/ holds rocprofv3's durations of the PRODUCT library for the same kernels
+            with _lib.diagnostic_library():
+                do_step()                                       # (code-object load of the twin)
+                torch.cuda.synchronize()
+                ops.seq_profile(True)
+                for _ in range(steps):
+                    do_step()
+                torch.cuda.synchronize()
+                kern_us = {k: 1e3 * ms / n for k, (ms, n) in ops.seq_profile_read().items() if n}
+                ops.seq_profile(False)
+            check_status("after the per-kernel timing loop")
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if not stub else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    out = None
     if rank == 0:
         alg = algorithmic(cfg, B, T)
         peak = PEAK_TFLOPS[cfg["dtype"]]
         ms_per_step = 1e3 * dt / steps
         value = world * B * steps / dt
         out = {
-            "metric": "EEG-trials/sec (train fwd+bwd)", "value": round(value, 1), "unit": "trials/s",
+            "metric": "EEG-trials/sec (train fwd+bwd)" if not stub else "STUB: launcher / rendezvous rehearsal, not a measurement",
+            "value": round(value, 1), "unit": "trials/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "stub" if stub else "synthetic",
             "preheat_steps": preheat,
-            "config": {"workload": f"{cfg['text']}, batch {B}/GPU", "name": args.config,
+            "config": {"workload": f"{cfg['text']}, batch {B}/GPU", "name": name,
                        "batch_per_gpu": B, "global_batch": B * world, "T": T, "C": C, "H": H, "L": L, "K": K,
                        "bidirectional": cfg["bidirectional"], "weights": weights, "parallelism": f"dp{world}",
                        "loss_last_step": round(loss, 5), "launch": "eager"},
@@ -298,23 +326,20 @@ def main():
                 bound = "fp32-valu"
                 why = ("fp32 path: arithmetic intensity ~110 FLOP/B >> ridge (~20) so the compute roof binds, not HBM; peak = 157.3 "
                        "TFLOP/s fp32 (packed-FMA vector rate == f32 MFMA rate on gfx950); the kernels are v_pk_fma_f32 (VALU) "
-                       "recurrences, one trial per CU at this batch, bound by instruction issue + the LDS hand-off of h per step; "
+                       "recurrences bound by instruction issue + the LDS hand-off of h per step; "
                        "north_star's 40 % of HBM is out of reach for H=48 by construction (at the fp32 peak the step would still "
                        "take 71 us = 18 % of 8 TB/s for its algorithmic bytes): see `hbm` for the measured HBM view")
             else:
                 fwd_key, bwd_key = "scan_fwd", "scan_bwd"
                 names = dict(zip((fwd_key, bwd_key), scan_kernel_names(cfg)))
                 bound = "mfma"
-                why = ("bf16 path: peak = 2.5 PFLOP/s dense bf16 MFMA; the persistent scan kernels hold the recurrent weights in registers "
-                       "and are bound by the chain of one time step (flag poll -> exchange loads through the L2 -> cell -> LDS -> 48-64 "
-                       "MFMAs -> exchange stores -> drain -> flag; T + 1 serial steps per launch), not by the matrix pipe or HBM: both "
-                       "fractions are printed; a step of the fused backward scan is ~11 000 cycles of which the MFMAs need 1 540")
+                why = SEQ_ROOFLINE_NOTE
             dom = max((fwd_key, bwd_key), key=lambda n: kern_us[n])
             t_s = kern_us[dom] * 1e-6
             fl = alg["fwd_flop"] if dom == fwd_key else alg["bwd_flop"]
             by = alg["fwd_bytes"] if dom == fwd_key else alg["bwd_bytes"]
             tf, gbs = fl / t_s / 1e12, by / t_s / 1e9
-            traffic, tsrc = recorded_traffic(args.config, cfg["precision"], names[dom], B, T)
+            traffic, tsrc = recorded_traffic(name, cfg["precision"], names[dom], B, T)
             out["roofline"] = {
                 "kernel": names[dom], "bound": bound, "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(tf / peak, 4), "traffic": traffic, "traffic_source": tsrc,
@@ -323,13 +348,16 @@ def main():
                         "algorithmic_bytes_per_launch": by},
                 "note": why,
             }
+            if traffic:
+                out["roofline"]["traffic_over_algorithmic"] = round(traffic / by, 2)
+                out["roofline"]["hbm"]["measured_traffic_GBps"] = round(traffic / t_s / 1e9, 1)
             out["kernels_us"] = {k: round(v, 2) for k, v in kern_us.items()}
             out["step_frac_of_peak"] = round(alg["flop_train"] / (ms_per_step * 1e-3) / 1e12 / peak, 4)
             out["step_hbm_frac"] = round(alg["bytes_train"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        note(f"GPU: {value:.0f} trials/s, {ms_per_step:.3f} ms/step")
+        note(f"{name} GPU: {value:.0f} trials/s, {ms_per_step:.3f} ms/step")
 
         # ---- further points of SURVEY 8(d) (one GPU only; bounded) -------------------------------------------------------
-        if world == 1 and not args.no_extras and not args.no_kernel_timing:
+        if world == 1 and extras and not args.no_kernel_timing and not stub:
             model.eval()
             with torch.no_grad():
                 for _ in range(5):
@@ -352,12 +380,12 @@ def main():
                 out["T625"] = {"B": B, "T": 625, "median_ms_per_step": round(statistics.median(ms6), 4),
                                "trials_per_s": round(B / (statistics.median(ms6) * 1e-3), 1)}
 
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and cpu_baseline and not stub:
             note("timing the PyTorch-CPU baseline")
             from oracle.torch_ref import host_cores, time_cpu_train
             # a BOUNDED sample of the same workload: the full batch where a step takes a fraction of a second, a slice of
             # the batch for the large models (the CPU rate per trial does not depend on the batch beyond oneDNN's blocking)
-            Bs = B if small else (64 if args.config == "cfg3" else 4)
+            Bs = B if small else (64 if name == "cfg3" else 4)
             kw = dict(B=Bs, T=T, C=C, H=H, L=L, K=K, stacked=True, bidirectional=cfg["bidirectional"])
             cpu = time_cpu_train(budget_s=args.cpu_budget_s, **kw)
             cpu1 = time_cpu_train(threads=1, budget_s=args.cpu_budget_s / 2, min_steps=2, **kw)
@@ -370,6 +398,108 @@ def main():
                                    "one_thread": {"value": round(cpu1["trials_per_s"], 1), "cores": 1,
                                                   "sample": f"{cpu1['steps']} steps, median {cpu1['ms_per_step']:.1f} ms/step"}}
             out["speedup_vs_cpu"] = round(value / cpu["trials_per_s"], 1)
+    # release this config's buffers (the workspaces are large: 22.7 GB at cfg5) before the next one is measured
+    del trainer, model, x, y
+    if not stub:
+        torch.cuda.empty_cache()
+    return out
+
+
+SEQ_ROOFLINE_NOTE = ("bf16 path: peak = 2.5 PFLOP/s dense bf16 MFMA; the persistent scan kernels hold the recurrent weights in registers; a "
+                     "launch is T + 1 serial steps (flag poll -> exchange loads through the L2 -> cell -> LDS -> 48-64 MFMAs -> exchange "
+                     "stores -> drain -> flag), so the achieved fraction is set by the length of one step's chain and by the fabric "
+                     "traffic of the exchange (`traffic_over_algorithmic`), not by the matrix pipe")
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a torchrun environment: this parent process, which has not touched and never touches a
+    GPU, starts one child per GPU with the rendezvous environment torchrun would set, and waits.  Rank 0 prints the JSON line on
+    the inherited stdout.  Returns the exit code (the first non-zero child code; the remaining children are then ended)."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:                                  # a rank failed: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--T", type=int, default=None)
+    ap.add_argument("--preheat-steps", type=int, default=None, help="untimed steps before the warm-up steps (GPU clock ramp)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events and the extra points")
+    ap.add_argument("--no-extras", action="store_true", help="skip the inference / T=625 points")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the cfg3 / cfg4 / cfg5 measurements")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))          # (nothing above has initialised a GPU: importing torch does not)
+    stub = bool(os.environ.get("NSD_BENCH_STUB"))
+    cfg = CONFIGS[args.config]
+    small = cfg["precision"] == "fp32"
+    steps = args.steps if args.steps is not None else (200 if small else 20)
+    warmup = args.warmup if args.warmup is not None else (50 if small else 5)
+    preheat = args.preheat_steps if args.preheat_steps is not None else (500 if small else 10)
+
+    import nsd_amd
+    from nsd_amd.trainer import init_distributed
+
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    dev = None
+    if not stub:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        if os.environ.get("NSD_BENCH_ONE_GPU"):      # rehearsal only: all ranks on GPU 0 (with NSD_DIST_BACKEND=gloo)
+            local = 0
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        nsd_amd.load_library()
+
+    out = run_config(args.config, args, rank, local, world, dev, steps, warmup, preheat, extras=not args.no_extras,
+                     cpu_baseline=not args.no_cpu_baseline, stub=stub)
+
+    # the driver runs `bench.py --gpus 1 --steps K --warmup W` = cfg2; the other BASELINE configs ride in the same line so that
+    # their numbers are driver-timed too (a few steps each, no CPU leg: ~10 s in all)
+    if (world == 1 and args.config == "cfg2" and not args.no_other_configs and not stub and args.batch_per_gpu is None
+            and args.T is None and not args.no_kernel_timing):
+        others = {}
+        for name, (k, w, ph) in (("cfg3", (20, 5, 10)), ("cfg4", (100, 20, 200)), ("cfg5", (8, 2, 3))):
+            o = run_config(name, args, rank, local, world, dev, k, w, ph, extras=False, cpu_baseline=False)
+            others[name] = {key: o[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "step_ms_events",
+                                                    "roofline", "kernels_us", "step_frac_of_peak", "step_hbm_frac") if key in o}
+        out["other_configs"] = others
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define NSD_VERSION 200          /* 0.2.0: every entry point that touches the training workspace takes its size */
+#define NSD_VERSION 300          /* 0.3.0: sequence-batched path: persistent workspace header (nsd_seq_workspace_init), sticky
+                                    status, nsd_seq_guard / nsd_adam_step_guarded; diagnostics left the shipped library */
 #define NSD_MAX_LAYERS 8
 
 #define NSD_OK            0
@@ -52,12 +53,6 @@ extern "C" {
 #define NSD_FLAG_TRAIN      2u   /* keep activations in the workspace for nsd_*_bwd */
 #define NSD_FLAG_BIDIR      8u   /* nsd_seq_* entry points only: bidirectional LSTM (torch.nn.LSTM(bidirectional=True)); the
                                     sequence fed to the attention pooling and the head is 2H wide */
-#define NSD_FLAG_NO_L2_EXCHANGE 16u /* nsd_seq_* only, diagnostics: scan groups always use the write-through exchange, also when
-                                    all their workgroups report the same XCD (results are identical either way) */
-#define NSD_FLAG_SPREAD_GROUPS 32u /* nsd_seq_* only, diagnostics: give the workgroups of a scan group consecutive block ids, i.e.
-                                    spread every group over all XCDs (exercises the write-through exchange for real) */
-#define NSD_FLAG_NO_FUSED_LAYERS 64u /* nsd_seq_* only, diagnostics: two unidirectional layers as two scans + GEMMs (the general
-                                    route) instead of the single skewed launch */
 #define NSD_FLAG_BF16       4u   /* large-H batched path only (H % 16 == 0, H >= 64, B >= 16; ignored elsewhere): GEMM operands
                                     rounded to bf16 at the matrix pipe (fp32 accumulate, fp32 storage and cell arithmetic) --
                                     BASELINE cfg3's precision; results differ from fp32 at the 1e-2 level */
@@ -205,6 +200,9 @@ int nsd_loss_sum(const nsd_dims *d, const float *workspace, int64_t workspace_by
 /* torch.optim.Adam semantics (no amsgrad); step counted from 1; all vectors length n */
 int nsd_adam_step(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float grad_scale, int32_t step, void *stream);
+/* the same update, skipped entirely (p, m, v untouched) when the device flag skip[0] != 0: see nsd_seq_guard */
+int nsd_adam_step_guarded(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, float grad_scale, int32_t step, const float *skip, void *stream);
 
 /*
  * Counter-based random streams of the trainer (the reference's training RNG is torch's and is not
@@ -265,9 +263,19 @@ int nsd_gemm_bf16(const void *A, int64_t lda, int32_t a_kmajor, const void *B, i
  *   nsd_seq_train_fwd   forward + head + mean CE (scale = 1/B_global) + head backward; logits[B,K] written
  *   nsd_seq_train_bwd   BPTT + all parameter gradients -> grads[P] (overwritten), same rng as the forward call
  *   nsd_seq_loss_sum    sum of the per-trial CE losses of the last nsd_seq_train_fwd -> out[0] (device)
- *   nsd_seq_status      BLOCKING: status_out[4] = {0 ok | 1 / 2 a forward / backward scan group timed out waiting for one of
- *                       its workgroups (results are then invalid), reserved, scan groups (over all scan launches since the last
- *                       nsd_seq_train_fwd / nsd_seq_infer) whose workgroups all reported ONE XCD, groups spread over several}
+ * Failure reporting (the persistent scan kernels assume that all workgroups of a scan group are resident at once -- true on an
+ * MI355X this process has to itself; a CU mask, another process or a partition mode can break it -- and bound every wait: a group
+ * that cannot assemble gives up after ~1-2 s).  A time-out is never silent:
+ *   - the workspace starts with a persistent header whose first word is a STICKY status (OR of every time-out code; bit 0 a
+ *     forward, bit 1 a backward scan).  nsd_seq_workspace_init zeroes it: call it once after allocating the workspace (an
+ *     uninitialised header reads as a failure).  No forward / backward call ever clears it.
+ *   - logits, probs and the per-trial loss of an evaluation on a workspace that reports a time-out are NaN.
+ *   nsd_seq_status      BLOCKING: status_out[4] = {code of the last evaluation OR the sticky word (0 = ok), the sticky word alone,
+ *                       scan groups (over all scan launches since the last nsd_seq_train_fwd / nsd_seq_infer) whose workgroups
+ *                       all reported ONE XCD, groups spread over several}
+ *   nsd_seq_guard       enqueued: flag_out[0] (device fp32) = 1 if the workspace reports a time-out, else 0.  Append it to the
+ *                       gradient vector that is all-reduced and hand it to nsd_adam_step_guarded: every rank then skips the
+ *                       update when any rank's gradient is garbage.
  */
 int64_t nsd_seq_param_count(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int32_t D);
 int     nsd_seq_param_layout(int32_t C, int32_t H, int32_t L, int32_t K, int32_t F, int32_t D, int64_t *offsets);
@@ -280,15 +288,9 @@ int nsd_seq_train_fwd(const nsd_dims *d, const float *params, const float *x, co
 int nsd_seq_train_bwd(const nsd_dims *d, const float *params, const nsd_rng *rng, uint32_t flags, void *workspace,
                       int64_t workspace_bytes, float *grads, void *stream);
 int nsd_seq_loss_sum(const nsd_dims *d, uint32_t flags, const void *workspace, int64_t workspace_bytes, float *out, void *stream);
+int nsd_seq_workspace_init(void *workspace, int64_t workspace_bytes, void *stream);
 int nsd_seq_status(const void *workspace, int32_t *status_out, void *stream);
-/* Opt-in launch timing for benchmarks (off by default, nothing is recorded): nsd_seq_profile(1) records HIP events on the
- * launch stream around the kernels of every following nsd_seq_* call, nsd_seq_profile(0) stops and discards;
- * nsd_seq_profile_read sums the records of one kind and forgets them (BLOCKING).  kind: 0 forward scan, 1 backward scan,
- * 2 input-projection GEMM, 3 weight-gradient GEMMs, 4 input-gradient GEMM, 5 head, 6 head parameter gradients, 7 operand
- * preparation. */
-int nsd_seq_profile(int32_t enable);
-int nsd_seq_profile_read(int32_t kind, float *total_ms, int32_t *count);
-
+int nsd_seq_guard(const void *workspace, float *flag_out, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -517,7 +517,13 @@ int nsd_loss_sum(const nsd_dims *d, const float *workspace, int64_t workspace_by
 int nsd_adam_step(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float grad_scale, int32_t step, void *stream) {
     if (n < 0 || !p || !g || !m || !v) { nsd_set_error("adam: null pointer or n<0"); return NSD_E_INVALID; }
-    return nsd_adam_launch(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step, (hipStream_t)stream);
+    return nsd_adam_launch(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step, nullptr, (hipStream_t)stream);
+}
+
+int nsd_adam_step_guarded(int64_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, float grad_scale, int32_t step, const float *skip, void *stream) {
+    if (n < 0 || !p || !g || !m || !v || !skip) { nsd_set_error("adam_guarded: null pointer or n<0"); return NSD_E_INVALID; }
+    return nsd_adam_launch(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step, skip, (hipStream_t)stream);
 }
 
 int nsd_train_masks(uint64_t seed, uint32_t base_stream, float p_lstm, float p_head, int64_t n_lstm, float *drop_lstm,

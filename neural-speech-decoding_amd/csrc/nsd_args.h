@@ -92,7 +92,8 @@ int nsd_grad_reduce_adam_launch(const float *slabs, long slab_stride, int n_slab
                                 long ph, int n_hslabs, float *grads, float *p, float *m, float *v, float lr, float b1,
                                 float b2, float eps, float wd, float gscale, int step, hipStream_t st);
 int nsd_adam_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
-                    float wd, float gscale, int step, hipStream_t st);
+                    float wd, float gscale, int step, const float *skip, hipStream_t st);
+int nsd_seq_guard_launch(const int *header, int status_word, float *flag_out, hipStream_t st);
 int nsd_dropout_mask_launch(uint64_t seed, uint32_t stream_id, float p, long n, float *out, hipStream_t st);
 int nsd_train_masks_launch(uint64_t seed, uint32_t base, const long long *step_dev, float p_lstm, float p_head, long n_lstm,
                            float *drop_lstm, long n_head, float *rrelu, float *drop_head, hipStream_t st);

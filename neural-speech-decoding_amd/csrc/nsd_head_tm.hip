@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
     const int b = blockIdx.x * 4 + wave;
     if (b >= a.B) return;                                       // whole waves leave; nothing below needs the workgroup
     const int c0 = lane * VPL, T = a.T, F = a.F, K = a.K;
+    // a scan group of this evaluation (or of an earlier one on this workspace) timed out: the sequence below is garbage
+    const bool bad = a.status != nullptr && (a.status[0] | a.status[-NSD_SEQ_HEADER_WORDS]) != 0;
     float aw[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) aw[v] = a.attn_w[c0 + v];
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
         const float tot = wave_sum(lane < F ? act * a.fc3_w[(long)k * F + lane] : 0.f);
         if (lane == k) logit = tot + a.fc3_b[k];
     }
+    if (bad) logit = __uint_as_float(0x7fc00000u);              // NaN: logits, probabilities and the loss all carry it
     if (lane < K) a.logits[(long)b * K + lane] = logit;
     const float lmax = wave_max(logit);
     const float ex = lane < K ? __expf(logit - lmax) : 0.f;

@@ -144,8 +144,11 @@ int nsd_grad_reduce_adam_launch(const float *slabs, long slab_stride, int n_slab
 // Adam (torch.optim.Adam, amsgrad=False).  g is multiplied by grad_scale first (1/world_size after a
 // SUM all-reduce).
 // ---------------------------------------------------------------------------------------------
+// skip: null, or a device flag -- a non-zero value leaves p, m, v untouched (nsd_adam_step_guarded: the gradient is known to be
+// garbage, e.g. a scan group of the sequence-batched path timed out on some rank)
 __global__ void adam_kernel(long n, float *p, const float *g, float *m, float *v, float lr_over_bc1, float rsqrt_bc2,
-                            float beta1, float beta2, float eps, float wd, float gscale) {
+                            float beta1, float beta2, float eps, float wd, float gscale, const float *skip) {
+    if (skip != nullptr && skip[0] != 0.f) return;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float pi = p[i];
         const float gi = fmaf(wd, pi, g[i] * gscale);
@@ -189,14 +192,23 @@ int nsd_step_inc_launch(long long *step_dev, hipStream_t st) {
     return NSD_OK;
 }
 
+__global__ void seq_guard_kernel(const int *header, int status_word, float *flag_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) flag_out[0] = (header[0] | header[status_word]) != 0 ? 1.f : 0.f;
+}
+int nsd_seq_guard_launch(const int *header, int status_word, float *flag_out, hipStream_t st) {
+    hipLaunchKernelGGL(seq_guard_kernel, dim3(1), dim3(64), 0, st, header, status_word, flag_out);
+    NSD_CHECK_LAUNCH("seq_guard");
+    return NSD_OK;
+}
+
 int nsd_adam_launch(long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps,
-                    float wd, float gscale, int step, hipStream_t st) {
+                    float wd, float gscale, int step, const float *skip, hipStream_t st) {
     if (n <= 0) return NSD_OK;
     if (step < 1) { nsd_set_error("adam: step must be >= 1"); return NSD_E_INVALID; }
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, p, g, m, v, (float)(lr / bc1),
-                       (float)(1.0 / sqrt(bc2)), b1, b2, eps, wd, gscale);
+                       (float)(1.0 / sqrt(bc2)), b1, b2, eps, wd, gscale, skip);
     NSD_CHECK_LAUNCH("adam");
     return NSD_OK;
 }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 
     unsigned *gflags = a.flags + (long)(dir * a.groups + me.group) * GROUP_WORDS;
     const int rv = group_rendezvous<P>(gflags, me.p, wave, lane);
-    if (rv < 0 && lane == 0) { s_abort = 1; atomicExch(a.status, ST_FWD_TIMEOUT); }
+    if (rv < 0 && lane == 0) { s_abort = 1; report_timeout(a.status, ST_FWD_TIMEOUT); }
     __syncthreads();
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
             bf16_t *Bt = Bt2[s & 1];
             if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
                 s_abort = 1;                                    // (the wave still walks to the barrier below: the exit is uniform)
-                atomicExch(a.status, ST_FWD_TIMEOUT);
+                report_timeout(a.status, ST_FWD_TIMEOUT);
             }
             // gather h_{t-1} of the whole tile (all H units) from the exchange ring: the block of a batch tile is laid out [gate tile
             // = 4p + wave][nt][trial][8 units] -- every producer wave writes whole 128-byte lines with one store instruction, and a
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 
     unsigned *gflags = a.flags + (long)(dir * a.groups + me.group) * GROUP_WORDS;
     const int rv = group_rendezvous<P>(gflags, me.p, wave, lane);
-    if (rv < 0 && lane == 0) { s_abort = 1; atomicExch(a.status, ST_BWD_TIMEOUT); }
+    if (rv < 0 && lane == 0) { s_abort = 1; report_timeout(a.status, ST_BWD_TIMEOUT); }
     __syncthreads();
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
         if (s > 0) {
             if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
                 s_abort = 1;
-                atomicExch(a.status, ST_BWD_TIMEOUT);
+                report_timeout(a.status, ST_BWD_TIMEOUT);
             }
             stp.mark(0);
             // the partial sums the P members sent this wave at step s-1, added in member order
@@ -601,7 +601,7 @@ static int check_grid(const char *who, int H, int MG, int groups, int D) {
 
 int nsd_scan_fwd_launch(const ScanFwdArgs &a, int H, int MG, hipStream_t st) {
     if (const int rc = check_grid("scan_fwd", H, MG, a.groups, a.D)) return rc;
-    const dim3 grid(a.D * a.groups * (H / 32));
+    const dim3 grid(a.D * a.groups * (H / 32) - a.diag_short_grid);
     switch (H) {
     case 64: return launch_fwd_h<64>(a, MG, grid, st);
     case 128: return launch_fwd_h<128>(a, MG, grid, st);
@@ -611,7 +611,7 @@ int nsd_scan_fwd_launch(const ScanFwdArgs &a, int H, int MG, hipStream_t st) {
 }
 int nsd_scan_bwd_launch(const ScanBwdArgs &a, int H, int MG, hipStream_t st) {
     if (const int rc = check_grid("scan_bwd", H, MG, a.groups, a.D)) return rc;
-    const dim3 grid(a.D * a.groups * (H / 32));
+    const dim3 grid(a.D * a.groups * (H / 32) - a.diag_short_grid);
     switch (H) {
     case 64: return launch_bwd_h<64>(a, MG, grid, st);
     case 128: return launch_bwd_h<128>(a, MG, grid, st);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
 
     unsigned *gflags = a.flags + (long)me.group * GROUP_WORDS;
     const int rv = group_rendezvous<P>(gflags, me.p, wave, lane);
-    if (rv < 0 && lane == 0) { s_abort = 1; atomicExch(a.status, ST2_FWD_TIMEOUT); }
+    if (rv < 0 && lane == 0) { s_abort = 1; report_timeout(a.status, ST2_FWD_TIMEOUT); }
     __syncthreads();
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         if (s >= 1) {
             if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
                 s_abort = 1;
-                atomicExch(a.status, ST2_FWD_TIMEOUT);
+                report_timeout(a.status, ST2_FWD_TIMEOUT);
             }
             stp.mark(0);
             // the exchange ring: per tensor and step parity one block of MG*H bf16 per batch tile, laid out [gate tile = 4p+wave]
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
 
     unsigned *gflags = a.flags + (long)me.group * GROUP_WORDS;
     const int rv = group_rendezvous<P>(gflags, me.p, wave, lane);
-    if (rv < 0 && lane == 0) { s_abort = 1; atomicExch(a.status, ST2_BWD_TIMEOUT); }
+    if (rv < 0 && lane == 0) { s_abort = 1; report_timeout(a.status, ST2_BWD_TIMEOUT); }
     __syncthreads();
     if (s_abort) return;
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
         if (s >= 1) {
             if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
                 s_abort = 1;
-                atomicExch(a.status, ST2_BWD_TIMEOUT);
+                report_timeout(a.status, ST2_BWD_TIMEOUT);
             }
             stp.mark(0);
             // the partial sums the P members sent this wave at step s-1, added in member order
@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
 // LDS of the forward kernel: 2 x 3 tiles of MG x (H + 8) bf16; of the backward kernel: 32 KB x NT (the workgroup's own da as B operands)
 bool nsd_scan2_supported(int H, int MG) {
     if (!(H == 64 || H == 128 || H == 256)) return false;
+    if (MG != 32) return false;                                  // only the 32-trial instantiations are built: larger batches take the layer-by-layer scans
     const long fwd = 2L * 3 * MG * (H + 8) * 2, bwd = 2L * 2 * 8 * (MG / 32) * 1024;
     return fwd <= 150 * 1024 && bwd <= 150 * 1024;
 }
@@ -567,7 +568,7 @@ static int launch2_bwd(const Scan2BwdArgs &a, int MG, const dim3 grid, hipStream
 
 int nsd_scan2_fwd_launch(const Scan2FwdArgs &a, int H, int MG, hipStream_t st) {
     if (!nsd_scan2_supported(H, MG) || a.groups * (H / 32) > nsd_num_cus()) { nsd_set_error("scan2_fwd: unsupported geometry H=%d MG=%d groups=%d", H, MG, a.groups); return NSD_E_INVALID; }
-    const dim3 grid(a.groups * (H / 32));
+    const dim3 grid(a.groups * (H / 32) - a.diag_short_grid);
     switch (H) {
     case 64: return launch2_fwd<64>(a, MG, grid, st);
     case 128: return launch2_fwd<128>(a, MG, grid, st);
@@ -576,7 +577,7 @@ int nsd_scan2_fwd_launch(const Scan2FwdArgs &a, int H, int MG, hipStream_t st) {
 }
 int nsd_scan2_bwd_launch(const Scan2BwdArgs &a, int H, int MG, hipStream_t st) {
     if (!nsd_scan2_supported(H, MG) || a.groups * (H / 32) > nsd_num_cus()) { nsd_set_error("scan2_bwd: unsupported geometry H=%d MG=%d groups=%d", H, MG, a.groups); return NSD_E_INVALID; }
-    const dim3 grid(a.groups * (H / 32));
+    const dim3 grid(a.groups * (H / 32) - a.diag_short_grid);
     switch (H) {
     case 64: return launch2_bwd<64>(a, MG, grid, st);
     case 128: return launch2_bwd<128>(a, MG, grid, st);

@@ -41,6 +41,12 @@ struct Stamps {
 
 constexpr unsigned SPIN_LIMIT = 1u << 20;          // polls (each >= ~1 us with the sleep): ~1-2 s, then give up
 constexpr int ST_FWD_TIMEOUT = 1, ST_BWD_TIMEOUT = 2;
+// a scan group gave up: the code goes into the status word of the evaluation AND into the workspace's sticky word (never cleared
+// by a forward call: the caller sees the failure whenever it looks, and the guarded Adam update skips until it does)
+__device__ __forceinline__ void report_timeout(int *status, const int code) {
+    atomicExch(status, code);
+    atomicOr(status - NSD_SEQ_HEADER_WORDS, code);
+}
 constexpr int GROUP_WORDS = 128;                   // flag words per group: [0,64) one per wave of every member, [64,80) XCC ids
 
 // ---------------------------------------------------------------------------------------------------------------------------

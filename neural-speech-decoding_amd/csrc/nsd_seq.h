@@ -25,7 +25,12 @@
 #define NSD_SEQ_MAX_DIRS 2
 
 __host__ __device__ __forceinline__ long seq_row(const int t, const int b, const int T) { return ((long)(b >> 5) * T + t) * 32 + (b & 31); }
-#define NSD_SEQ_STATUS_WORDS 16
+#define NSD_SEQ_STATUS_WORDS 32
+// The workspace starts with a persistent header of NSD_SEQ_HEADER_BYTES (word 0: STICKY status = OR of every time-out code since
+// nsd_seq_workspace_init; never cleared by a forward call), followed by the status words of the evaluation in flight (cleared by
+// every forward call): [0] status, [2] / [3] scan groups on one XCD / spread, [4..] diagnostic stamps.
+#define NSD_SEQ_HEADER_BYTES 256
+#define NSD_SEQ_HEADER_WORDS (NSD_SEQ_HEADER_BYTES / 4)
 
 struct SeqDims {
     int B, T, C, H, L, K, F, D;
@@ -43,7 +48,7 @@ SeqParamLayout nsd_seq_make_layout(int C, int H, int L, int K, int F, int D);
 
 // byte offsets inside the caller's workspace
 struct SeqWs {
-    int64_t status, flags;                                       // int32[16]; uint32 [L][D][groups][16] + backward copy
+    int64_t status, flags;                                       // int32[32] behind the persistent header; uint32 [L][D][groups][128] + backward copy
     int64_t xbf;
     int64_t wf[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS], wb[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS], wx[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS];
     int64_t wxt[NSD_MAX_LAYERS], bsum[NSD_MAX_LAYERS][NSD_SEQ_MAX_DIRS];
@@ -78,6 +83,7 @@ struct ScanFwdArgs {
     int allow_l2_mode;                       // 0: always the write-through exchange (tests: both modes must agree)
     int spread_groups;                       // diagnostics: consecutive block ids per group = a group spread over all XCDs
     RngArgs rng;                             // rng.on: multiplier of stream rng.base on this layer's output
+    int diag_short_grid;                     // diagnostic build only (forced time-out test): launch this many workgroups fewer
 };
 struct ScanBwdArgs {
     const bf16_t *wb[NSD_SEQ_MAX_DIRS];      // [H][4H] recurrent weights transposed, k = unit-major gate column
@@ -95,6 +101,7 @@ struct ScanBwdArgs {
     int B, Bp, T, D, ld, groups, group0, groups_total, layer;
     int allow_l2_mode, spread_groups;
     RngArgs rng;
+    int diag_short_grid;                     // diagnostic build only (forced time-out test): launch this many workgroups fewer
 };
 // two unidirectional layers in ONE launch, layer 1 one time step behind layer 0 (nsd_scan2.hip): half the serial steps, the
 // input projection of layer 1 and the input gradient of layer 1 ride in the scans (no GEMM, no xproj / din round trip)
@@ -114,6 +121,7 @@ struct Scan2FwdArgs {
     int B, Bp, T, groups, group0;
     int allow_l2_mode, spread_groups;
     RngArgs rng;
+    int diag_short_grid;                     // diagnostic build only (forced time-out test): launch this many workgroups fewer
 };
 struct Scan2BwdArgs {
     const bf16_t *wb0, *wb1, *wxt1;          // [H][4H] each: W_hh0^T, W_hh1^T, W_ih1^T (k = unit-major gate column)
@@ -127,6 +135,7 @@ struct Scan2BwdArgs {
     int B, Bp, T, groups, group0, groups_total;
     int allow_l2_mode, spread_groups;
     RngArgs rng;                             // rng.on: multiplier of layer 0's output
+    int diag_short_grid;                     // diagnostic build only (forced time-out test): launch this many workgroups fewer
 };
 bool nsd_scan2_supported(int H, int MG);
 int nsd_scan2_fwd_launch(const Scan2FwdArgs &a, int H, int MG, hipStream_t st);
@@ -161,6 +170,8 @@ struct HeadTmArgs {
     float *hb;                               // per-trial rows for the parameter-gradient reductions, stride hb_stride
     long hb_stride;
     int B, Bp, T, DH, F, K, train;
+    const int *status;                       // status words of the evaluation (sticky word NSD_SEQ_HEADER_WORDS before): a scan time-out
+                                             // poisons logits / probs / loss with NaN -- nothing downstream can mistake garbage for a result
 };
 int nsd_head_tm_launch(const HeadTmArgs &a, hipStream_t st);
 // head parameter gradients from the per-trial rows: grads_head points at ln.weight inside the flat gradient vector

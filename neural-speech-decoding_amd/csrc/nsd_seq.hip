@@ -7,12 +7,15 @@
 #include <vector>
 #include "nsd_seq.h"
 #include "nsd_args.h"
+#include "nsd_diag.h"
 
 namespace {
 
-// ---- opt-in launch timing (nsd_seq_profile): HIP events on the launch stream around the kernels of the path, so that a
-// benchmark can quote the dominant kernel's own duration.  Off by default: no events are created, nothing is recorded.
+// ---- opt-in launch timing: DIAGNOSTIC BUILD ONLY (make diag -> libnsd_hip_diag.so, -DNSD_DIAG=1; declared in nsd_diag.h, not in
+// include/nsd.h).  HIP events on the launch stream around the kernels of the path, so that a benchmark can quote the dominant
+// kernel's own duration.  The product library has neither the state nor the entry points.
 enum { PK_SCAN_FWD = 0, PK_SCAN_BWD = 1, PK_GEMM_XPROJ = 2, PK_GEMM_DW = 3, PK_GEMM_DIN = 4, PK_HEAD = 5, PK_HEAD_GRADS = 6, PK_PREP = 7, PK_COUNT = 8 };
+#if NSD_DIAG
 struct ProfRec { hipEvent_t a, b; int kind; };
 struct ProfState { bool on = false; std::vector<ProfRec> recs; } g_prof;
 struct ProfScope {
@@ -27,11 +30,18 @@ struct ProfScope {
     }
     ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.recs[idx].b, st); }
 };
+#else
+struct ProfScope { ProfScope(int, hipStream_t) {} ~ProfScope() {} };
+#endif
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 int derive(const nsd_dims *d, uint32_t flags, SeqDims *o) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
+    if (flags & ~(uint32_t)(NSD_FLAG_BIDIR | NSD_FLAG_RESIDUAL | NSD_FLAG_TRAIN | (NSD_DIAG ? NSD_DIAG_FLAG_ALL : 0u))) {
+        nsd_set_error("seq path: unknown flag bits 0x%x", flags);
+        return NSD_E_INVALID;
+    }
     SeqDims s;
     s.B = d->B; s.T = d->T; s.C = d->C; s.H = d->H; s.L = d->L; s.K = d->K; s.F = d->F;
     s.D = (flags & NSD_FLAG_BIDIR) ? 2 : 1;
@@ -48,7 +58,7 @@ int derive(const nsd_dims *d, uint32_t flags, SeqDims *o) {
     s.Bp = (int)align_up(s.B > 0 ? s.B : 1, s.MG);
     s.groups = s.Bp / s.MG;
     // two unidirectional layers: one launch advances both, layer 1 a step behind layer 0 (nsd_scan2.hip)
-    s.fused2 = (s.D == 1 && s.L == 2 && !s.residual && !(flags & NSD_FLAG_NO_FUSED_LAYERS) && s.CP <= 64 && nsd_scan2_supported(s.H, s.MG)) ? 1 : 0;
+    s.fused2 = (s.D == 1 && s.L == 2 && !s.residual && !(NSD_DIAG && (flags & NSD_DIAG_FLAG_NO_FUSED_LAYERS)) && s.CP <= 64 && nsd_scan2_supported(s.H, s.MG)) ? 1 : 0;
     *o = s;
     return NSD_OK;
 }
@@ -61,7 +71,8 @@ SeqWs make_ws(const SeqDims &s) {
     const int64_t R = (int64_t)s.T * s.Bp, H = s.H, G = 4 * H, DH = (int64_t)s.D * H;
     int64_t p = 0;
     auto take = [&](int64_t bytes) { const int64_t at = p; p = align_up(p + bytes, 256); return at; };
-    w.status = take(NSD_SEQ_STATUS_WORDS * 4);
+    (void)take(NSD_SEQ_HEADER_BYTES);                            // persistent header: sticky status (nsd_seq_workspace_init zeroes it)
+    w.status = take(NSD_SEQ_STATUS_WORDS * 4);                   // == NSD_SEQ_HEADER_BYTES: nsd_seq_status / nsd_seq_guard rely on it
     w.flags_bytes = 2LL * s.L * s.D * s.groups * 128 * 4;        // forward + backward flag sets of every layer (one word per wave)
     w.flags = take(w.flags_bytes);
     w.xbf = take(R * s.CP * 2);
@@ -151,7 +162,8 @@ struct Ctx {
     hipStream_t st;
     int cap;                                                     // groups per scan launch
     int spread;                                                  // NSD_FLAG_SPREAD_GROUPS
-    int l2_mode;                                                 // same-XCD exchange shortcut allowed (NSD_FLAG_NO_L2_EXCHANGE clears it)
+    int l2_mode;                                                 // same-XCD exchange shortcut allowed (diagnostic build: NSD_DIAG_FLAG_NO_L2_EXCHANGE clears it)
+    int short_grid;                                              // diagnostic build: NSD_DIAG_FLAG_LOSE_MEMBER -> every scan launch misses its last workgroup
 };
 
 int split_count(int M, int N, long K) {
@@ -210,7 +222,7 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.groups = s.groups - g0 < c.cap ? s.groups - g0 : c.cap; a.group0 = g0;
             a.rng = rng; a.rng.on = lstm_drop ? 1 : 0;
-            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread;
+            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread; a.diag_short_grid = c.short_grid;
             ProfScope ps(PK_SCAN_FWD, c.st);
             if (const int rc = nsd_scan2_fwd_launch(a, H, s.MG, c.st)) return rc;
         }
@@ -254,7 +266,7 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
             a.rng = rng;
             a.rng.on = masked ? 1 : 0;
-            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread;
+            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread; a.diag_short_grid = c.short_grid;
             ProfScope ps(PK_SCAN_FWD, c.st);
             if (const int rc = nsd_scan_fwd_launch(a, H, s.MG, c.st)) return rc;
         }
@@ -272,6 +284,7 @@ HeadTmArgs head_args(Ctx &c, float *logits, float *probs) {
     h.eval_slope = (float)((0.125 + 1.0 / 3.0) / 2.0);           // nn.RReLU eval slope, lstm_eeg_model.py:27
     h.logits = logits; h.probs = probs;
     h.B = s.B; h.Bp = s.Bp; h.T = s.T; h.DH = s.D * s.H; h.F = s.F; h.K = s.K;
+    h.status = at<int>(c.ws, c.w.status);
     return h;
 }
 
@@ -281,6 +294,11 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
     const long R = (long)s.T * s.Bp;
     float *parts = at<float>(c.ws, c.w.parts);
     const bool lstm_drop = rng.on && rng.thr_lstm != 0;
+    // the backward scans' flag sets (rendezvous words, per-wave step counters) start from zero on EVERY backward call: a second
+    // nsd_seq_train_bwd on the same forward (retain_graph) would otherwise find last call's counters at T and race through
+    if (hipMemsetAsync(at<char>(c.ws, c.w.flags) + c.w.flags_bytes / 2, 0, (size_t)(c.w.flags_bytes / 2), c.st) != hipSuccess) {
+        nsd_set_error("seq: memset failed"); return NSD_E_LAUNCH;
+    }
     // contractions over the whole sequence for layer l: dW_hh, dW_ih (split-K, fixed-order reduction), biases from the scan's
     // per-tile sums.  da: [T*Bp][ldda] with direction d in columns d*4H..; dbp: [D][groups][4H]
     auto weight_grads = [&](int l, const bf16_t *da, long ldda, const float *dbp) -> int {
@@ -328,7 +346,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.groups = s.groups - g0 < c.cap ? s.groups - g0 : c.cap; a.group0 = g0; a.groups_total = s.groups;
             a.rng = rng; a.rng.on = lstm_drop ? 1 : 0;
-            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread;
+            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread; a.diag_short_grid = c.short_grid;
             ProfScope ps(PK_SCAN_BWD, c.st);
             if (const int rc = nsd_scan2_bwd_launch(a, H, s.MG, c.st)) return rc;
         }
@@ -357,7 +375,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
             a.rng = rng;
             a.rng.on = masked ? 1 : 0;
-            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread;
+            a.allow_l2_mode = c.l2_mode; a.spread_groups = c.spread; a.diag_short_grid = c.short_grid;
             ProfScope ps(PK_SCAN_BWD, c.st);
             if (const int rc = nsd_scan_bwd_launch(a, H, s.MG, c.st)) return rc;
         }
@@ -389,8 +407,9 @@ int make_ctx(const nsd_dims *d, uint32_t flags, const float *params, void *ws, i
     }
     c->ws = ws; c->params = params; c->st = (hipStream_t)stream;
     c->cap = nsd_num_cus() / (c->s.P * c->s.D);
-    c->l2_mode = (flags & NSD_FLAG_NO_L2_EXCHANGE) ? 0 : 1;
-    c->spread = (flags & NSD_FLAG_SPREAD_GROUPS) ? 1 : 0;
+    c->l2_mode = (NSD_DIAG && (flags & NSD_DIAG_FLAG_NO_L2_EXCHANGE)) ? 0 : 1;
+    c->spread = (NSD_DIAG && (flags & NSD_DIAG_FLAG_SPREAD_GROUPS)) ? 1 : 0;
+    c->short_grid = (NSD_DIAG && (flags & NSD_DIAG_FLAG_LOSE_MEMBER)) ? 1 : 0;
     return NSD_OK;
 }
 
@@ -512,19 +531,44 @@ int nsd_seq_loss_sum(const nsd_dims *d, uint32_t flags, const void *workspace, i
     return nsd_loss_sum_launch(reinterpret_cast<const float *>(reinterpret_cast<const char *>(workspace) + w.loss), s.B, out, (hipStream_t)stream);
 }
 
-// Blocking read of the path's status word: 0 = ok, 1 / 2 = a forward / backward scan group gave up waiting for a member
-// (a workgroup of the group was not resident, or the device was lost).  The only entry point that synchronises.
-int nsd_seq_status(const void *workspace, int32_t *status_out, void *stream) {
-    if (!workspace || !status_out) { nsd_set_error("seq_status: null pointer"); return NSD_E_INVALID; }
-    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
-        hipMemcpy(status_out, workspace, 4 * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
-        nsd_set_error("seq_status: %s", hipGetErrorString(hipGetLastError()));
+// Zero the persistent header of a freshly allocated workspace (the sticky status word).  Call once per allocation; an
+// uninitialised header reads as a failure, never as success.
+int nsd_seq_workspace_init(void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!workspace) { nsd_set_error("seq_workspace_init: null pointer"); return NSD_E_INVALID; }
+    if (workspace_bytes < NSD_SEQ_HEADER_BYTES + NSD_SEQ_STATUS_WORDS * 4) { nsd_set_error("seq_workspace_init: workspace too small"); return NSD_E_WORKSPACE; }
+    if (hipMemsetAsync(workspace, 0, NSD_SEQ_HEADER_BYTES + NSD_SEQ_STATUS_WORDS * 4, (hipStream_t)stream) != hipSuccess) {
+        nsd_set_error("seq_workspace_init: %s", hipGetErrorString(hipGetLastError()));
         return NSD_E_LAUNCH;
     }
     return NSD_OK;
 }
 
-// Opt-in launch timing for benchmarks: enable != 0 starts recording HIP events (on the launch stream) around the kernels of
+// Blocking read of the path's status: status_out[0] = code of the evaluation in flight OR the sticky word (0 = ok, bit 0 / bit 1 =
+// a forward / backward scan group gave up waiting for a member: a workgroup of the group was not resident, or the device was
+// lost), [1] = the sticky word alone (every code since nsd_seq_workspace_init), [2] / [3] = scan groups on one XCD / spread.
+int nsd_seq_status(const void *workspace, int32_t *status_out, void *stream) {
+    if (!workspace || !status_out) { nsd_set_error("seq_status: null pointer"); return NSD_E_INVALID; }
+    int32_t sticky = 0, cur[4] = {0, 0, 0, 0};
+    const char *base = reinterpret_cast<const char *>(workspace);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+        hipMemcpy(&sticky, base, sizeof(sticky), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(cur, base + NSD_SEQ_HEADER_BYTES, sizeof(cur), hipMemcpyDeviceToHost) != hipSuccess) {
+        nsd_set_error("seq_status: %s", hipGetErrorString(hipGetLastError()));
+        return NSD_E_LAUNCH;
+    }
+    status_out[0] = cur[0] | sticky; status_out[1] = sticky; status_out[2] = cur[2]; status_out[3] = cur[3];
+    return NSD_OK;
+}
+
+// flag_out[0] (device, fp32) = 1 if the workspace reports a scan time-out (current or sticky), else 0; enqueued, never blocks.
+// The trainer appends the flag to the flat gradient it all-reduces, so that EVERY rank skips the update when ANY rank failed.
+int nsd_seq_guard(const void *workspace, float *flag_out, void *stream) {
+    if (!workspace || !flag_out) { nsd_set_error("seq_guard: null pointer"); return NSD_E_INVALID; }
+    return nsd_seq_guard_launch(reinterpret_cast<const int *>(workspace), NSD_SEQ_HEADER_WORDS, flag_out, (hipStream_t)stream);
+}
+
+#if NSD_DIAG
+// Diagnostic build only (nsd_diag.h).  enable != 0 starts recording HIP events (on the launch stream) around the kernels of
 // every following nsd_seq_* call, 0 stops and discards.  nsd_seq_profile_read sums one kind and forgets its records
 // (BLOCKING: waits for those events).  kind: 0 forward scan, 1 backward scan, 2 input-projection GEMM, 3 weight-gradient
 // GEMMs (+ their reductions), 4 input-gradient GEMM, 5 head, 6 head parameter gradients, 7 operand preparation.
@@ -548,5 +592,6 @@ int nsd_seq_profile_read(int32_t kind, float *total_ms, int32_t *count) {
     *total_ms = tot; *count = n;
     return NSD_OK;
 }
+#endif
 
 }  // extern "C"

@@ -304,6 +304,15 @@ def _default_preprocessor(sr: int, tailoring_lambda: float, package: Optional[st
     return cls(sr=sr, tailoring_lambda=tailoring_lambda)
 
 
+def _raise_on_poison(probs: np.ndarray, x: np.ndarray, what: str) -> None:
+    """The bf16 path's head writes NaN probabilities when a scan group of the evaluation timed out (include/nsd.h, 'Failure
+    reporting').  NaN out of a finite window is therefore a failed evaluation, not a result: refuse.  (A window that itself holds
+    NaN / inf gives NaN probabilities and label index 0 as in the reference, lstm_eeg_model.py:97-99.)"""
+    if np.isnan(probs).any() and np.isfinite(x).all():
+        raise NsdError(f"{what}: NaN probabilities from a finite window -- a scan group of the sequence-batched path timed out because "
+                       "its workgroups were not all resident (another process on the GPU, a CU mask, a partition mode)")
+
+
 class IdentityPreProcessor:
     """Explicit opt-out of the MindsAI filter: same shape / dtype / ValueError contract as the reference's
     PreProcessor.transform (preprocessor.py:21-36), no filtering.  Selected with `preprocess="identity"`."""
@@ -365,6 +374,7 @@ class SimplePredictor:
         x = self.pre.transform(chunk_TxC)
         x_t = torch.from_numpy(np.ascontiguousarray(x[None, ...], dtype=np.float32)).to(self.gpu, non_blocking=True)
         probs = self.model.predict_proba(x_t)[0].cpu().numpy().astype(np.float32)
+        _raise_on_poison(probs, x, "SimplePredictor.predict")
         y_idx = int(np.argmax(probs))
         return probs, self.class_names[y_idx]
 
@@ -387,5 +397,6 @@ class SimplePredictor:
         xs = np.stack([np.ascontiguousarray(self.pre.transform(rec[s0:s0 + window]), dtype=np.float32) for s0 in starts])
         x_t = torch.from_numpy(xs).to(self.gpu, non_blocking=True)
         probs = self.model.predict_proba(x_t).cpu().numpy().astype(np.float32)
+        _raise_on_poison(probs, xs, "SimplePredictor.predict_windows")
         return probs, [self.class_names[int(i)] for i in probs.argmax(1)]
 

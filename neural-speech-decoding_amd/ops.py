@@ -114,13 +114,15 @@ _extra_flags = 0
 _seq_extra_flags = 0
 
 
-def set_seq_l2_exchange(on: bool, spread_groups: bool = False, fused_layers: bool = True) -> None:
-    """Sequence-batched path, diagnostics: on=False -> scan groups always use the write-through exchange
-    (NSD_FLAG_NO_L2_EXCHANGE); spread_groups=True -> every group is spread over all XCDs (NSD_FLAG_SPREAD_GROUPS);
-    fused_layers=False -> two unidirectional layers run as two scans + GEMMs instead of one skewed launch."""
+def set_seq_diag_flags(l2_exchange: bool = True, spread_groups: bool = False, fused_layers: bool = True,
+                       lose_member: bool = False) -> None:
+    """Diagnostic build only (inside `with _lib.diagnostic_library():`; the product library rejects these bits):
+    l2_exchange=False -> scan groups always use the write-through exchange; spread_groups=True -> every group is spread over all
+    XCDs; fused_layers=False -> two unidirectional layers run as two scans + GEMMs instead of one skewed launch; lose_member=True
+    -> every scan launch misses its last workgroup (that group must time out and report it)."""
     global _seq_extra_flags
-    _seq_extra_flags = ((0 if on else _lib.NSD_FLAG_NO_L2_EXCHANGE) | (_lib.NSD_FLAG_SPREAD_GROUPS if spread_groups else 0)
-                        | (0 if fused_layers else _lib.NSD_FLAG_NO_FUSED_LAYERS))
+    _seq_extra_flags = ((0 if l2_exchange else _lib.NSD_DIAG_FLAG_NO_L2_EXCHANGE) | (_lib.NSD_DIAG_FLAG_SPREAD_GROUPS if spread_groups else 0)
+                        | (0 if fused_layers else _lib.NSD_DIAG_FLAG_NO_FUSED_LAYERS) | (_lib.NSD_DIAG_FLAG_LOSE_MEMBER if lose_member else 0))
 
 
 def set_gemm_bf16(on: bool) -> None:
@@ -333,10 +335,15 @@ def loss_sum(spec: ModelSpec, ws: torch.Tensor, B: int, T: int, out: Optional[to
 
 def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, step: int, lr: float = 1e-3,
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0,
-              grad_scale: float = 1.0) -> None:
+              grad_scale: float = 1.0, skip: Optional[torch.Tensor] = None) -> None:
+    """torch.optim.Adam update of the flat vector.  skip: device fp32 flag (ops.seq_guard); non-zero -> nothing is updated."""
     n = p.numel()
-    _call("nsd_adam_step", p.device, n, _dev_f32(p, "p"), _dev_f32(g, "g", p.shape), _dev_f32(m, "m", p.shape),
-          _dev_f32(v, "v", p.shape), lr, beta1, beta2, eps, weight_decay, grad_scale, step, STREAM)
+    if skip is None:
+        _call("nsd_adam_step", p.device, n, _dev_f32(p, "p"), _dev_f32(g, "g", p.shape), _dev_f32(m, "m", p.shape),
+              _dev_f32(v, "v", p.shape), lr, beta1, beta2, eps, weight_decay, grad_scale, step, STREAM)
+    else:
+        _call("nsd_adam_step_guarded", p.device, n, _dev_f32(p, "p"), _dev_f32(g, "g", p.shape), _dev_f32(m, "m", p.shape),
+              _dev_f32(v, "v", p.shape), lr, beta1, beta2, eps, weight_decay, grad_scale, step, _dev_f32(skip, "skip"), STREAM)
 
 
 def dropout_mask(seed: int, stream_id: int, p: float, shape, device) -> torch.Tensor:
@@ -384,7 +391,9 @@ def seq_workspace(spec: ModelSpec, B: int, T: int, device) -> torch.Tensor:
     n = _lib.lib().nsd_seq_workspace_bytes(C.byref(d), spec.seq_flags)
     if n < 0:
         check(int(n), "nsd_seq_workspace_bytes")
-    return torch.empty(int(n), dtype=torch.uint8, device=device)
+    ws = torch.empty(int(n), dtype=torch.uint8, device=device)
+    _call("nsd_seq_workspace_init", ws.device, ws.data_ptr(), _nbytes(ws), STREAM)     # persistent header: sticky status = 0
+    return ws
 
 
 def _seq_rng(rng: Optional[dict]):
@@ -395,11 +404,27 @@ def _seq_rng(rng: Optional[dict]):
 
 
 def seq_status(ws: torch.Tensor, detail: bool = False):
-    """0 = ok; 1 / 2 = a forward / backward scan group timed out (results invalid).  detail=True: (status, groups that ran on
-    one XCD, groups spread over several XCDs) counted over the scan launches since the last forward.  Synchronises."""
+    """0 = ok; bit 0 / bit 1 = a forward / backward scan group timed out, in the last evaluation or (sticky) in any evaluation
+    since the workspace was created: results invalid.  detail=True: (status, groups that ran on one XCD, groups spread over
+    several XCDs) counted over the scan launches since the last forward.  Synchronises."""
     out = (C.c_int32 * 4)(-1, 0, 0, 0)
     _call("nsd_seq_status", ws.device, ws.data_ptr(), out, STREAM)
     return (int(out[0]), int(out[2]), int(out[3])) if detail else int(out[0])
+
+
+def seq_guard(ws: torch.Tensor, flag: torch.Tensor) -> None:
+    """flag[0] (device fp32) = 1 if `ws` reports a scan time-out (last evaluation or sticky), else 0.  Enqueued, no sync."""
+    _call("nsd_seq_guard", ws.device, ws.data_ptr(), _dev_f32(flag, "flag"), STREAM)
+
+
+def seq_raise_on_timeout(ws: torch.Tensor, what: str) -> None:
+    """Synchronises; raises NsdError when `ws` reports a scan time-out."""
+    st = seq_status(ws)
+    if st != 0:
+        stage = " and ".join(n for bit, n in ((1, "forward"), (2, "backward")) if st & bit) or f"code {st}"
+        raise NsdError(f"{what}: a {stage} scan group of the sequence-batched path timed out (status {st}): its workgroups were not "
+                       "all resident at once (another process on the GPU, a CU mask or a partition mode?).  Results since then "
+                       "are invalid (NaN logits / loss, the guarded Adam update was skipped); allocate a fresh workspace to go on")
 
 
 def seq_infer(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: Optional[torch.Tensor] = None, *,
@@ -453,7 +478,10 @@ SEQ_PROFILE_KINDS = ("scan_fwd", "scan_bwd", "gemm_xproj", "gemm_dw", "gemm_din"
 
 
 def seq_profile(enable: bool) -> None:
-    """Start / stop the opt-in HIP-event timing of the sequence-batched path's kernels (nsd_seq_profile)."""
+    """Diagnostic build only (`with _lib.diagnostic_library():`): start / stop the HIP-event timing of the sequence-batched
+    path's kernels (nsd_seq_profile, csrc/nsd_diag.h)."""
+    if not _lib.diag_active():
+        raise NsdError("seq_profile: per-kernel timing lives in the diagnostic build: use `with _lib.diagnostic_library():`")
     _call("nsd_seq_profile", None, 1 if enable else 0)
 
 

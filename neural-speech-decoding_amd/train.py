@@ -110,6 +110,8 @@ def main(argv=None) -> int:
             sel = tr_dev[torch.from_numpy(idx[lo:hi]).to(dev)]
             trainer.step(x_all[sel].contiguous(), y_all[sel].contiguous(), global_batch=len(idx))
             n_seen += hi - lo
+        if epoch % args.log_every == 0 or epoch == args.epochs - 1:
+            trainer.check()                  # every rank: raises (non-zero exit) if a scan group timed out anywhere
         if rank == 0 and (epoch % args.log_every == 0 or epoch == args.epochs - 1):
             acc_tr = evaluate(model, x_all[tr_dev], y_all[tr_dev])
             acc_va = evaluate(model, x_all[va_idx], y_all[va_idx]) if len(va_idx) else float("nan")

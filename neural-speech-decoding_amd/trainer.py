@@ -101,7 +101,12 @@ class Trainer:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
-        self.grads = torch.zeros_like(self.flat)
+        # the flat gradient with ONE extra element behind it: the bf16 path's failure flag (ops.seq_guard).  The whole buffer is
+        # what the ranks all-reduce, so a scan time-out on ANY rank makes EVERY rank skip the update (guarded Adam) -- still
+        # one collective per step.  Always 0 on the fp32 path.
+        self._grads_ext = torch.zeros(self.flat.numel() + 1, dtype=torch.float32, device=self.flat.device)
+        self.grads = self._grads_ext[:self.flat.numel()]
+        self._skip = self._grads_ext[self.flat.numel():]
         self.reducer = FlatGradAllReducer(group)
         self.rank = dist.get_rank(group) if self.reducer.world > 1 else 0
         self.world = self.reducer.world
@@ -149,7 +154,7 @@ class Trainer:
             # no exchange step between reduction and update: one launch does both
             self._local_grads(x, y, 1.0 / float(global_batch), fuse_adam=True)
         else:
-            DataParallelStep(self.grads, self.reducer, self._local_grads, self.grads.zero_, self._adam)(x, y, global_batch)
+            DataParallelStep(self._grads_ext, self.reducer, self._local_grads, self._grads_ext.zero_, self._adam)(x, y, global_batch)
         if B > 0:
             self._last_B, self._last_T = B, int(x.shape[1])
 
@@ -158,17 +163,26 @@ class Trainer:
                     weight_decay=self.weight_decay)
 
     def _adam(self) -> None:
-        ops.adam_step(self.flat, self.grads, self.m, self.v, **self._hyper())
+        # bf16 path: skipped on the device when any rank's scan timed out (self._skip, summed over ranks by the all-reduce)
+        ops.adam_step(self.flat, self.grads, self.m, self.v, skip=self._skip if self.model.precision == "bf16" else None, **self._hyper())
+
+    def _prepare_input(self, x: torch.Tensor) -> torch.Tensor:
+        """What EEG_LSTM.forward does to a window before the LSTM (lstm_eeg_model.py facade): contiguous fp32 and, for
+        normalize=True, the per-channel z-score -- the model must be trained on what it is evaluated on."""
+        x = x.contiguous().float()
+        return ops.zscore(x) if self.model.normalize and x.shape[0] > 0 else x
 
     def _local_grads(self, x: torch.Tensor, y: torch.Tensor, scale: float, fuse_adam: bool = False) -> None:
         """Launches that leave this shard's gradient (scaled) in self.grads; fuse_adam: the update rides in the last one."""
         from . import _lib
         sp = self.spec
         B, T, _ = x.shape
+        x = self._prepare_input(x)
         if self.model.precision == "bf16":
             # sequence-batched path: forward (+ head, CE, head backward), backward (+ all parameter gradients), Adam
             key = ("seq", B, T)
             if key not in self._bufs:
+                self._check_old_workspaces("Trainer.step")     # a reported time-out must not vanish with the buffer
                 self._bufs = {key: {"ws": ops.seq_workspace(sp, B, T, self.flat.device),
                                     "logits": torch.empty((B, sp.K), dtype=torch.float32, device=self.flat.device)}}
             buf = self._bufs[key]
@@ -178,6 +192,7 @@ class Trainer:
                            p_head=self.model.head_dropout_p)
             ops.seq_train_fwd(sp, self.flat, x, y, buf["ws"], rng=rng, scale=scale, logits=buf["logits"])
             ops.seq_train_bwd(sp, self.flat, buf["ws"], B, T, rng=rng, grads=self.grads)
+            ops.seq_guard(buf["ws"], self._skip)
             if fuse_adam:
                 self._adam()
             return
@@ -212,6 +227,9 @@ class Trainer:
         """(x [B,T,C] fp32, y [B] int32) device buffers owned by the trainer.  Fill them in place (copy_, index_select
         with out=...) and call step_static(B, T): the whole step is then ONE hipGraph replay per segment instead of
         seven launches, with no host-side argument that changes from step to step."""
+        if self.model.precision == "bf16":
+            raise ops.NsdError("Trainer.static_inputs / step_static (hipGraph replay) exist for the fp32 path only; "
+                               "precision='bf16' trains through Trainer.step")
         buf = self._buffers(B, T)
         if "x" not in buf:
             dev = self.flat.device
@@ -232,7 +250,12 @@ class Trainer:
                                              dl.numel(), dl.data_ptr(), sl.numel(), sl.data_ptr(), dh.data_ptr(), st), "train_masks_dev")
         elif self.stochastic:
             raise ops.NsdError("graph step needs all three random streams (dropout > 0, num_layers > 1) or stochastic=False")
-        ops.train_step_grads(self.spec, self.flat, buf["x"], buf["ws"], buf["y"], buf["logits"], self.grads,
+        xin = buf["x"]
+        if self.model.normalize:                               # a static buffer of its own: nothing is allocated inside the capture
+            if "xn" not in buf:
+                buf["xn"] = torch.empty_like(buf["x"])
+            xin = ops.zscore(buf["x"], out=buf["xn"])
+        ops.train_step_grads(self.spec, self.flat, xin, buf["ws"], buf["y"], buf["logits"], self.grads,
                              scale=1.0 / (B * self.world), drop_lstm=dl, rrelu_slope=sl, drop_head=dh, residual=self.model.residual)
 
     def _issue_segment_b(self) -> None:
@@ -247,6 +270,9 @@ class Trainer:
         """One optimisation step on the trainer's static input buffers, replayed from captured hipGraphs.
         world == 1: one graph.  world > 1: graph A, the eager RCCL all-reduce of the flat gradient, graph B (Adam)."""
         key = (B, T)
+        if self.model.precision == "bf16":
+            raise ops.NsdError("Trainer.step_static (hipGraph replay) exists for the fp32 path only; precision='bf16' trains "
+                               "through Trainer.step")
         if key not in self._graphs:
             self.static_inputs(B, T)
             self._step_dev.fill_(self.step_count)
@@ -282,11 +308,30 @@ class Trainer:
 
     @_on_own_device
     def scan_status(self) -> int:
-        """precision='bf16' only: 0 unless a scan group of the last step timed out (see nsd_seq_status).  Synchronises."""
+        """precision='bf16' only: 0 unless a scan group timed out in any step on the current workspace (the status is sticky:
+        nsd_seq_status).  Synchronises."""
         for key, buf in self._bufs.items():
             if key[0] == "seq":
                 return ops.seq_status(buf["ws"])
         return 0
+
+    def _check_old_workspaces(self, what: str) -> None:
+        for key, buf in self._bufs.items():
+            if key[0] == "seq":
+                ops.seq_raise_on_timeout(buf["ws"], what)
+
+    @_on_own_device
+    def check(self) -> None:
+        """Raise NsdError if a scan group of the bf16 path timed out on ANY rank since the workspaces were created
+        (synchronises this rank's stream; no collective: the flag read here was summed over the ranks by the step's own
+        all-reduce, so every rank raises in the same step).  nsd_amd.train calls it on every rank at every log interval."""
+        if self.model.precision != "bf16":
+            return
+        if float(self._skip.item()) != 0.0:
+            self._check_old_workspaces("Trainer")              # this rank's own status, with the stage in the message
+            raise ops.NsdError("Trainer: a scan group of the sequence-batched path timed out on another rank; every rank has "
+                               "skipped its Adam updates since (guarded update).  Results are invalid")
+        self._check_old_workspaces("Trainer")
 
     @_on_own_device
     def last_loss(self) -> float:
@@ -296,7 +341,10 @@ class Trainer:
         if self.model.precision == "bf16":
             ws = self._bufs[("seq", self._last_B, self._last_T)]["ws"]
             ops.seq_loss_sum(self.spec, ws, self._last_B, self._last_T, out=self._loss)
-            return float(self._loss.item()) / self._last_B
+            loss = float(self._loss.item()) / self._last_B
+            if loss != loss:                                   # NaN: the head poisons its outputs when a scan timed out
+                ops.seq_raise_on_timeout(ws, "Trainer.last_loss")
+            return loss
         ws = self._buffers(self._last_B, self._last_T)["ws"]
         ops.loss_sum(self.spec, ws, self._last_B, self._last_T, out=self._loss)
         return float(self._loss.item()) / self._last_B

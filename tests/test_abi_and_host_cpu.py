@@ -26,8 +26,51 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in nsd.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert L.nsd_version() == 200
+    assert L.nsd_version() == 300
     assert not hasattr(L, "nsd_debug_profile_buffer")           # diagnostics are not in the shipped library
+
+
+def test_diagnostics_live_only_in_the_diagnostic_build():
+    """The exchange-mode / forced time-out flag bits and the per-kernel timing entry points (csrc/nsd_diag.h) are not in
+    include/nsd.h, not exported by libnsd_hip.so and rejected by it; libnsd_hip_diag.so (same objects, orchestration compiled with
+    -DNSD_DIAG=1) has them.  No product module asks for the diagnostic library."""
+    import ctypes as C
+    hdr = open(os.path.join(ROOT, "include", "nsd.h")).read()
+    for word in ("nsd_seq_profile", "NO_L2_EXCHANGE", "SPREAD_GROUPS", "NO_FUSED_LAYERS", "LOSE_MEMBER"):
+        assert word not in hdr, word
+    L = nsd_amd.load_library()
+    assert not hasattr(L, "nsd_seq_profile") and not hasattr(L, "nsd_seq_profile_read")
+    d = _lib.Dims(64, 10, 8, 256, 2, 5, 32)
+    assert L.nsd_seq_supported(C.byref(d), 0) == 1 and L.nsd_seq_supported(C.byref(d), _lib.NSD_FLAG_BIDIR) == 1
+    for bit in (_lib.NSD_DIAG_FLAG_NO_L2_EXCHANGE, _lib.NSD_DIAG_FLAG_SPREAD_GROUPS, _lib.NSD_DIAG_FLAG_NO_FUSED_LAYERS,
+                _lib.NSD_DIAG_FLAG_LOSE_MEMBER, 1 << 20):
+        assert L.nsd_seq_supported(C.byref(d), bit) == 0
+        assert L.nsd_seq_workspace_bytes(C.byref(d), bit) == -1 and b"unknown flag" in L.nsd_last_error()
+    with _lib.diagnostic_library() as DL:
+        assert DL is not L and hasattr(DL, "nsd_seq_profile") and DL.nsd_version() == 300
+        assert DL.nsd_seq_supported(C.byref(d), _lib.NSD_DIAG_FLAG_SPREAD_GROUPS) == 1
+        assert ops.ModelSpec(H=256, K=5).param_count == 807878        # calls inside the block go to the diagnostic library
+        with pytest.raises(nsd_amd.NsdError):
+            with _lib.diagnostic_library():
+                pass
+    assert _lib.lib() is L and not _lib.diag_active()
+    with pytest.raises(nsd_amd.NsdError, match="diagnostic build"):
+        ops.seq_profile(True)
+    pkg = os.path.join(ROOT, "neural-speech-decoding_amd")
+    for fn in ("lstm_eeg_model.py", "trainer.py", "train.py", "tester.py", "streaming_process.py", "data.py", "__init__.py"):
+        assert "diagnostic_library" not in open(os.path.join(pkg, fn)).read(), fn
+
+
+def test_seq_failure_reporting_entry_points_without_a_gpu():
+    import ctypes as C
+    L = nsd_amd.load_library()
+    assert L.nsd_seq_workspace_init(None, 1 << 20, None) == -1
+    assert L.nsd_seq_workspace_init(4096, 16, None) == -3          # smaller than the persistent header
+    assert L.nsd_seq_guard(None, None, None) == -1
+    assert L.nsd_adam_step_guarded(8, 4096, 4096, 4096, 4096, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1, None, None) == -1   # skip flag is mandatory
+    # the workspace starts with the 256-byte persistent header (sticky status), the per-evaluation status words follow
+    src = open(os.path.join(ROOT, "neural-speech-decoding_amd", "csrc", "nsd_seq.h")).read()
+    assert "#define NSD_SEQ_HEADER_BYTES 256" in src
 
 
 @pytest.mark.parametrize("dims", [orc.Dims(), orc.Dims(H=256, K=5), orc.Dims(C=64, H=512, L=3, K=5), orc.Dims(L=1)])

@@ -152,3 +152,31 @@ def test_data_parallel_step_uneven_and_empty_shards(tmp_path, world, batches):
     # difference can move such an element by up to 2*lr per step; everywhere else the trajectories coincide
     dp = np.abs(res[0]["p"] - p)
     assert dp.max() <= 2 * 1e-3 * len(batches) and (dp > 2e-5).mean() < 0.01
+
+
+@pytest.mark.timeout(300)
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` OUTSIDE a torchrun environment: the parent (which never touches a GPU) spawns the two ranks with
+    the rendezvous environment, they run the launcher / barrier / max-over-ranks / reporting code on a stub step (gloo), and
+    exactly one JSON line comes back from rank 0.  The same command line inside a torchrun environment (WORLD_SIZE set) must
+    NOT spawn again."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NSD_BENCH_STUB="1", NSD_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--preheat-steps", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["data"] == "stub" and out["metric"].startswith("STUB")
+    assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"] and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and out["scaling"] == "weak"
+    # a mismatching launcher environment is refused (rc 2), not re-launched
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                        env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 2 and "WORLD_SIZE=1" in r2.stderr

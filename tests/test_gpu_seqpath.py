@@ -146,6 +146,7 @@ def test_gemm_bf16_large_tile_split_k_shift_period(nsd, dev):
 # ---------------------------------------------------------------------------------------------------
 # the path itself against the fp32 oracle (unidirectional): inference, training gradients, dropout streams
 # ---------------------------------------------------------------------------------------------------
+from nsd_amd import _lib                                  # noqa: E402  (diagnostic_library(): the test-only twin of the product library)
 from oracle import nsd_oracle as orc                      # noqa: E402  (test infrastructure: the checker)
 from tests.golden.make_goldens import synth_labels, synth_params, synth_x      # noqa: E402
 
@@ -266,25 +267,32 @@ def test_seq_exchange_modes_agree(nsd, dev):
     flat = _flat(st, d, dev)
     xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
     out, placement = [], []
-    for on, spread in ((True, False), (False, False), (True, True)):
-        ops.set_seq_l2_exchange(on, spread)
-        try:
-            spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
-            ws = ops.seq_workspace(spec, B, T, dev)
-            lg = ops.seq_train_fwd(spec, flat, xt, yt, ws).clone()
-            g = ops.seq_train_bwd(spec, flat, ws, B, T).clone()
-            stt, one_xcd, spread_n = ops.seq_status(ws, detail=True)
-            assert stt == 0
-            placement.append((one_xcd, spread_n))
-            out.append((lg, g))
-        finally:
-            ops.set_seq_l2_exchange(True, False)
+    spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    out.append((ops.seq_train_fwd(spec, flat, xt, yt, ws).clone(), ops.seq_train_bwd(spec, flat, ws, B, T).clone()))   # the PRODUCT library
+    stt, one_xcd, spread_n = ops.seq_status(ws, detail=True)
+    assert stt == 0
+    placement.append((one_xcd, spread_n))
+    with _lib.diagnostic_library():                              # the flag bits exist in libnsd_hip_diag.so only
+        for on, spread in ((True, False), (False, False), (True, True)):
+            ops.set_seq_diag_flags(on, spread)
+            try:
+                spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+                ws = ops.seq_workspace(spec, B, T, dev)
+                lg = ops.seq_train_fwd(spec, flat, xt, yt, ws).clone()
+                g = ops.seq_train_bwd(spec, flat, ws, B, T).clone()
+                stt, one_xcd, spread_n = ops.seq_status(ws, detail=True)
+                assert stt == 0
+                placement.append((one_xcd, spread_n))
+                out.append((lg, g))
+            finally:
+                ops.set_seq_diag_flags()
     print("scan groups on one XCD / spread, per mode:", placement)
     for lg, g in out[1:]:
         assert torch.equal(out[0][0], lg) and torch.equal(out[0][1], g)
     n_groups = 2 * 8                                            # one skewed two-layer scan forward + one backward, 256 / 32 batch tiles
     assert all(a + b == n_groups for a, b in placement)
-    assert placement[2][1] == n_groups                          # spread really means spread: the write-through path carried the run
+    assert placement[3][1] == n_groups                          # spread really means spread: the write-through path carried the run
 
 
 def test_seq_exchange_modes_agree_layer_by_layer_kernels(nsd, dev):
@@ -299,18 +307,23 @@ def test_seq_exchange_modes_agree_layer_by_layer_kernels(nsd, dev):
     yt = torch.from_numpy(synth_labels(B, K, seed=3)).to(dev)
     rng = dict(seed=99, base_stream=8, p_lstm=0.5, p_head=0.5)
     out, placement = [], []
-    for on, spread in ((True, False), (False, False), (True, True)):
-        ops.set_seq_l2_exchange(on, spread)
-        try:
-            ws = ops.seq_workspace(spec, B, T, dev)
-            lg = ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng).clone()
-            g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
-            stt, one_xcd, spread_n = ops.seq_status(ws, detail=True)
-            assert stt == 0
-            placement.append((one_xcd, spread_n))
-            out.append((lg, g))
-        finally:
-            ops.set_seq_l2_exchange(True, False)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    out.append((ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng).clone(), ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()))  # product library
+    placement.append(ops.seq_status(ws, detail=True)[1:])
+    with _lib.diagnostic_library():
+        for on, spread in ((True, False), (False, False), (True, True)):
+            ops.set_seq_diag_flags(on, spread)
+            try:
+                spec = ops.ModelSpec(C=C, H=H, L=L, K=K, D=2)
+                ws = ops.seq_workspace(spec, B, T, dev)
+                lg = ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng).clone()
+                g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
+                stt, one_xcd, spread_n = ops.seq_status(ws, detail=True)
+                assert stt == 0
+                placement.append((one_xcd, spread_n))
+                out.append((lg, g))
+            finally:
+                ops.set_seq_diag_flags()
     for lg, g in out[1:]:
         assert torch.equal(out[0][0], lg) and torch.equal(out[0][1], g)
     n_groups = 2 * 2 * 2 * 3                                    # layers x passes x directions x batch tiles
@@ -331,18 +344,19 @@ def test_two_layer_skewed_launch_vs_layer_by_layer(nsd, dev):
     xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
     rng = dict(seed=77, base_stream=16, p_lstm=0.5, p_head=0.5)
     res = []
-    for fused in (True, False):
-        ops.set_seq_l2_exchange(True, False, fused)
-        try:
-            spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
-            ws = ops.seq_workspace(spec, B, T, dev)
-            lg = ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng).clone()
-            g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
-            stt, a, b = ops.seq_status(ws, detail=True)
-            assert stt == 0 and a + b == (2 if fused else 4) * 4          # 4 batch tiles; 2 scan launches fused, 4 layer by layer
-            res.append((lg, g))
-        finally:
-            ops.set_seq_l2_exchange(True, False, True)
+    with _lib.diagnostic_library():
+        for fused in (True, False):
+            ops.set_seq_diag_flags(fused_layers=fused)
+            try:
+                spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+                ws = ops.seq_workspace(spec, B, T, dev)
+                lg = ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng).clone()
+                g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
+                stt, a, b = ops.seq_status(ws, detail=True)
+                assert stt == 0 and a + b == (2 if fused else 4) * 4          # 4 batch tiles; 2 scan launches fused, 4 layer by layer
+                res.append((lg, g))
+            finally:
+                ops.set_seq_diag_flags()
     assert (res[0][0] - res[1][0]).abs().max().item() < 2e-2
     assert (res[0][1] - res[1][1]).abs().max().item() <= 3e-2 * res[1][1].abs().max().item()
 
@@ -684,3 +698,254 @@ def test_fused_stack_projects_wide_inputs_inside_the_scan(nsd, dev, C):
     _grad_check(g.cpu().numpy(), g_ref, d, fc_rtol=2 * SEQ_GRAD_RTOL)
     lg, _ = ops.seq_infer(spec, flat, torch.from_numpy(x).to(dev))
     assert np.abs(lg.cpu().numpy() - fw["logits"]).max() < SEQ_LOGIT_TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# robustness of the flag protocol and failure reporting
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,L,D,B,T", [(256, 2, 1, 96, 20), (128, 2, 2, 70, 12), (128, 3, 1, 40, 9)])
+def test_backward_twice_after_one_forward(nsd, dev, H, L, D, B, T):
+    """nsd_seq_train_bwd may be called again on the same forward (autograd's retain_graph): the backward scans' rendezvous words
+    and per-wave step counters start from zero on every call, so the second call exchanges for real and gives the same bits."""
+    from nsd_amd import ops
+    K = 5
+    st = synth_params(8, H, L, K, seed=H + D, D=D)
+    spec = ops.ModelSpec(C=8, H=H, L=L, K=K, D=D)
+    flat = _flat_from_state(spec, st, dev)
+    xt = torch.from_numpy(synth_x(B, T, seed=4)).to(dev)
+    yt = torch.from_numpy(synth_labels(B, K, seed=4)).to(dev)
+    rng = dict(seed=5, base_stream=4, p_lstm=0.5, p_head=0.5)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng)
+    g1 = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
+    g2 = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
+    g3 = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
+    assert ops.seq_status(ws) == 0 and torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    assert torch.equal(g1, g2) and torch.equal(g1, g3)
+    # ... and the nn.Module surface with retain_graph
+    m = nsd.EEG_LSTM(8, H, L, K, dropout=0.0, precision="bf16", bidirectional=D == 2).to(dev).eval()
+    _, loss = m.loss(xt, yt)
+    loss.backward(retain_graph=True)
+    ga = torch.cat([p.grad.reshape(-1) for _, p in m._named_in_order()]).clone()
+    for p in m.parameters():
+        p.grad = None
+    loss.backward()
+    gb = torch.cat([p.grad.reshape(-1) for _, p in m._named_in_order()])
+    assert torch.equal(ga, gb)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fused", [True, False])
+def test_scan_timeout_is_reported_everywhere(nsd, dev, fused):
+    """A scan group whose workgroups are not all resident gives up after a bounded spin.  The diagnostic build can provoke that
+    (every scan launch misses its last workgroup).  The failure must be impossible to miss: status word, STICKY status that a
+    later, healthy forward does not clear, NaN logits / probabilities / loss, an Adam update that is skipped on the device,
+    NsdError from Trainer.last_loss() / Trainer.check() and from SimplePredictor-style probability checks."""
+    from nsd_amd import ops
+    from nsd_amd.trainer import Trainer
+    from nsd_amd.lstm_eeg_model import _raise_on_poison
+    H, L, K, B, T = 128, 2, 3, 64, 6
+    D = 1 if fused else 2                                        # fused two-layer launch / layer-by-layer bidirectional kernels
+    torch.manual_seed(1)
+    m = nsd.EEG_LSTM(8, H, L, K, dropout=0.5, precision="bf16", bidirectional=D == 2).to(dev).train()
+    spec, flat = m.spec, m.flat_parameters()
+    xt = torch.from_numpy(synth_x(B, T, seed=2)).to(dev)
+    yt = torch.from_numpy(synth_labels(B, K, seed=2)).to(dev)
+    tr = Trainer(m, lr=1e-2, seed=3)
+    tr.step(xt, yt)
+    assert tr.scan_status() == 0 and np.isfinite(tr.last_loss())
+    tr.check()
+    before = flat.clone()
+    with _lib.diagnostic_library():
+        ops.set_seq_diag_flags(lose_member=True)
+        try:
+            tr.step(xt, yt)                                     # forward and backward scans both lose a member: ~2-4 s of bounded spinning
+            code = tr.scan_status()
+        finally:
+            ops.set_seq_diag_flags()
+    assert code & 1, code                                       # the forward time-out is there (the backward's too where it ran)
+    assert torch.equal(flat, before), "the guarded Adam update must be skipped when the gradient is garbage"
+    with pytest.raises(nsd.NsdError, match="timed out"):
+        tr.last_loss()
+    with pytest.raises(nsd.NsdError, match="timed out"):
+        tr.check()
+    # a healthy step on the same workspace: the evaluation itself is fine again, but the sticky word still reports the failure,
+    # the outputs stay poisoned and the parameters stay put -- nobody trains on through a failure unnoticed
+    tr.step(xt, yt)
+    assert tr.scan_status() != 0 and torch.equal(flat, before)
+    ws = tr._bufs[("seq", B, T)]["ws"]
+    lg = ops.seq_train_fwd(spec, flat, xt, yt, ws)
+    assert torch.isnan(lg).all()
+    _, probs = ops.seq_infer(spec, flat, xt, ws)
+    assert torch.isnan(probs).all()
+    with pytest.raises(nsd.NsdError, match="timed out"):
+        _raise_on_poison(probs.cpu().numpy(), xt.cpu().numpy(), "predict")
+    # a fresh workspace is clean
+    ws2 = ops.seq_workspace(spec, B, T, dev)
+    lg2 = ops.seq_train_fwd(spec, flat, xt, yt, ws2)
+    assert ops.seq_status(ws2) == 0 and torch.isfinite(lg2).all()
+    # an UNINITIALISED header (a C caller that forgot nsd_seq_workspace_init) reads as a failure, never as success
+    ws3 = torch.full_like(ws2, 0x5A)
+    lg3 = ops.seq_train_fwd(spec, flat, xt, yt, ws3)
+    assert ops.seq_status(ws3) != 0 and torch.isnan(lg3).all()
+
+
+def test_large_batches_at_small_hidden_sizes_take_the_layer_by_layer_scans(nsd, dev):
+    """H = 64 with more 32-trial tiles than fit the machine at once (B > 4096): the path switches to 64-trial tiles, for which the
+    fused two-layer launch is not built -- nsd_seq_supported / workspace_bytes / the run itself must agree on the general route."""
+    from nsd_amd import ops
+    H, L, K, B, T = 64, 2, 3, 4100, 3
+    d = orc.Dims(C=8, H=H, L=L, K=K)
+    spec = ops.ModelSpec(C=8, H=H, L=L, K=K)
+    assert spec.seq_path(B, T)
+    st = synth_params(8, H, L, K, seed=8)
+    x, y = synth_x(B, T, seed=6), synth_labels(B, K, seed=6)
+    flat_np = orc.flatten_state(st, d)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, d)
+    flat = torch.from_numpy(flat_np).to(dev)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    logits = ops.seq_train_fwd(spec, flat, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), ws)
+    g = ops.seq_train_bwd(spec, flat, ws, B, T)
+    st_code, one_xcd, spread = ops.seq_status(ws, detail=True)
+    assert st_code == 0 and one_xcd + spread == 2 * 2 * 65, (st_code, one_xcd, spread)     # layers x passes x 65 tiles of 64
+    assert np.abs(logits.cpu().numpy() - fw["logits"]).max() < SEQ_LOGIT_TOL
+    _grad_check(g.cpu().numpy(), g_ref, d)
+
+
+def test_trainer_normalize_trains_on_what_it_evaluates(nsd, dev):
+    """EEG_LSTM(normalize=True): Trainer.step z-scores the windows exactly as forward / predict_proba do -- the gradients equal
+    those of a normalize=False model fed pre-normalised windows (fp32 and bf16 paths)."""
+    from nsd_amd import ops
+    from nsd_amd.trainer import Trainer
+    for prec, H in (("fp32", 48), ("bf16", 64)):
+        torch.manual_seed(7)
+        a = nsd.EEG_LSTM(8, H, 2, 3, dropout=0.5, normalize=True, precision=prec).to(dev).train()
+        b = nsd.EEG_LSTM(8, H, 2, 3, dropout=0.5, normalize=False, precision=prec).to(dev).train()
+        b.load_state_dict(a.state_dict(), strict=True)
+        x = torch.from_numpy(5.0 + 30.0 * synth_x(40, 50, seed=3)).to(dev)              # far from zero mean / unit variance
+        y = torch.from_numpy(synth_labels(40, 3, seed=3)).to(dev)
+        ta, tb = Trainer(a, seed=11), Trainer(b, seed=11)
+        ta.step(x, y)
+        tb.step(ops.zscore(x), y)
+        assert torch.equal(ta.grads, tb.grads) and ta.grads.abs().max().item() > 0
+        assert torch.equal(a.flat_parameters(), b.flat_parameters())
+        if prec == "bf16":
+            with pytest.raises(nsd.NsdError, match="fp32 path only"):
+                ta.static_inputs(40, 50)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE cfg5 at its own sizes: H = 512, two directions, 64-trial tiles (NT = 2 instantiations), C = 64
+# ---------------------------------------------------------------------------------------------------
+def _cfg5_vs_torch(nsd, dev, B, T, rng, seed):
+    from nsd_amd import ops
+    from oracle.torch_ref import TorchRefEEG, host_cores
+    C, H, L, K, F = 64, 512, 2, 5, 32
+    st = synth_params(C, H, L, K, seed=seed, D=2)
+    spec = ops.ModelSpec(C=C, H=H, L=L, K=K, D=2)
+    flat = _flat_from_state(spec, st, dev)
+    x, y = synth_x(B, T, C=C, seed=seed + 1), synth_labels(B, K, seed=seed + 1)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    logits = ops.seq_train_fwd(spec, flat, torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), ws, rng=rng)
+    g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).cpu().numpy()
+    loss = float(ops.seq_loss_sum(spec, ws, B, T).item()) / B
+    status = ops.seq_status(ws, detail=True)
+    del ws
+    torch.set_num_threads(host_cores())
+    m = TorchRefEEG(C, H, L, K, bidirectional=True).eval()
+    m.load_reference_state({k: torch.from_numpy(v) for k, v in st.items()})
+    masks = ()
+    if rng is not None:
+        masks = (torch.from_numpy(orc.dropout_mask(rng["seed"], rng["base_stream"], rng["p_lstm"], (L - 1, B, T, 2 * H))),
+                 torch.from_numpy(orc.rrelu_noise(rng["seed"], rng["base_stream"] + 1, (B, F))),
+                 torch.from_numpy(orc.dropout_mask(rng["seed"], rng["base_stream"] + 2, rng["p_head"], (B, F))))
+    lg_ref = m(torch.from_numpy(x), *masks)
+    loss_ref = torch.nn.functional.cross_entropy(lg_ref, torch.from_numpy(y.astype(np.int64)))
+    loss_ref.backward()
+    g_ref = m.reference_named_grads()
+    offs = spec.offsets()
+    errs = {"logits": float(np.abs(logits.cpu().numpy() - lg_ref.detach().numpy()).max()), "loss": abs(loss - float(loss_ref))}
+    for k in spec.names():
+        ref = g_ref[k].numpy().ravel()
+        got = g[offs[k]:offs[k] + ref.size]
+        errs[k] = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6)) if k != "attn.bias" else float(np.abs(got - ref).max())
+    return status, errs
+
+
+@pytest.mark.timeout(900)
+def test_cfg5_kernels_two_launch_waves_64_steps_with_dropout_vs_torch(nsd, dev):
+    """H = 512 bidirectional, 64-trial tiles, B = 576 -> 9 groups per direction against 8 resident: TWO launches of every scan
+    (`cap` in nsd_seq.hip), T = 64 (the exchange rings wrap 32 times), in-kernel dropout / RReLU streams, against the torch
+    composition fed the tensors of the same streams.  This is the regression guard for the asm-MFMA accumulator hazard (DESIGN
+    4.3b finding 9) at a length where a stale accumulator cannot hide."""
+    rng = dict(seed=0xABCDEF, base_stream=24, p_lstm=0.6, p_head=0.6)
+    status, errs = _cfg5_vs_torch(nsd, dev, 576, 64, rng, seed=101)
+    print("cfg5 kernels, B=576 T=64, dropout streams: errors vs torch:", {k: round(v, 5) for k, v in errs.items()})
+    assert status[0] == 0 and status[1] + status[2] == 2 * 2 * 2 * 9, status               # layers x passes x directions x tiles
+    assert errs["logits"] < SEQ_LOGIT_TOL and errs["loss"] < 2e-2
+    for k, v in errs.items():
+        if k in ("logits", "loss"):
+            continue
+        assert v <= (1e-4 if k == "attn.bias" else SEQ_GRAD_RTOL), (k, v)
+
+
+@pytest.mark.timeout(1100)
+def test_cfg5_kernels_thousand_steps_vs_torch(nsd, dev):
+    """cfg5's own sequence length: T = 1000, C = 64, H = 512 bidirectional, 64-trial tiles (B = 264 -> 5 tiles): bf16 drift over
+    1000 recurrent steps, the owner-major saved blocks at T = 1000, the 0.65-GB projection / input-gradient matrices -- logits,
+    loss and every gradient tensor against the fp32 torch composition on the host cores (~1 min of CPU)."""
+    status, errs = _cfg5_vs_torch(nsd, dev, 264, 1000, None, seed=103)
+    print("cfg5 kernels, B=264 T=1000: errors vs torch:", {k: round(v, 5) for k, v in errs.items()})
+    assert status[0] == 0 and status[1] + status[2] == 2 * 2 * 2 * 5, status
+    assert errs["logits"] < SEQ_LOGIT_TOL and errs["loss"] < 2e-2
+    for k, v in errs.items():
+        if k in ("logits", "loss"):
+            continue
+        assert v <= (1e-4 if k == "attn.bias" else (2 * SEQ_GRAD_RTOL if k.startswith("fc.") else SEQ_GRAD_RTOL)), (k, v)
+
+
+@pytest.mark.timeout(900)
+def test_cfg5_full_size_properties(nsd, dev):
+    """BASELINE cfg5's per-GPU share at its full size (B = 512, T = 1000, C = 64, H = 512, bidirectional; 22.7-GB workspace)
+    through size-independent properties: determinism, sub-batch equality of the logits (bitwise where the same kernel
+    instantiation runs, within the bf16 bound across the 32- / 64-trial instantiations), gradient additivity over a batch split,
+    permutation invariance, status word."""
+    from nsd_amd import ops
+    C, H, L, K, B, T = 64, 512, 2, 5, 512, 1000
+    spec = ops.ModelSpec(C=C, H=H, L=L, K=K, D=2)
+    flat = _flat_from_state(spec, synth_params(C, H, L, K, seed=41, D=2), dev)
+    x = torch.from_numpy(synth_x(B, T, C=C, seed=42)).to(dev)
+    y = torch.from_numpy(synth_labels(B, K=K, seed=42)).to(dev)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    assert ws.numel() > 20e9
+    rng = dict(seed=77, base_stream=12, p_lstm=0.6, p_head=0.6)
+    lg = ops.seq_train_fwd(spec, flat, x, y, ws, rng=rng, scale=1.0 / B).clone()
+    g = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
+    st_code, one_xcd, spread = ops.seq_status(ws, detail=True)
+    assert st_code == 0 and one_xcd + spread == 2 * 2 * 2 * 8, (st_code, one_xcd, spread)
+    assert torch.isfinite(g).all() and torch.isfinite(lg).all() and g.abs().max().item() > 0
+    # determinism
+    lg2 = ops.seq_train_fwd(spec, flat, x, y, ws, rng=rng, scale=1.0 / B)
+    assert torch.equal(lg2, lg) and torch.equal(ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng), g)
+    # eval logits of sub-batches: 320 trials still run the 64-trial instantiation -> bitwise; 100 trials run the 32-trial one
+    full, _ = ops.seq_infer(spec, flat, x, ws)
+    sub, _ = ops.seq_infer(spec, flat, x[64:384].contiguous())
+    assert torch.equal(sub, full[64:384])
+    sub32, _ = ops.seq_infer(spec, flat, x[400:500].contiguous())
+    assert (sub32 - full[400:500]).abs().max().item() < 1e-2
+    # gradient additivity (no dropout: the streams are indexed by the position inside the batch)
+    ops.seq_train_fwd(spec, flat, x, y, ws, scale=1.0 / B)
+    ga = ops.seq_train_bwd(spec, flat, ws, B, T).clone()
+    tot = torch.zeros_like(ga)
+    for lo, hi in ((0, 320), (320, 512)):                       # 320 -> 64-trial tiles, 192 -> 32-trial tiles
+        wsp = ops.seq_workspace(spec, hi - lo, T, dev)
+        ops.seq_train_fwd(spec, flat, x[lo:hi].contiguous(), y[lo:hi].contiguous(), wsp, scale=1.0 / B)
+        tot += ops.seq_train_bwd(spec, flat, wsp, hi - lo, T)
+        assert ops.seq_status(wsp) == 0
+        del wsp
+    assert (ga - tot).abs().max().item() <= 3e-3 * ga.abs().max().item(), (ga - tot).abs().max().item() / ga.abs().max().item()
+    # permutation invariance of the mean gradient
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(dev)
+    ops.seq_train_fwd(spec, flat, x[perm].contiguous(), y[perm].contiguous(), ws, scale=1.0 / B)
+    gp = ops.seq_train_bwd(spec, flat, ws, B, T)
+    assert (gp - ga).abs().max().item() <= 3e-3 * ga.abs().max().item()
