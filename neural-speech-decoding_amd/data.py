@@ -85,21 +85,37 @@ def load_trials(directory: str, label_map: Optional[Dict[str, int]] = None, *, s
     return TrialSet(x=x, y=y, prefix=prefix, files=files, label_map=label_map)
 
 
-def load_trials_npz(path: str, label_map: Optional[Dict[str, int]] = None) -> TrialSet:
-    """The same TrialSet from a packed copy of the data set (`x` [N,T,C] float32, `prefix` [N], `stem` [N]; written by
-    tests/golden/make_trials_fixture.py with load_trials itself) -- the form in which the recorded trials travel to
-    machines that do not hold the CSV directory."""
+def load_trials_npz(path: str, label_map: Optional[Dict[str, int]] = None, x_key: str = "x") -> TrialSet:
+    """The same TrialSet from a packed copy of the data set (`x` [N,T,C] float32, `stem` [N] and optionally `prefix` [N]; written
+    by tests/golden/make_trials_fixture.py with load_trials itself) -- the form in which the recorded trials travel to
+    machines that do not hold the CSV directory.  `x_key`: the array holding the windows (`x_filt` in
+    tests/golden/recorded_trials_filtered.npz: the same trials as the reference's PreProcessor hands them to the model)."""
     label_map = dict(LABELS_3CLASS_CHECKPOINT if label_map is None else label_map)
     z = np.load(path, allow_pickle=False)
-    prefix_all = [str(p) for p in z["prefix"]]
+    if x_key not in z.files:
+        raise KeyError(f"{path!r} has no array {x_key!r} (arrays: {z.files})")
+    prefix_all = [str(p) for p in z["prefix"]] if "prefix" in z.files else [prefix_of(str(s)) for s in z["stem"]]
     keep = np.array([p in label_map for p in prefix_all])
     if not keep.any():
         raise FileNotFoundError(f"no trials with prefixes {sorted(label_map)} in {path!r}")
     prefix = [p for p, k in zip(prefix_all, keep) if k]
     files = [str(s) + ".csv" for s, k in zip(z["stem"], keep) if k]
-    x = np.ascontiguousarray(z["x"][keep], dtype=np.float32)
+    x = np.ascontiguousarray(z[x_key][keep], dtype=np.float32)
     y = np.array([label_map[p] for p in prefix], np.int32)
     return TrialSet(x=x, y=y, prefix=prefix, files=files, label_map=label_map)
+
+
+def stratified_folds(y: Sequence[int], k: int, seed: int = 0) -> List[np.ndarray]:
+    """k disjoint validation index sets covering every trial once, each with (nearly) the class proportions of the whole set."""
+    y = np.asarray(y)
+    rs = np.random.RandomState(seed)
+    folds: List[List[int]] = [[] for _ in range(k)]
+    for cls in np.unique(y):
+        idx = np.flatnonzero(y == cls)
+        rs.shuffle(idx)
+        for i, v in enumerate(idx):
+            folds[i % k].append(int(v))
+    return [np.sort(np.array(f, dtype=np.int64)) for f in folds]
 
 
 def stratified_split(y: Sequence[int], val_fraction: float = 0.2, seed: int = 0) -> Tuple[np.ndarray, np.ndarray]:

@@ -74,8 +74,7 @@ class _EEGFunction(torch.autograd.Function):
                                residual=module.residual)
         offs, shapes = spec.offsets(), spec.shapes()
         grads = tuple(g[offs[n]:offs[n] + math.prod(shapes[n])].view(shapes[n]) for n in spec.names())
-        ctx.ws = None
-        return (None, None, None) + grads
+        return (None, None, None) + grads          # (ctx.ws lives as long as the graph does: retain_graph may come back)
 
 
 class _EEGSeqFunction(torch.autograd.Function):
@@ -103,8 +102,7 @@ class _EEGSeqFunction(torch.autograd.Function):
         g = ops.seq_train_bwd(spec, module._flat, ctx.ws, B, T, rng=ctx.rng) * dloss
         offs, shapes = spec.offsets(), spec.shapes()
         grads = tuple(g[offs[n]:offs[n] + math.prod(shapes[n])].view(shapes[n]) for n in spec.names())
-        ctx.ws = None
-        return (None, None, None, None) + grads
+        return (None, None, None, None) + grads    # (the workspace stays with the graph: a second backward re-runs the scans on it)
 
 
 class EEG_LSTM(nn.Module):

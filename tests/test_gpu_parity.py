@@ -621,7 +621,7 @@ def test_multi_rank_launch_sequence_over_rccl_single_rank_group(nsd, dev, ref_st
             tb.step(x, y)
         finally:
             dist.all_reduce = orig
-        assert calls == [tb.flat.numel()]                  # exactly one collective per step, the whole flat gradient
+        assert calls == [tb.flat.numel() + 1]              # exactly one collective per step: the whole flat gradient + the failure flag behind it
         torch.cuda.synchronize()
         # tb scaled its CE gradient by 1/(B*2) (a power of two: exact), everything downstream is linear in it
         assert torch.equal(ta.grads, 2.0 * tb.grads)
@@ -825,3 +825,94 @@ def test_train_on_recorded_trials(nsd, dev, tmp_path):
     with torch.no_grad():
         acc = float((pred.model(_t(ts.x[va], dev)).argmax(-1).cpu().numpy() == ts.y[va]).mean())
     assert acc == pytest.approx(done["best_val_acc"], abs=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+# SimplePredictor.predict WITH the reference's preprocessing (lstm_eeg_model.py:66,91): fixture of the reference's own run
+# ---------------------------------------------------------------------------------------------------
+FILTERED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "recorded_trials_filtered.npz")
+
+
+class _ReplayPreProcessor:
+    """Stands where the reference's PreProcessor stands (same .transform([T,C]) -> [T,C] contract, preprocessor.py:21-36) and
+    returns, for a recorded window, exactly what the reference's MindsAI-filter-backed PreProcessor returned for it
+    (tests/golden/recorded_trials_filtered.npz).  The filter itself is third-party and is never restated."""
+
+    def __init__(self, raw, filtered):
+        self.table = {np.ascontiguousarray(r).tobytes(): f for r, f in zip(raw, filtered)}
+
+    def transform(self, chunk):
+        x = np.asarray(chunk)
+        if x.ndim != 2:
+            raise ValueError(f"Expected 2D array [samples, channels], got {x.shape}")
+        return self.table[np.ascontiguousarray(x, dtype=np.float32).tobytes()]
+
+
+def test_predict_with_the_references_preprocessing(nsd, dev, ref_state, tmp_path):
+    """The reference's `SimplePredictor.predict` as tester.py:83-88 runs it -- MindsAI filter ON, reference checkpoint -- on all
+    324 recorded windows (fixture: the filtered windows and the probabilities / labels the reference returned, generated by
+    tests/golden/make_predict_fixture.py from the imported reference).  This facade, given the same filtered windows through the
+    preprocessor slot, must return the same probabilities (1e-5) and the same label for every window; per-window predict() and
+    the batched predict_windows() route both."""
+    rec, flt = np.load(RECORDED), np.load(FILTERED)
+    assert list(rec["stem"]) == list(flt["stem"])
+    raw, xf, want, labels = rec["x"], flt["x_filt"], flt["ref_probs"], [str(s) for s in flt["ref_label"]]
+    assert np.abs(raw - xf).max() > 1.0                         # the filter really changes the windows (tens of microvolts)
+    pred = nsd.SimplePredictor(_write_pth(str(tmp_path), ref_state, False), sr=125, device="cpu",
+                               preprocess=_ReplayPreProcessor(raw, xf))
+    worst, flips = 0.0, 0
+    for i in range(0, len(raw), 9):                             # 36 windows one by one, the live loop's shape (B = 1, T = 625)
+        probs, label = pred.predict(raw[i])
+        worst = max(worst, float(np.abs(probs - want[i]).max()))
+        flips += label != labels[i]
+    assert worst < 1e-5 and flips == 0, (worst, flips)
+    # every window, batched: the same preprocess -> model -> softmax per window
+    for lo in range(0, len(raw), 108):
+        block = np.concatenate(list(raw[lo:lo + 108]), axis=0)
+        probs, labs = pred.predict_windows(block, 625)
+        assert np.abs(probs - want[lo:lo + 108]).max() < 1e-5
+        assert labs == labels[lo:lo + 108]
+    # the accuracy anchor of BASELINE.md section 2: 68.7 % under the checkpoint's label order (Water, Food, Noise)
+    from nsd_amd import data as Dm
+    three = [i for i, s in enumerate(rec["prefix"]) if str(s) in Dm.LABELS_3CLASS_CHECKPOINT]
+    acc = np.mean([int(want[i].argmax()) == Dm.LABELS_3CLASS_CHECKPOINT[str(rec["prefix"][i])] for i in three])
+    assert acc == pytest.approx(123 / 179)
+
+
+def test_shipped_default_checkpoint_is_paired_with_the_references_preprocessing(nsd, dev):
+    """tester.DEFAULT_MODEL is this repository's own training output (not the reference's file): trained on the windows as the
+    reference's PreProcessor hands them to the model (x_filt), i.e. for the predictor's DEFAULT preprocessing.  It must load
+    strict=True, classify those windows far above chance, and do visibly worse on unfiltered windows (the train/serve skew the
+    pairing avoids)."""
+    from nsd_amd import data as Dm, tester
+    assert os.path.isfile(tester.DEFAULT_MODEL)
+    rec, flt = np.load(RECORDED), np.load(FILTERED)
+    pred = nsd.SimplePredictor(tester.DEFAULT_MODEL, sr=125, preprocess=_ReplayPreProcessor(rec["x"], flt["x_filt"]))
+    three = [i for i, s in enumerate(rec["prefix"]) if str(s) in Dm.LABELS_3CLASS_CHECKPOINT]
+    y = np.array([Dm.LABELS_3CLASS_CHECKPOINT[str(rec["prefix"][i])] for i in three])
+    with torch.no_grad():
+        acc_f = float((pred.model(_t(flt["x_filt"][three], dev)).argmax(-1).cpu().numpy() == y).mean())
+        acc_r = float((pred.model(_t(rec["x"][three], dev)).argmax(-1).cpu().numpy() == y).mean())
+    print(f"shipped checkpoint: accuracy on its training windows (filtered) {acc_f:.3f}, on the same windows unfiltered {acc_r:.3f}")
+    assert acc_f >= 0.70 and acc_f > acc_r
+    probs, label = pred.predict(rec["x"][three[0]])
+    assert probs.shape == (3,) and label in nsd.CLASS_NAMES
+
+
+@pytest.mark.timeout(900)
+def test_train_cli_kfold_reports_mean_and_sd_without_epoch_selection(nsd, dev, tmp_path):
+    """nsd_amd.train --kfold 3 on the filtered windows: every fold trains for the same pre-set number of epochs and is scored after
+    its LAST epoch; the line reports mean and sd over the folds; --out is then trained on all trials with the same recipe."""
+    import json
+    from nsd_amd import train as cli
+    out, log = str(tmp_path / "kf.pth"), str(tmp_path / "kf.jsonl")
+    rc = cli.main(["--data", FILTERED, "--npz-key", "x_filt", "--classes", "3", "--epochs", "40", "--batch", "32", "--lr", "0.003",
+                   "--seed", "1", "--kfold", "3", "--out", out, "--log-every", "20", "--log-jsonl", log])
+    assert rc == 0 and os.path.exists(out)
+    recs = [json.loads(l) for l in open(log)]
+    done = recs[-1]
+    folds = [r for r in recs if "fold" in r]
+    assert done["done"] and done["kfold"] == 3 and len(folds) == 3 and sum(r["n_val"] for r in folds) == 179
+    assert done["acc_val_mean"] == pytest.approx(np.mean([r["acc_val_last_epoch"] for r in folds]), abs=1e-3)
+    assert done["acc_val_mean"] > 0.45 and done["acc_val_sd"] >= 0.0 and done["shipped"]["trained_on"] == 179
+    nsd.SimplePredictor(out, sr=125, preprocess="identity")                 # strict=True load

@@ -152,7 +152,7 @@ from tests.golden.make_goldens import synth_labels, synth_params, synth_x      #
 
 # bf16 operands / bf16 saved activations, fp32 accumulation: measured agreement with the fp32 oracle is ~1e-2 on logits
 # of magnitude ~1 and a few percent of each gradient tensor's largest element; the bounds below are ~3x that.
-SEQ_LOGIT_TOL = 4e-2
+SEQ_LOGIT_TOL = 2e-2
 SEQ_GRAD_RTOL = 6e-2
 
 
@@ -175,6 +175,7 @@ def _grad_check(got, ref, d, rtol=SEQ_GRAD_RTOL, fc_rtol=None):
         else:
             rt = fc_rtol if (fc_rtol is not None and k.startswith("fc.")) else rtol
             assert err <= rt * scale + 1e-6, (k, err, scale)
+    print("    [grad err / max|grad|] worst:", max((v, k) for k, v in worst.items() if k != "attn.bias"))
     return worst
 
 

@@ -19,7 +19,7 @@ for mode in ("infer", "train"):
         else:
             ops.seq_train_fwd(spec, flat, x, y, ws, rng=dict(seed=1, base_stream=4, p_lstm=0.6, p_head=0.6))
         torch.cuda.synchronize()
-    st = ws[:128].cpu().numpy().view(np.int32)
+    st = ws[256:384].cpu().numpy().view(np.int32)
     acc = st[4:20].view(np.uint64)
     tot = acc.sum()
     print(f"{mode}: forward scan, cycles per step of workgroup 0 wave 0 (s_memtime = 100 MHz ticks? see total): total/step {tot / (T + 1):.0f}")
@@ -29,7 +29,7 @@ g = torch.zeros(spec.param_count, device=dev)
 for _ in range(3):
     ops.seq_train_bwd(spec, flat, ws, B, T, rng=dict(seed=1, base_stream=4, p_lstm=0.6, p_head=0.6), grads=g)
     torch.cuda.synchronize()
-acc = ws[:128].cpu().numpy().view(np.int32)[4:20].view(np.uint64)
+acc = ws[256:384].cpu().numpy().view(np.int32)[4:20].view(np.uint64)
 tot = acc.sum()
 print(f"backward scan: total/step {tot / (T + 1):.0f}")
 for n, v in zip(["poll", "partial-sum loads + add", "cells (dh-dependent part)", "own da -> LDS + barrier", "MFMA (48) + saved-set request", "convert + ring stores", "drain + flag", "row-major stores + cell factors of the next step"], acc):
@@ -47,7 +47,7 @@ if "--cfg5" in sys.argv:
         ops.seq_train_fwd(spec, flat, x, y, ws, rng=dict(seed=1, base_stream=4, p_lstm=0.6, p_head=0.6))
         ops.seq_train_bwd(spec, flat, ws, B, T, rng=dict(seed=1, base_stream=4, p_lstm=0.6, p_head=0.6), grads=g)
         torch.cuda.synchronize()
-    acc = ws[:128].cpu().numpy().view(np.int32)[4:20].view(np.uint64)
+    acc = ws[256:384].cpu().numpy().view(np.int32)[4:20].view(np.uint64)
     tot = acc.sum()
     print(f"cfg5 backward scan (layer 0, workgroup 0 wave 0): total/step {tot / T:.0f}")
     for n, v in zip(["poll", "partial-sum loads + add", "cell (dh-dependent part)", "own da -> LDS + barrier", "saved-set request + 64 MFMAs + convert + ring stores", "-", "drain + flag", "row-major stores + upstream term + cell factors of the next step"], acc):
