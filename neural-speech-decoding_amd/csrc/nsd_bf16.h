@@ -49,6 +49,13 @@ __device__ __forceinline__ bf16x8 cat_tr(const s16x4 lo, const s16x4 hi) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// ---- streaming (nt) accesses for what a scan touches ONCE per launch: saved activations, row-major copies for the GEMMs, inputs.
+// The exchange rings of a scan group are rewritten every other step and live in the XCD's L2 as dirty lines (the L2 is write-back:
+// tools/micro/l2_writeback.hip -- 419 MB stored into a resident 1-MB ring leave 1 MB on the fabric); a ring of a few MB per XCD
+// survives there only if the step's streaming bytes do not push it out, so those carry the non-temporal hint.
+template <class V> __device__ __forceinline__ V ld_stream(const void *p) { return __builtin_nontemporal_load(reinterpret_cast<const V *>(p)); }
+template <class V> __device__ __forceinline__ void st_stream(void *p, const V v) { __builtin_nontemporal_store(v, reinterpret_cast<V *>(p)); }
+
 // ---- agent-scope (sc1) accesses for data exchanged between workgroups inside one launch --------------------------------
 // Stores write through (the line is not kept in the XCD's L2), loads bypass the CU's L1: together with a drained
 // vmcnt + a flag they are the hand-off of MI355X guide, Guideline 16 (R1), with no release/acquire fence.

@@ -154,11 +154,11 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 const bf16_t *src = a.xbf + seq_row(t, b0 + 32 * nt + col, a.T) * CP + 8 * hh;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < ks0) xf[nt][k] = *reinterpret_cast<const bf16x8 *>(src + 16 * k);
+                    if (k < ks0) xf[nt][k] = ld_stream<bf16x8>(src + 16 * k);
             } else {
                 const bf16_t *src = a.xproj[dir] + ((((long)((b0 >> 5) + nt) * a.T + t) * (G >> 5) + gt) * 64 + lane) * 16;
-                xp[nt][0] = *reinterpret_cast<const u32x4 *>(src);
-                xp[nt][1] = *reinterpret_cast<const u32x4 *>(src + 8);
+                xp[nt][0] = ld_stream<u32x4>(src);
+                xp[nt][1] = ld_stream<u32x4>(src + 8);
             }
         }
     };
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int b = b0 + 32 * nt + col;
             const long row = seq_row(t, b, a.T);
-            *reinterpret_cast<u32x2 *>(a.hs + row * ld + dir * H + u0) = u32x2{hw[nt][0], hw[nt][1]};
+            st_stream<u32x2>(a.hs + row * ld + dir * H + u0, u32x2{hw[nt][0], hw[nt][1]});
             if (a.lk) {
                 float m[4] = {1.f, 1.f, 1.f, 1.f};
                 if (a.rng.on && b < a.B) {
@@ -276,16 +276,16 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 // the multiplier acts on the value the next layer really reads: the bf16 h (+ the residual input, extension)
                 float h0 = bf16_lo(hw[nt][0]), h1 = bf16_hi(hw[nt][0]), h2 = bf16_lo(hw[nt][1]), h3 = bf16_hi(hw[nt][1]);
                 if (a.res) {
-                    const u32x2 rv2 = *reinterpret_cast<const u32x2 *>(a.res + row * ld + dir * H + u0);
+                    const u32x2 rv2 = ld_stream<u32x2>(a.res + row * ld + dir * H + u0);
                     h0 += bf16_lo(rv2[0]); h1 += bf16_hi(rv2[0]); h2 += bf16_lo(rv2[1]); h3 += bf16_hi(rv2[1]);
                 }
                 u32x2 v = {pack_bf16x2(h0 * m[0], h1 * m[1]), pack_bf16x2(h2 * m[2], h3 * m[3])};
-                *reinterpret_cast<u32x2 *>(a.lk + row * ld + dir * H + u0) = v;
+                st_stream<u32x2>(a.lk + row * ld + dir * H + u0, v);
             }
             if (train) {
                 u32x2 cv = {pack_bf16x2(c[nt][0], c[nt][1]), pack_bf16x2(c[nt][2], c[nt][3])};
                 const long blk = saved_block((b0 >> 5) + nt, P, me.p, a.T, t, wave);
-                *reinterpret_cast<u32x2 *>(a.cs[dir] + saved_cs(blk, lane)) = cv;
+                st_stream<u32x2>(a.cs[dir] + saved_cs(blk, lane), cv);
                 unsigned gw[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                     gw[2 * j + 1] = pack_bf16x2(gg[nt][j], go[nt][j]);
                 }
                 bf16_t *gd = a.ga[dir] + saved_ga(blk, 0, lane);
-                *reinterpret_cast<u32x4 *>(gd) = u32x4{gw[0], gw[1], gw[2], gw[3]};
-                *reinterpret_cast<u32x4 *>(gd + 512) = u32x4{gw[4], gw[5], gw[6], gw[7]};
+                st_stream<u32x4>(gd, u32x4{gw[0], gw[1], gw[2], gw[3]});
+                st_stream<u32x4>(gd + 512, u32x4{gw[4], gw[5], gw[6], gw[7]});
             }
         }
     }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dpl[nt][j] = TOP ? a.dpooled[(long)(b0 + 32 * nt + col) * ld + dir * H + u0 + j] : 0.f;
     const char *ring0 = reinterpret_cast<const char *>(a.xch) + ((long)dir * a.groups_total + a.group0 + me.group) * SLOT_BYTES;
-    const long slot_stride = (long)a.D * a.groups_total * SLOT_BYTES;
+    unsigned *gacks = gflags + ACK_WORD;                      // consume counters of the group (single-slot ring: nsd_scan2.hip, "backward")
     // block (consumer, producer, nt, consumer wave) of 64 lanes x 8 B; with NT == 2 the two halves share one block of 64 lanes x 16 B
     auto blk_off = [&](const int cons, const int prod, const int nt, const int q) {
         return NT == 2 ? (unsigned)((((cons * P + prod) * 4 + q)) << 10) : (unsigned)(((((cons * P + prod) * NT + nt) * 4 + q)) << 9);
@@ -384,13 +384,13 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             const long row = seq_row(t, b, T);
             const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t, wave);
             const bf16_t *gs = a.ga[dir] + saved_ga(blk, 0, lane);
-            v.gq[nt][0] = *reinterpret_cast<const u32x4 *>(gs);
-            v.gq[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 512);
-            v.cq[nt] = *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk, lane));
+            v.gq[nt][0] = ld_stream<u32x4>(gs);
+            v.gq[nt][1] = ld_stream<u32x4>(gs + 512);
+            v.cq[nt] = ld_stream<u32x2>(a.cs[dir] + saved_cs(blk, lane));
             const bool first = dir == 0 ? t == 0 : t == T - 1;
-            v.cpq[nt] = first ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs[dir] + saved_cs(blk + 4 * (tprev - t), lane));
-            if constexpr (TOP) { v.al[nt] = a.alpha[row]; v.ds[nt] = a.dscore[row]; }
-            else v.dv[nt] = *reinterpret_cast<const f32x4 *>(a.din + row * ld + dir * H + u0);
+            v.cpq[nt] = first ? u32x2{0u, 0u} : ld_stream<u32x2>(a.cs[dir] + saved_cs(blk + 4 * (tprev - t), lane));
+            if constexpr (TOP) { v.al[nt] = ld_stream<float>(a.alpha + row); v.ds[nt] = ld_stream<float>(a.dscore + row); }
+            else v.dv[nt] = ld_stream<f32x4>(a.din + row * ld + dir * H + u0);
         }
     };
     Saved sv;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dup[nt][j] = fmaf(sv.al[nt], dpl[nt][j], sv.ds[nt] * aw[j]);
             }
-            if (a.dres) *reinterpret_cast<f32x4 *>(a.dres + row * ld + dir * H + u0) = f32x4{dup[nt][0], dup[nt][1], dup[nt][2], dup[nt][3]};
+            if (a.dres) st_stream<f32x4>(a.dres + row * ld + dir * H + u0, f32x4{dup[nt][0], dup[nt][1], dup[nt][2], dup[nt][3]});
             pin(fc[nt]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) pin(dup[nt][j]);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             }
             stp.mark(0);
             // the partial sums the P members sent this wave at step s-1, added in member order
-            const nsd_rsrc rr = make_rsrc(ring0 + (long)((s - 1) & 1) * slot_stride, (unsigned)SLOT_BYTES);
+            const nsd_rsrc rr = make_rsrc(ring0, (unsigned)SLOT_BYTES);
             if constexpr (NT == 2) {                             // both 32-trial halves of a lane in ONE 16-byte piece (half the instructions)
                 u32x4 v16[P];
 #pragma unroll
@@ -464,6 +464,9 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                         drec[nt][2] += bf16_lo(v8[q][nt][1]); drec[nt][3] += bf16_hi(v8[q][nt][1]);
                     }
             }
+            // this wave has taken its partial sums of step s-1 out of the ring: the producers may rewrite the slot
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_xchg_u32(same_l2, gacks + 4 * me.p + wave, (unsigned)s);
         }
         stp.mark(1);
         // ---- the dh-dependent rest of the cell: da_t
@@ -486,10 +489,13 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             __syncthreads();
             if (s_abort) break;
             stp.mark(3);
+            // the consume counters of the group, requested now and looked at before the first ring store of the step (the MFMAs of
+            // a consumer's row tile lie in between): every member must have taken step s-1's sums before the slot is rewritten
+            unsigned ackv = ld_sc1_u32(gacks + (lane < 4 * P ? lane : 0));     // (every lane loads: no exec-masked block for the compare to be pulled into)
             load_saved(s + 1, sv);
             __builtin_amdgcn_sched_barrier(0);
             if (has_rows) {
-                const nsd_rsrc rw = make_rsrc(ring0 + (long)(s & 1) * slot_stride, (unsigned)SLOT_BYTES);
+                const nsd_rsrc rw = make_rsrc(ring0, (unsigned)SLOT_BYTES);
                 constexpr int NF = KS * NT, D = NF < 4 ? NF : 4;
                 auto frag = [&](const int i) { return *reinterpret_cast<const bf16x8 *>(&dab[par][i / NT][i % NT][lane * 8]); };
 #pragma unroll
@@ -509,6 +515,10 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) mfma_settle(acc[nt]);
+                    if (ri == 0) pin(ackv);                              // the compare stays HERE: at the load it would expose an L2 round trip per step
+                    if (ri == 0 && !__all(ackv >= (unsigned)s)) {   // (rare: the counters were read ~2 000 cycles after they were written)
+                        if (!wait_group<4 * P>(gacks, (unsigned)s, lane) && lane == 0) { s_abort = 1; report_timeout(a.status, ST_BWD_TIMEOUT); }
+                    }
                     if constexpr (NT == 2) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -536,8 +546,8 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             bf16_t *d = a.da + seq_row(t, b0 + 32 * nt + col, T) * ldda + dir * G + 4 * u0;
-            *reinterpret_cast<u32x4 *>(d) = u32x4{dw[nt][0], dw[nt][1], dw[nt][2], dw[nt][3]};
-            *reinterpret_cast<u32x4 *>(d + 8) = u32x4{dw[nt][4], dw[nt][5], dw[nt][6], dw[nt][7]};
+            st_stream<u32x4>(d, u32x4{dw[nt][0], dw[nt][1], dw[nt][2], dw[nt][3]});
+            st_stream<u32x4>(d + 8, u32x4{dw[nt][4], dw[nt][5], dw[nt][6], dw[nt][7]});
         }
     }
     stp.store(a.status, blockIdx.x == 0 && tid == 0);

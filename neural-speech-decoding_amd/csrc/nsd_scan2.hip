@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             const bf16_t *src = a.xbf + seq_row(t, b0 + 32 * nt + col, T) * CP + 8 * hh;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (k < ks0) xf[nt][k] = *reinterpret_cast<const bf16x8 *>(src + 16 * k);
+                if (k < ks0) xf[nt][k] = ld_stream<bf16x8>(src + 16 * k);
         }
     };
 #pragma unroll
@@ -210,31 +210,31 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             const int b = b0 + 32 * nt + col;
             if (do0 && train) {
                 const long row = seq_row(t0, b, T);
-                *reinterpret_cast<u32x2 *>(a.hs0 + row * H + u0) = u32x2{hw0[nt][0], hw0[nt][1]};
-                if (masked) *reinterpret_cast<u32x2 *>(a.lk0 + row * H + u0) = u32x2{lw0[nt][0], lw0[nt][1]};
+                st_stream<u32x2>(a.hs0 + row * H + u0, u32x2{hw0[nt][0], hw0[nt][1]});
+                if (masked) st_stream<u32x2>(a.lk0 + row * H + u0, u32x2{lw0[nt][0], lw0[nt][1]});
             }
-            if (do1) *reinterpret_cast<u32x2 *>(a.hs1 + seq_row(t1, b, T) * H + u0) = u32x2{hw1[nt][0], hw1[nt][1]};
+            if (do1) st_stream<u32x2>(a.hs1 + seq_row(t1, b, T) * H + u0, u32x2{hw1[nt][0], hw1[nt][1]});
         }
         if (train) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (do0) {
                     const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t0, wave);
-                    *reinterpret_cast<u32x2 *>(a.cs0 + saved_cs(blk, lane)) = u32x2{pack_bf16x2(c0[nt][0], c0[nt][1]), pack_bf16x2(c0[nt][2], c0[nt][3])};
+                    st_stream<u32x2>(a.cs0 + saved_cs(blk, lane), u32x2{pack_bf16x2(c0[nt][0], c0[nt][1]), pack_bf16x2(c0[nt][2], c0[nt][3])});
                     bf16_t *gd = a.ga0 + saved_ga(blk, 0, lane);
-                    *reinterpret_cast<u32x4 *>(gd) = u32x4{pack_bf16x2(g0[nt][0][0], g0[nt][0][1]), pack_bf16x2(g0[nt][0][2], g0[nt][0][3]),
-                                                           pack_bf16x2(g0[nt][1][0], g0[nt][1][1]), pack_bf16x2(g0[nt][1][2], g0[nt][1][3])};
-                    *reinterpret_cast<u32x4 *>(gd + 512) = u32x4{pack_bf16x2(g0[nt][2][0], g0[nt][2][1]), pack_bf16x2(g0[nt][2][2], g0[nt][2][3]),
-                                                               pack_bf16x2(g0[nt][3][0], g0[nt][3][1]), pack_bf16x2(g0[nt][3][2], g0[nt][3][3])};
+                    st_stream<u32x4>(gd, u32x4{pack_bf16x2(g0[nt][0][0], g0[nt][0][1]), pack_bf16x2(g0[nt][0][2], g0[nt][0][3]),
+                                                pack_bf16x2(g0[nt][1][0], g0[nt][1][1]), pack_bf16x2(g0[nt][1][2], g0[nt][1][3])});
+                    st_stream<u32x4>(gd + 512, u32x4{pack_bf16x2(g0[nt][2][0], g0[nt][2][1]), pack_bf16x2(g0[nt][2][2], g0[nt][2][3]),
+                                                      pack_bf16x2(g0[nt][3][0], g0[nt][3][1]), pack_bf16x2(g0[nt][3][2], g0[nt][3][3])});
                 }
                 if (do1) {
                     const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t1, wave);
-                    *reinterpret_cast<u32x2 *>(a.cs1 + saved_cs(blk, lane)) = u32x2{pack_bf16x2(c1[nt][0], c1[nt][1]), pack_bf16x2(c1[nt][2], c1[nt][3])};
+                    st_stream<u32x2>(a.cs1 + saved_cs(blk, lane), u32x2{pack_bf16x2(c1[nt][0], c1[nt][1]), pack_bf16x2(c1[nt][2], c1[nt][3])});
                     bf16_t *gd = a.ga1 + saved_ga(blk, 0, lane);
-                    *reinterpret_cast<u32x4 *>(gd) = u32x4{pack_bf16x2(g1[nt][0][0], g1[nt][0][1]), pack_bf16x2(g1[nt][0][2], g1[nt][0][3]),
-                                                           pack_bf16x2(g1[nt][1][0], g1[nt][1][1]), pack_bf16x2(g1[nt][1][2], g1[nt][1][3])};
-                    *reinterpret_cast<u32x4 *>(gd + 512) = u32x4{pack_bf16x2(g1[nt][2][0], g1[nt][2][1]), pack_bf16x2(g1[nt][2][2], g1[nt][2][3]),
-                                                               pack_bf16x2(g1[nt][3][0], g1[nt][3][1]), pack_bf16x2(g1[nt][3][2], g1[nt][3][3])};
+                    st_stream<u32x4>(gd, u32x4{pack_bf16x2(g1[nt][0][0], g1[nt][0][1]), pack_bf16x2(g1[nt][0][2], g1[nt][0][3]),
+                                                pack_bf16x2(g1[nt][1][0], g1[nt][1][1]), pack_bf16x2(g1[nt][1][2], g1[nt][1][3])});
+                    st_stream<u32x4>(gd + 512, u32x4{pack_bf16x2(g1[nt][2][0], g1[nt][2][1]), pack_bf16x2(g1[nt][2][2], g1[nt][2][3]),
+                                                      pack_bf16x2(g1[nt][3][0], g1[nt][3][1]), pack_bf16x2(g1[nt][3][2], g1[nt][3][3])});
                 }
             }
         }
@@ -253,7 +253,14 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
 // reads 48 KB, the K reduction ends inside one wave, and nothing of the cell waits for LDS.  Rounding the partial sums to bf16
 // costs about what rounding da to bf16 already costs (both ~2^-9 relative on terms of the same sum); parity tests unchanged.
 //
-// ring slot of a group (step parity):  R16 [consumer member][producer member][nt][consumer wave 4][lane 64] x 16 B =
+// The ring of a group has ONE slot, and it lives in the XCD's L2: the L2 is write-back (tools/micro/l2_writeback.hip), a group on one
+// XCD stores with plain stores, and a slot that is rewritten every step stays there as dirty lines as long as it fits -- 1.5 MB per
+// XCD at cfg3, where two parity slots (3 MB of the 4-MB L2, beside the step's streaming bytes) were written back every step:
+// 3 GB of the launch's 8 GB of fabric traffic, and as much again in reads that missed.  One slot needs a second handshake: a wave
+// counts what it has CONSUMED (consume counter s = "I hold the sums of step s-1"), and a producer looks at the group's consume
+// counters before its first ring store of step s.  The counters are requested right after the step barrier and were written
+// ~2 000 cycles earlier, so the look is a register compare; the bounded poll behind it is the rare path.
+// ring slot of a group:  R16 [consumer member][producer member][nt][consumer wave 4][lane 64] x 16 B =
 //   {rec1 = W_hh1^T da1 (4 bf16) | din0 = W_ih1^T da1 (4 bf16)} of the lane's 4 units, R8 the same index x 8 B = rec0 = W_hh0^T da0.
 //   A producer wave's accumulator registers 4q..4q+3 of lane (trial, hh) ARE consumer wave q's lane (trial, hh) units, so
 //   every store / load instruction moves one contiguous 1-KB / 512-B block (whole lines, one producer each).
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dpl[nt][j] = a.dpooled[(long)(b0 + 32 * nt + col) * H + u0 + j];
     const char *ring0 = reinterpret_cast<const char *>(a.xch) + (long)(a.group0 + me.group) * Ring::SLOT_BYTES;
-    const long slot_stride = (long)a.groups_total * Ring::SLOT_BYTES;
+    unsigned *gacks = gflags + ACK_WORD;                      // consume counters of the group: the ring has ONE slot (see "backward" above)
 
     // Saved activations / upstream terms of a step (HBM reads, independent of the recurrence).  Vector memory returns in issue
     // order: an HBM read issued just before the flag poll or before the publishing drain puts its whole latency on the step.
@@ -343,10 +350,10 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
                 const long row = seq_row(x1, b, T);
                 const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x1, wave);
                 const bf16_t *gs = a.ga1 + saved_ga(blk, 0, lane);
-                v.q1[nt][0] = *reinterpret_cast<const u32x4 *>(gs); v.q1[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 512);
-                v.cq1[nt] = *reinterpret_cast<const u32x2 *>(a.cs1 + saved_cs(blk, lane));
-                v.cp1[nt] = x1 == 0 ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs1 + saved_cs(blk - 4, lane));   // (step x1 - 1: 4 blocks back)
-                v.al[nt] = a.alpha[row]; v.ds[nt] = a.dscore[row];
+                v.q1[nt][0] = ld_stream<u32x4>(gs); v.q1[nt][1] = ld_stream<u32x4>(gs + 512);
+                v.cq1[nt] = ld_stream<u32x2>(a.cs1 + saved_cs(blk, lane));
+                v.cp1[nt] = x1 == 0 ? u32x2{0u, 0u} : ld_stream<u32x2>(a.cs1 + saved_cs(blk - 4, lane));   // (step x1 - 1: 4 blocks back)
+                v.al[nt] = ld_stream<float>(a.alpha + row); v.ds[nt] = ld_stream<float>(a.dscore + row);
             } else {
                 v.q1[nt][0] = u32x4{0u, 0u, 0u, 0u}; v.q1[nt][1] = u32x4{0u, 0u, 0u, 0u}; v.cq1[nt] = u32x2{0u, 0u}; v.cp1[nt] = u32x2{0u, 0u};
                 v.al[nt] = 0.f; v.ds[nt] = 0.f;
@@ -354,9 +361,9 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             if (d0) {
                 const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x0, wave);
                 const bf16_t *gs = a.ga0 + saved_ga(blk, 0, lane);
-                v.q0[nt][0] = *reinterpret_cast<const u32x4 *>(gs); v.q0[nt][1] = *reinterpret_cast<const u32x4 *>(gs + 512);
-                v.cq0[nt] = *reinterpret_cast<const u32x2 *>(a.cs0 + saved_cs(blk, lane));
-                v.cp0[nt] = x0 == 0 ? u32x2{0u, 0u} : *reinterpret_cast<const u32x2 *>(a.cs0 + saved_cs(blk - 4, lane));
+                v.q0[nt][0] = ld_stream<u32x4>(gs); v.q0[nt][1] = ld_stream<u32x4>(gs + 512);
+                v.cq0[nt] = ld_stream<u32x2>(a.cs0 + saved_cs(blk, lane));
+                v.cp0[nt] = x0 == 0 ? u32x2{0u, 0u} : ld_stream<u32x2>(a.cs0 + saved_cs(blk - 4, lane));
             } else {
                 v.q0[nt][0] = u32x4{0u, 0u, 0u, 0u}; v.q0[nt][1] = u32x4{0u, 0u, 0u, 0u}; v.cq0[nt] = u32x2{0u, 0u}; v.cp0[nt] = u32x2{0u, 0u};
             }
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             }
             stp.mark(0);
             // the partial sums the P members sent this wave at step s-1, added in member order
-            const nsd_rsrc rr = make_rsrc(ring0 + (long)((s - 1) & 1) * slot_stride, (unsigned)Ring::SLOT_BYTES);
+            const nsd_rsrc rr = make_rsrc(ring0, (unsigned)Ring::SLOT_BYTES);
             u32x4 v16[P][NT];
             u32x2 v8[P][NT];
 #pragma unroll
@@ -417,6 +424,9 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
                     drec0[nt][0] += bf16_lo(v8[q][nt][0]); drec0[nt][1] += bf16_hi(v8[q][nt][0]);
                     drec0[nt][2] += bf16_lo(v8[q][nt][1]); drec0[nt][3] += bf16_hi(v8[q][nt][1]);
                 }
+            // this wave has taken its partial sums of step s-1 out of the ring: the producers may rewrite the slot
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_xchg_u32(same_l2, gacks + 4 * me.p + wave, (unsigned)s);
             stp.mark(1);
         }
         // ---- the dh-dependent rest of both cells: da1_{t1}, da0_{t0}
@@ -456,12 +466,14 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             __syncthreads();
             if (s_abort) break;
             stp.mark(3);
+            // the consume counters of the group, requested now and looked at before the first ring store of the step
+            unsigned ackv = ld_sc1_u32(gacks + (lane < 4 * P ? lane : 0));     // (every lane loads: no exec-masked block for the compare to be pulled into)
             if (!(NSD_SCAN_ABLATE & (8 | 16 | 32 | 64))) load_saved(s + 1, sv);   // (its factors were taken at the top of the step: the registers are free)
             __builtin_amdgcn_sched_barrier(0);
             // ---- partial sums of dh for every unit of the group from this workgroup's 128 + 128 columns, one consumer (row tile) at
             // a time: its three accumulator tiles are converted and sent while the next consumer's MFMAs run
             if (has_rows) {
-                const nsd_rsrc rw = make_rsrc(ring0 + (long)(s & 1) * slot_stride, (unsigned)Ring::SLOT_BYTES);
+                const nsd_rsrc rw = make_rsrc(ring0, (unsigned)Ring::SLOT_BYTES);
                 constexpr int NF = KS * NT, D = 3;
                 auto frag = [&](const int layer, const int i) { return *reinterpret_cast<const bf16x8 *>(&dab[par][layer][i / NT][i % NT][lane * 8]); };
 #pragma unroll
@@ -482,6 +494,10 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) mfma_settle(aR1[nt], aX0[nt], aR0[nt]);
+                    if (ri == 0) pin(ackv);                              // the compare stays HERE: at the load it would expose an L2 round trip per step
+                    if (ri == 0 && !__all(ackv >= (unsigned)s)) {   // (rare: the counters were read ~2 000 cycles after they were written)
+                        if (!wait_group<4 * P>(gacks, (unsigned)s, lane) && lane == 0) { s_abort = 1; report_timeout(a.status, ST2_BWD_TIMEOUT); }
+                    }
                     if (ri == RT - 1) stp.mark(4);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
@@ -512,13 +528,13 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             const int rb = b0 + 32 * nt + col;
             if (do1) {
                 bf16_t *d = a.da1 + seq_row(t1, rb, T) * G + 4 * u0;
-                *reinterpret_cast<u32x4 *>(d) = u32x4{dw1[nt][0], dw1[nt][1], dw1[nt][2], dw1[nt][3]};
-                *reinterpret_cast<u32x4 *>(d + 8) = u32x4{dw1[nt][4], dw1[nt][5], dw1[nt][6], dw1[nt][7]};
+                st_stream<u32x4>(d, u32x4{dw1[nt][0], dw1[nt][1], dw1[nt][2], dw1[nt][3]});
+                st_stream<u32x4>(d + 8, u32x4{dw1[nt][4], dw1[nt][5], dw1[nt][6], dw1[nt][7]});
             }
             if (do0) {
                 bf16_t *d = a.da0 + seq_row(t0, rb, T) * G + 4 * u0;
-                *reinterpret_cast<u32x4 *>(d) = u32x4{dw0[nt][0], dw0[nt][1], dw0[nt][2], dw0[nt][3]};
-                *reinterpret_cast<u32x4 *>(d + 8) = u32x4{dw0[nt][4], dw0[nt][5], dw0[nt][6], dw0[nt][7]};
+                st_stream<u32x4>(d, u32x4{dw0[nt][0], dw0[nt][1], dw0[nt][2], dw0[nt][3]});
+                st_stream<u32x4>(d + 8, u32x4{dw0[nt][4], dw0[nt][5], dw0[nt][6], dw0[nt][7]});
             }
         }
     }

@@ -47,7 +47,7 @@ __device__ __forceinline__ void report_timeout(int *status, const int code) {
     atomicExch(status, code);
     atomicOr(status - NSD_SEQ_HEADER_WORDS, code);
 }
-constexpr int GROUP_WORDS = 128;                   // flag words per group: [0,64) one per wave of every member, [64,80) XCC ids
+constexpr int GROUP_WORDS = NSD_SEQ_GROUP_WORDS, ACK_WORD = NSD_SEQ_ACK_WORD;                   // flag words per group: [0,64) one per wave of every member, [64,80) XCC ids
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // group geometry shared by both scans
@@ -230,6 +230,7 @@ __device__ __forceinline__ void cell_factors(const u32x4 gq0, const u32x4 gq1, c
 // poll, the optimizer sinks the whole computation (tanh, the products, the dropout stream) into that block -- onto the critical
 // path (1 100 of the fused backward's 11 100 cycles).  An empty asm statement that "modifies" a value pins it where it is.
 __device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(unsigned &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(CellFac &f) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { pin(f.A[j]); pin(f.Fi[j]); pin(f.Ff[j]); pin(f.Fg[j]); pin(f.Fo[j]); pin(f.fg[j]); }

@@ -29,6 +29,10 @@ __host__ __device__ __forceinline__ long seq_row(const int t, const int b, const
 // The workspace starts with a persistent header of NSD_SEQ_HEADER_BYTES (word 0: STICKY status = OR of every time-out code since
 // nsd_seq_workspace_init; never cleared by a forward call), followed by the status words of the evaluation in flight (cleared by
 // every forward call): [0] status, [2] / [3] scan groups on one XCD / spread, [4..] diagnostic stamps.
+// flag words per scan group: [0,64) one publish counter per wave of every member, [64,80) XCC ids of the members (rendezvous),
+// [128,192) one consume counter ("ack") per wave of every member -- the backward partial-sum ring has ONE slot (nsd_scan2.hip)
+#define NSD_SEQ_GROUP_WORDS 256
+#define NSD_SEQ_ACK_WORD 128
 #define NSD_SEQ_HEADER_BYTES 256
 #define NSD_SEQ_HEADER_WORDS (NSD_SEQ_HEADER_BYTES / 4)
 

@@ -73,7 +73,7 @@ SeqWs make_ws(const SeqDims &s) {
     auto take = [&](int64_t bytes) { const int64_t at = p; p = align_up(p + bytes, 256); return at; };
     (void)take(NSD_SEQ_HEADER_BYTES);                            // persistent header: sticky status (nsd_seq_workspace_init zeroes it)
     w.status = take(NSD_SEQ_STATUS_WORDS * 4);                   // == NSD_SEQ_HEADER_BYTES: nsd_seq_status / nsd_seq_guard rely on it
-    w.flags_bytes = 2LL * s.L * s.D * s.groups * 128 * 4;        // forward + backward flag sets of every layer (one word per wave)
+    w.flags_bytes = 2LL * s.L * s.D * s.groups * NSD_SEQ_GROUP_WORDS * 4;        // forward + backward flag sets of every layer (one word per wave)
     w.flags = take(w.flags_bytes);
     w.xbf = take(R * s.CP * 2);
     for (int l = 0; l < s.L; ++l) {
@@ -106,10 +106,10 @@ SeqWs make_ws(const SeqDims &s) {
     w.hb_stride = align_up(nsd_head_tm_row_floats((int)DH, s.F, s.K), 4);
     w.hb = take((int64_t)s.Bp * w.hb_stride * 4);
     w.dbp = take((int64_t)(s.D > 2 ? s.D : 2) * s.groups * G * 4);
-    {   // exchange rings of the scans, sized for the widest user: da tiles (single-layer backward) or the partial-sum blocks of the
-        // fused backward (nsd_scan2.hip, PartRing: P * P * NT * 4 blocks of 1.5 KB per group and step parity)
+    {   // exchange rings of the scans, sized for the widest user: h tiles of the forward scans (two slots, step parity) or the
+        // partial-sum blocks of the fused backward (nsd_scan2.hip, PartRing: P * P * NT * 4 blocks of 1.5 KB per group, ONE slot)
         const int64_t tiles = 2LL * s.groups * 3 * s.MG * (s.D * 4LL * H) * 2, Pm = H / 32;
-        const int64_t parts = 2LL * s.groups * s.D * Pm * Pm * (s.MG / 32) * 4 * 1536;
+        const int64_t parts = 1LL * s.groups * s.D * Pm * Pm * (s.MG / 32) * 4 * 1536;
         w.xch = take(tiles > parts ? tiles : parts);
     }
     w.parts = take(PARTS_FLOATS * 4);                            // split-K partials of the weight-gradient GEMMs
@@ -218,7 +218,7 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
                 a.cs0 = at<bf16_t>(c.ws, c.w.cs[0][0]); a.ga0 = at<bf16_t>(c.ws, c.w.ga[0][0]);
                 a.cs1 = at<bf16_t>(c.ws, c.w.cs[1][0]); a.ga1 = at<bf16_t>(c.ws, c.w.ga[1][0]);
             }
-            a.flags = at<unsigned>(c.ws, c.w.flags) + (long)g0 * 128;
+            a.flags = at<unsigned>(c.ws, c.w.flags) + (long)g0 * NSD_SEQ_GROUP_WORDS;
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.groups = s.groups - g0 < c.cap ? s.groups - g0 : c.cap; a.group0 = g0;
             a.rng = rng; a.rng.on = lstm_drop ? 1 : 0;
@@ -261,7 +261,7 @@ int forward(Ctx &c, const float *x, const RngArgs &rng, bool train) {
             a.xbf = at<bf16_t>(c.ws, c.w.xbf); a.CP = s.CP;
             a.lk = writes_lk(s, l, lstm_drop) ? at<bf16_t>(c.ws, c.w.lk[l]) : nullptr;
             a.res = (s.residual && l >= 1) ? in : nullptr;
-            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)l * s.D * s.groups + (long)g0 * s.D) * 128;   // disjoint per chunk
+            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)l * s.D * s.groups + (long)g0 * s.D) * NSD_SEQ_GROUP_WORDS;   // disjoint per chunk
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
             a.rng = rng;
@@ -342,7 +342,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             a.xch = at<bf16_t>(c.ws, c.w.xch);
             a.alpha = at<float>(c.ws, c.w.alpha); a.dscore = at<float>(c.ws, c.w.dscore); a.dpooled = at<float>(c.ws, c.w.dpooled);
             a.attn_w = c.params + c.pl.attn_w;
-            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)s.L * s.D * s.groups + (long)g0) * 128;
+            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)s.L * s.D * s.groups + (long)g0) * NSD_SEQ_GROUP_WORDS;
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.groups = s.groups - g0 < c.cap ? s.groups - g0 : c.cap; a.group0 = g0; a.groups_total = s.groups;
             a.rng = rng; a.rng.on = lstm_drop ? 1 : 0;
@@ -369,7 +369,7 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             a.dres = (s.residual && l >= 1) ? at<float>(c.ws, c.w.din[1]) : nullptr;
             a.alpha = at<float>(c.ws, c.w.alpha); a.dscore = at<float>(c.ws, c.w.dscore); a.dpooled = at<float>(c.ws, c.w.dpooled);
             a.attn_w = c.params + c.pl.attn_w;
-            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)(s.L + l) * s.D * s.groups + (long)g0 * s.D) * 128;
+            a.flags = at<unsigned>(c.ws, c.w.flags) + ((long)(s.L + l) * s.D * s.groups + (long)g0 * s.D) * NSD_SEQ_GROUP_WORDS;
             a.dbp = at<float>(c.ws, c.w.dbp); a.groups_total = s.groups; a.xch = at<bf16_t>(c.ws, c.w.xch);
             a.status = at<int>(c.ws, c.w.status);
             a.B = s.B; a.Bp = s.Bp; a.T = s.T; a.D = s.D; a.ld = DH; a.groups = ng; a.group0 = g0; a.layer = l;
