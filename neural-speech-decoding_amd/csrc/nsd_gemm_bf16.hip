@@ -157,6 +157,45 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
         }
 }
 
+
+// epilogue of the 256 x 256 kernels: the wave's 4 x 2 accumulator tiles starting at (mb0, nb0)
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&acc)[4][2], const int mb0, const int nb0, const int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int mb = mb0 + 32 * i, nb = nb0 + 32 * j;
+            const int n = nb + (lane & 31);
+            if (EPI == GEMM_EPI_TILE_BF16) {
+                if (mb + 32 <= g.M && nb + 32 <= g.N) {
+                    unsigned w[8];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float b0 = g.bias ? g.bias[mb + mfma32_row(r, lane)] : 0.f;
+                        const float b1 = g.bias ? g.bias[mb + mfma32_row(r + 1, lane)] : 0.f;
+                        w[r >> 1] = pack_bf16x2(acc[i][j][r] + b0, acc[i][j][r + 1] + b1);
+                    }
+                    bf16_t *dst = reinterpret_cast<bf16_t *>(g.C) + (((long)(nb >> 5) * (g.M >> 5) + (mb >> 5)) * 64 + lane) * 16;
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{w[0], w[1], w[2], w[3]};
+                    *reinterpret_cast<u32x4 *>(dst + 8) = u32x4{w[4], w[5], w[6], w[7]};
+                }
+            } else {
+                if (n >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + mfma32_row(r, lane);
+                    if (m >= g.M) continue;
+                    if (EPI == GEMM_EPI_F32)
+                        (reinterpret_cast<float *>(g.C) + (long)blockIdx.z * g.M * g.ldc)[(long)m * g.ldc + n] =
+                            acc[i][j][r] + (g.add ? g.add[(long)m * g.ldc + n] : 0.f);
+                    else
+                        reinterpret_cast<bf16_t *>(g.C)[(long)m * g.ldc + n] = (bf16_t)acc[i][j][r];
+                }
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // 256 x 256 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA tiles), LDS double-buffered, ONE barrier per K chunk.
 // Why a second kernel: the 128 x 128 tile moves 32 KB from the L2 per 128 x 128 x 64 MACs = 64 FLOP per byte, and a CU takes
@@ -359,6 +398,214 @@ int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
 }
 }  // namespace big
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile for TWO K-CONTIGUOUS operands (input projection, input gradient: the two largest GEMMs of cfg5), staged by LDS-DMA.
+// What the counters said about the register-staged kernel above on these shapes (37 % MFMA busy, 39 % of the wave cycles in
+// s_waitcnt / barrier): a chunk's global loads are requested at the top of the chunk BEFORE it and written to the LDS a quarter
+// of a chunk later -- ~500 cycles of flight time against an L2 round trip of 500-800 -- and the staging registers leave no room
+// for a second set.  Here the next chunk's bytes go global -> LDS directly (buffer_load_dwordx4 ... lds: no staging registers,
+// no ds_write pass), requested right after the barrier that frees their buffer, i.e. a whole chunk (~2 000 cycles) ahead.
+//   LDS image of an operand chunk: [256 rows][64 k] bf16, 128-byte rows, UNPADDED (a wave's DMA instruction fills 64 lanes x 16 B =
+//   8 whole rows, lane-linear); the 16-byte piece c of row r sits at piece c ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128
+//   group (16 consecutive rows, one k piece) then cover all 16 slots of the 256-byte bank row -- conflict-free.  The permutation
+//   is applied on the SOURCE address of each lane (the destination of an LDS-DMA is fixed) and on the fragment reads.
+//   Rows beyond M / N and k beyond the split's range are sent out of the buffer descriptor's range: the DMA writes zeros.
+// ---------------------------------------------------------------------------------------------------------------------------
+// timing experiments only (-DNSD_GEMM_ABL=n, never shipped; results wrong): 1 no DMA inside the loop, 2 no MFMAs, 4 no fragment reads
+#ifndef NSD_GEMM_ABL
+#define NSD_GEMM_ABL 0
+#endif
+#if NSD_GEMM_ABL & 8
+__device__ unsigned long long g_gemm_stamps[8];
+extern "C" int nsd_debug_gemm_stamps(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps)) == hipSuccess ? 0 : -2; }
+#define GSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+namespace dma {
+constexpr int TM = 256, TN = 256, NTH = 512, ROWB = GK * 2;     // bytes per LDS row
+constexpr int OPB = TM * ROWB;                                   // bytes of one operand image (32 KB)
+constexpr unsigned OOB = 0x7fffff00u;                            // a byte offset beyond num_records of the descriptors below
+
+// SA / SB: LDS images (pipeline stages) of operand A / B.  Two stages = the next chunk is requested a chunk ahead: enough for an
+// operand that sits in the L2 (the weights: 4-8 MB, shared by every workgroup of the XCD).  The OTHER operand of these GEMMs is a
+// 1-4-GB activation matrix streamed from HBM exactly once, and every workgroup of an XCD that shares a chunk of it asks for it at
+// the same moment: one chunk (~2 000 cycles) of flight time against an HBM latency of ~4 500 under load left every chunk waiting.
+// It gets THREE stages -- requested two chunks ahead, its DMA stays in flight across the chunk barrier (counted vmcnt, raw
+// s_barrier) -- and the LDS is full: (2 + 3) x 32 KB = 160 KB.
+template <int EPI, int SA, int SB>
+__global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmArgs g) {
+    extern __shared__ __align__(16) unsigned char smem[];       // [SA A images | SB B images], the ONLY LDS object of the kernel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;                    // wave tile: rows 128 wm .., columns 64 wn ..
+    // XCD-aware tile order: as gemm_bf16_big_kernel
+    const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nt = tiles_m * tiles_n, tpx = (nt + 7) / 8;
+    const bool remap = gridDim.x == (unsigned)(8 * tpx) && nt >= 16;
+    const int q = remap ? (int)(blockIdx.x & 7) * tpx + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (q >= nt) return;
+    const int GH = tiles_m < 8 ? tiles_m : 8, per_group = GH * tiles_n, grp = q / per_group, rr = q - grp * per_group;
+    const int gh = (grp + 1) * GH <= tiles_m ? GH : tiles_m - grp * GH;
+    const int tile_m = grp * GH + rr % gh, tile_n = rr / gh;
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+    const long nchunks = (g.K + GK - 1) / GK;
+    const long per = (nchunks + g.splits - 1) / g.splits;
+    const long c_lo = (long)blockIdx.z * per, c_hi = (c_lo + per < nchunks) ? c_lo + per : nchunks;
+    const long k_lo = c_lo * GK, k_hi = (c_hi * GK < g.K) ? c_hi * GK : g.K;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+
+    // descriptors based at the tile's first row: lane offsets stay far below 2^31 (checked at launch)
+    const nsd_rsrc ra = make_rsrc(g.A + (long)m0 * g.lda, 0x7ffffe00u), rb = make_rsrc(g.B + (long)n0 * g.ldb, 0x7ffffe00u);
+    // this lane's piece of instruction i: row 64 i + 8 wave + (lane >> 3), LDS piece lane & 7 = source piece (lane & 7) ^ ((row >> 1) & 7)
+    unsigned va[4], vb[4];
+    int kpiece;                                                 // source k piece of this lane (the same for all 4 rows: 64 i + 8 wave keeps (row >> 1) & 7)
+    {
+        const int rl = lane >> 3, sw = (((8 * wave + rl) >> 1) & 7);
+        kpiece = (lane & 7) ^ sw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 64 * i + 8 * wave + rl;
+            va[i] = m0 + r < g.M ? (unsigned)(r * g.lda * 2 + kpiece * 16) : OOB;
+            vb[i] = n0 + r < g.N ? (unsigned)(r * g.ldb * 2 + kpiece * 16) : OOB;
+        }
+    }
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    unsigned char *const Abase = smem, *const Bbase = smem + (size_t)SA * OPB;
+    const long ntile = k_lo < k_hi ? (k_hi - k_lo + GK - 1) / GK : 0;
+    // request chunk t of one operand into its image t % S (nothing is issued beyond the split's range: the counted waits below
+    // assume exactly 4 DMA instructions per operand and chunk, so a chunk that does not exist is "requested" out of range: zeros)
+    // DMA instruction i (0..3) of chunk t of an operand: rows 64 i + 8 wave .. of the image t % S
+    auto dma_a = [&](const long t, const int i) {
+        unsigned char *dst = Abase + (size_t)(t % SA) * OPB + (size_t)wave * 8 * ROWB;
+        const long k0 = k_lo + t * GK;
+        const bool kok = t < ntile && k0 + 8 * kpiece < k_hi;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + i * 64 * ROWB), 16, kok ? va[i] : OOB, t < ntile ? (int)(k0 * 2) : 0, 0, 0);
+    };
+    auto dma_b = [&](const long t, const int i) {
+        unsigned char *dst = Bbase + (size_t)(t % SB) * OPB + (size_t)wave * 8 * ROWB;
+        const long k0 = k_lo + t * GK;
+        const bool kok = t < ntile && k0 + 8 * kpiece < k_hi;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(dst + i * 64 * ROWB), 16, kok ? vb[i] : OOB, t < ntile ? (int)(k0 * 2) : 0, 0, 0);
+    };
+    auto stage_a = [&](const long t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_a(t, i);
+    };
+    auto stage_b = [&](const long t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_b(t, i);
+    };
+    // fragment addresses: row base + (lane & 31), k piece (2 ks + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)   (row bases are multiples of 32)
+    const int fsw = ((lane & 31) >> 1) & 7, fkq = lane >> 5;
+    int koff[GK / 16];
+#pragma unroll
+    for (int ks = 0; ks < GK / 16; ++ks) koff[ks] = (lane & 31) * ROWB + 16 * ((2 * ks + fkq) ^ fsw);
+
+    if (ntile > 0) {
+        // prologue: chunk 0 of both, then what each operand keeps in flight ahead (S - 1 chunks)
+        stage_a(0); stage_b(0);
+        if (SA == 3) stage_a(1);
+        if (SB == 3) stage_b(1);
+        // issue order inside chunk t of the loop: [2-stage operand: chunk t+1] [3-stage operand: chunk t+2]; what must have landed
+        // at the end of chunk t is chunk t+1 of both: everything but the 4 youngest instructions where a 3-stage operand exists
+        if (SA == 3 || SB == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#if NSD_GEMM_ABL & 8
+        unsigned long long st_acc[4] = {0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
+        for (long t = 0; t < ntile; ++t) {
+            // (the barrier before this point ended every wave's reads of chunk t-1: its images are free)
+            GSTAMP(0);
+            const unsigned char *As = Abase + (size_t)(t % SA) * OPB + (size_t)(128 * wm) * ROWB, *Bs = Bbase + (size_t)(t % SB) * OPB + (size_t)(64 * wn) * ROWB;
+            bf16x8 fa[2][4], fb[2][2];
+            auto frags = [&](const int ks, bf16x8 (&a)[4], bf16x8 (&b)[2]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(As + i * 32 * ROWB + koff[ks]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(Bs + j * 32 * ROWB + koff[ks]);
+            };
+            // The chunk's 8 DMA instructions are spread over its 32 MFMAs, one behind every fourth: issued in one burst at the top
+            // of the chunk they took a quarter of the chunk's time (the CU's vector-memory path moves 64 B per clock: 64 KB per
+            // chunk) during which both waves of every SIMD stood in the issue queue and no MFMA ran.  Order: first the operand with
+            // two stages (its chunk t+1 must land by the end of THIS chunk), then the one with three (chunk t+2: a chunk of slack).
+            auto dma_step = [&](const int n) {                   // n = 0..7
+                if (NSD_GEMM_ABL & 1) return;
+                constexpr bool A_FIRST = SA == 2;
+                const bool first_half = n < 4;
+                const int i = n & 3;
+                if (first_half == A_FIRST) dma_a(t + (SA - 1), i); else dma_b(t + (SB - 1), i);
+            };
+            if (!(NSD_GEMM_ABL & 4) || t == 0) frags(0, fa[0], fb[0]);
+#pragma unroll
+            for (int ks = 0; ks < GK / 16; ++ks) {
+                if (ks + 1 < GK / 16 && (!(NSD_GEMM_ABL & 4) || t == 0)) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (!(NSD_GEMM_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                        else acc[i][j][0] += (float)fa[ks & 1][i][0] * (float)fb[ks & 1][j][0];
+                    if (i & 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma_step(2 * ks + (i >> 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            GSTAMP(1);                                          // fragment reads + MFMAs
+            if (SA == 3 || SB == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GSTAMP(2);                                          // wait for the DMA
+            __builtin_amdgcn_s_barrier();
+            GSTAMP(3);                                          // barrier
+        }
+#if NSD_GEMM_ABL & 8
+        if (blockIdx.x == 8 && blockIdx.z == 0 && tid == 0) { for (int i = 0; i < 4; ++i) g_gemm_stamps[i] = st_acc[i]; g_gemm_stamps[4] = (unsigned long long)ntile; }
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (out-of-range requests of the last chunks: nothing may be in flight when the LDS is released)
+    }
+    gemm_epilogue<EPI>(g, acc, m0 + 128 * wm, n0 + 64 * wn, lane);
+}
+
+template <int EPI, int SA, int SB>
+int launch_one(const GemmArgs &g, const dim3 grid, hipStream_t st) {
+    static bool once = false;                                   // up to 160 KB of dynamic LDS needs the opt-in (per kernel, once per process)
+    auto *kp = &gemm_bf16_dma_kernel<EPI, SA, SB>;
+    constexpr int LDS = (SA + SB) * OPB;
+    if (!once) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            nsd_set_error("gemm_bf16: cannot reserve %d bytes of LDS", LDS);
+            return NSD_E_INVALID;
+        }
+        once = true;
+    }
+    hipLaunchKernelGGL(kp, grid, dim3(NTH), LDS, st, g);
+    NSD_CHECK_LAUNCH("gemm_bf16_dma_kernel");
+    return NSD_OK;
+}
+template <int SA, int SB>
+int launch_stages(const GemmArgs &g, const dim3 grid, hipStream_t st) {
+    switch (g.epi) {
+    case GEMM_EPI_F32: return launch_one<GEMM_EPI_F32, SA, SB>(g, grid, st);
+    case GEMM_EPI_BF16: return launch_one<GEMM_EPI_BF16, SA, SB>(g, grid, st);
+    case GEMM_EPI_TILE_BF16: return launch_one<GEMM_EPI_TILE_BF16, SA, SB>(g, grid, st);
+    default: nsd_set_error("gemm_bf16: unknown epilogue %d", g.epi); return NSD_E_INVALID;
+    }
+}
+int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
+    // the operand with (many) more rows is the one streamed from HBM: it gets the third stage
+    static const int force = [] { const char *e = getenv("NSD_GEMM_DMA_STAGES"); return e ? atoi(e) : 0; }();   // test hook: 22 / 23 / 32
+    const int mode = force ? force : (g.M >= 4 * g.N ? 32 : (g.N >= 4 * g.M ? 23 : 22));
+    if (mode == 32) return launch_stages<3, 2>(g, grid, st);
+    if (mode == 23) return launch_stages<2, 3>(g, grid, st);
+    return launch_stages<2, 2>(g, grid, st);
+}
+}  // namespace dma
+
 template <bool AK, bool BK>
 int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
     switch (g.epi) {
@@ -374,6 +621,8 @@ int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
 }  // namespace
 
 // test hook: NSD_GEMM_SMALL_TILES=1 forces the 128 x 128 kernel (both kernels must give the same numbers)
+// test hook: NSD_GEMM_REG_STAGING=1 keeps the register-staged 256 x 256 kernel for two k-contiguous operands (A/B runs, parity)
+static bool getenv_reg_staging() { static const bool v = [] { const char *e = getenv("NSD_GEMM_REG_STAGING"); return e && e[0] == '1'; }(); return v; }
 static bool getenv_small_tiles() { static const bool v = [] { const char *e = getenv("NSD_GEMM_SMALL_TILES"); return e && e[0] == '1'; }(); return v; }
 
 int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
@@ -397,7 +646,10 @@ int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
         const int tiles = ((g.N + big::TN - 1) / big::TN) * ((g.M + big::TM - 1) / big::TM);
         const dim3 bgrid(tiles >= 16 ? 8 * ((tiles + 7) / 8) : tiles, 1, splits);   // 1-D; >= 16 tiles: padded to a multiple of 8, ids mapped XCD-aware
         if (g.a_kmajor) return g.b_kmajor ? big::launch_epi<true, true>(a, bgrid, st) : big::launch_epi<true, false>(a, bgrid, st);
-        return g.b_kmajor ? big::launch_epi<false, true>(a, bgrid, st) : big::launch_epi<false, false>(a, bgrid, st);
+        if (g.b_kmajor) return big::launch_epi<false, true>(a, bgrid, st);
+        // both operands k-contiguous: the LDS-DMA kernel (lane offsets inside a tile's 256 rows must stay below the descriptor range)
+        if (!getenv_reg_staging() && 256L * 2 * (g.lda > g.ldb ? g.lda : g.ldb) + 2 * g.K < 0x7f000000L) return dma::launch_epi(a, bgrid, st);
+        return big::launch_epi<false, false>(a, bgrid, st);
     }
     const dim3 grid((g.N + GN - 1) / GN, (g.M + GM - 1) / GM, splits);
     if (g.a_kmajor) return g.b_kmajor ? launch_epi<true, true>(a, grid, st) : launch_epi<true, false>(a, grid, st);
