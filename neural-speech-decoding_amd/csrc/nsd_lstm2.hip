@@ -13,6 +13,7 @@
 //     reduction, and lane s of the quad evaluates gate s.  No LDS round trip inside a step.
 //   * the two layers run skewed by one step in different waves (layer 1 handles t-1 while layer 0
 //     handles t), so there is exactly ONE workgroup barrier per time step.
+#include <stdlib.h>
 #include "nsd_args.h"
 
 
@@ -536,8 +537,14 @@ int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st) {
     if (grid <= 0) return NSD_OK;
     switch (H) {
     case 32: launch_fwd_h<32>(a, nb, grid, st); break;
-    case 48: {   // role-split kernel (nsd_lstm2_fwd48.hip): one trial per workgroup, one workgroup per CU, batches loop
+    case 48: {   // role-split kernel (nsd_lstm2_fwd48.hip), one workgroup per CU, batches loop.  One trial per workgroup while that leaves
+                 // CUs idle or barely covers them (latency is all that counts), two trials per workgroup in lock step once every CU
+                 // has at least two trials to work on (training only: the inference tail is built for one)
         const int cus = nsd_num_cus();
+        const char *env_nb = getenv("NSD_FWD48_NB");            // test hook (read per launch): 1 / 2 forces the instantiation
+        const int force_nb = env_nb ? atoi(env_nb) : 0;
+        const bool two = force_nb ? force_nb == 2 : a.B >= 2 * cus;
+        if (two && !a.logits_out) { const int ngrp2 = (a.B + 1) / 2; return nsd_lstm2_fwd48_launch(a, 2, ngrp2 < cus ? ngrp2 : cus, st); }
         return nsd_lstm2_fwd48_launch(a, 1, a.B < cus ? a.B : cus, st);
     }
     case 64: launch_fwd_h<64>(a, nb, grid, st); break;

@@ -64,7 +64,7 @@ struct FSmem {
     float pk[NB][8];             // inference tail: softmax numerators of the chunk being pooled
     float vec[NB][64];           // inference tail: LayerNorm output / activated fc.0 output
     // fused train head (head_train): raw attention scores of the trial, staged head weights, small vectors
-    float sc[TT_TMAX];
+    float sc[NB][TT_TMAX];
     float w0[64 * TT_W0S];       // fc.0 weight rows, stride 49 (odd: lane f reads row f without bank conflicts)
     float w3[TT_KMAX * 64];
     float vln[64], vx[64], vz[64], vdz[64], vdl[64], dp[64];
@@ -76,7 +76,9 @@ struct FSmem {
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <int NB>
-__device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b);
+__device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b, const int n);
+template <int NB>
+__device__ __forceinline__ void tail_all(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b0);
 
 // 12 operands of a k-slice from LDS as 6 pairs
 __device__ __forceinline__ void load_slice(const float *p, f32x2 (&v)[6]) {
@@ -129,6 +131,20 @@ __device__ __forceinline__ CellOut cell_step(const float arg, float &cK, const i
     out.c = cK * INV_KC;
     out.gate = s == 2 ? act * INV_KC : act;
     return out;
+}
+
+// x and the explicit dropout multipliers of a 32-step chunk, element e of the chunk image (trial-major): zero / one padding
+template <int NB>
+__device__ __forceinline__ float chunk_x_at(const Lstm2FwdArgs &a, const int b0, const int e, const int t0) {
+    const int n = e / (XCH * 8), tl = (e >> 3) & (XCH - 1), ch = e & 7;
+    const int b = b0 + n, t = t0 + tl;
+    return (e < NB * XCH * 8 && b < a.B && t < a.T && ch < a.C) ? a.x[((size_t)b * a.T + t) * a.C + ch] : 0.f;
+}
+__device__ __forceinline__ float4 chunk_mask_at(const Lstm2FwdArgs &a, const int b0, const int e, const int t0) {      // e: float4 index in [0, NB*384)
+    const int n = e / 384, rem = e - n * 384, tl = rem / 12, q = rem - tl * 12;
+    const int b = b0 + n, t = t0 + tl;
+    if (a.mask && b < a.B && t < a.T) return *reinterpret_cast<const float4 *>(a.mask + ((size_t)b * a.T + t) * H + 4 * q);
+    return make_float4(1.f, 1.f, 1.f, 1.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -193,11 +209,8 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
         step_barrier<false>(prof);
 
         for (int m0 = 0; m0 < n_steps; m0 += XCH) {
-            float xr[XPT]; float4 mr[MPT];
-#pragma unroll
-            for (int q = 0; q < XPT; ++q) xr[q] = x_at(r + 192 * q, m0 + XCH);
-#pragma unroll
-            for (int q = 0; q < MPT; ++q) mr[q] = a.rng.on ? make_float4(1.f, 1.f, 1.f, 1.f) : mask_at(r + 192 * q, m0 + XCH);
+            // (the NEXT chunk of x and of the explicit multipliers is fetched and written to the other LDS half by the spare wave: 19
+            // registers held across the chunk by these chain waves were what pushed the two-trial instantiation into scratch)
             const int cb = (m0 / XCH) & 1;
             for (int kh = 0; kh < XCH; kh += SRING) {
 #pragma unroll
@@ -226,20 +239,12 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
                         sr[4 * j + s] = o.gate;
                     }
                 }
-                if (k == XCH - 1) {
-#pragma unroll
-                    for (int q = 0; q < XPT; ++q) { const int e = r + 192 * q; if (e < XE) (&sm.xs[cb ^ 1][0][0][0])[e] = xr[q]; }
-                    if (!a.rng.on) {
-#pragma unroll
-                        for (int q = 0; q < MPT; ++q) *reinterpret_cast<float4 *>(&sm.ms[cb ^ 1][0][0][0] + 4 * (r + 192 * q)) = mr[q];
-                    }
-                }
                 step_barrier<false>(prof);
               }
             }
         }
-        step_barrier<false>(prof);      // the saver wave has drained the save ring of this trial group
-        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, b0);
+        if (a.head_train) tail_all<NB>(a, sm, threadIdx.x, b0);   // (its first barrier: the save ring of this trial group is drained)
+        else step_barrier<false>(prof);      // save ring drained
     }
     prof_store(a.dbg, prof);
 }
@@ -285,8 +290,8 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, con
             step_barrier<false, P_SLEEP>(prof);
           }
         }
-        step_barrier<false>(prof);      // save ring drained
-        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, grp * NB);
+        if (a.head_train) tail_all<NB>(a, sm, threadIdx.x, grp * NB);   // (its first barrier: the save ring of this trial group is drained)
+        else step_barrier<false>(prof);      // save ring drained
     }
     prof_store(a.dbg, prof);
 }
@@ -357,8 +362,8 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
             step_barrier<false>(prof);
           }
         }
-        step_barrier<false>(prof);      // save ring drained
-        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, grp * NB);
+        if (a.head_train) tail_all<NB>(a, sm, threadIdx.x, grp * NB);   // (its first barrier: the save ring of this trial group is drained)
+        else step_barrier<false>(prof);      // save ring drained
     }
     prof_store(a.dbg, prof);
 }
@@ -368,30 +373,34 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, co
 // ------------------------------------------------------------------------------------------------
 constexpr int SPIECES = 2 * SCH * SREC4 / 64;     // 24 wave-wide pieces (1 KB) per trial and chunk
 
+// One 16-byte piece of the chunk image per lane and q: where it lies in the ring and where it goes.  Two registers per piece (24
+// pieces): the destination as a 32-bit float offset from the workspace's hseq region (all saved arrays live in ONE workspace buffer,
+// a few hundred MB), and {ring offset, time index in chunk 0, row length} packed -- five registers per piece (a 64-bit pointer and
+// three ints) left no room for two trials' worth of pieces in flight.
 struct SvDesc {
-    char *base;          // destination of (trial 0, t = 0) for this lane's 16 bytes; null = not saved
-    int row_bytes;       // bytes per time step in the destination array
-    int t0;              // time index of this lane's record in chunk 0
-    int lds_off;         // float offset inside sv[0][0] (ring slot 0, trial 0)
+    int dst;             // float offset of (trial 0, t = 0) for this lane's 16 bytes, relative to sv_base; < 0: not saved
+    unsigned meta;       // bits 0..15 float offset inside sv[0][0] (ring slot 0, trial 0) | bits 16..23 (t0 + 2) | bit 24 row = 4H floats (else H)
 };
 
 template <int NB>
 __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int lane, const int n_steps) {
     const int T = a.T;
     SvDesc d[SPIECES];
+    float *const sv_base = a.hseq0;                            // (training launches always carry the whole workspace)
 #pragma unroll
     for (int q = 0; q < SPIECES; ++q) {
         const int e = q * 64 + lane;                       // float4 index in the chunk image [k][layer][84]
         const int k = e / (2 * SREC4), rem = e - k * (2 * SREC4);
         const int layer = rem / SREC4, w = rem - layer * SREC4;
-        d[q].t0 = k - (layer == 1 ? 2 : 0);
-        d[q].lds_off = (k * NB * 2 + layer) * SREC + 4 * w;
-        float *dst = nullptr; int rb = 0;
-        if (w < 48)      { dst = layer == 0 ? a.gact0 : a.gact1; rb = H * 16; if (dst) dst += 4 * w; }
-        else if (w < 60) { dst = layer == 0 ? a.hseq0 : a.hseq1; rb = H * 4;  if (dst) dst += 4 * (w - 48); }
-        else if (w < 72) { dst = layer == 0 ? a.cseq0 : a.cseq1; rb = H * 4;  if (dst) dst += 4 * (w - 60); }
-        else if (w < 84) { dst = layer == 0 ? a.inseq : a.top;   rb = H * 4;  if (dst) dst += 4 * (w - 72); }
-        d[q].base = (char *)dst; d[q].row_bytes = rb;
+        const int t0 = k - (layer == 1 ? 2 : 0);
+        const int lds_off = (k * NB * 2 + layer) * SREC + 4 * w;
+        float *dst = nullptr; int wide = 0;
+        if (w < 48)      { dst = layer == 0 ? a.gact0 : a.gact1; wide = 1; if (dst) dst += 4 * w; }
+        else if (w < 60) { dst = layer == 0 ? a.hseq0 : a.hseq1; if (dst) dst += 4 * (w - 48); }
+        else if (w < 72) { dst = layer == 0 ? a.cseq0 : a.cseq1; if (dst) dst += 4 * (w - 60); }
+        else if (w < 84) { dst = layer == 0 ? a.inseq : a.top;   if (dst) dst += 4 * (w - 72); }
+        d[q].dst = (dst && sv_base) ? (int)(dst - sv_base) : -1;
+        d[q].meta = (unsigned)lds_off | ((unsigned)(t0 + 2) << 16) | ((unsigned)wide << 24);
     }
     Prof prof = prof_init(a.dbg);
     // The LDS reads of a batch of pieces are all issued before the first store: one LDS latency per call instead of one
@@ -406,21 +415,22 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int q = qb + u;
-                const int t = d[q].t0 + SCH * chunk;
-                ok[u] = d[q].base && (unsigned)t < (unsigned)T;
+                const int t = (int)((d[q].meta >> 16) & 0xffu) - 2 + SCH * chunk;
+                ok[u] = d[q].dst >= 0 && (unsigned)t < (unsigned)T;
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
-                    v[u][n] = ok[u] ? *reinterpret_cast<const float4 *>(ring + d[q].lds_off + n * 2 * SREC) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[u][n] = ok[u] ? *reinterpret_cast<const float4 *>(ring + (d[q].meta & 0xffffu) + n * 2 * SREC) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int q = qb + u;
-                const int t = d[q].t0 + SCH * chunk;
+                const int t = (int)((d[q].meta >> 16) & 0xffu) - 2 + SCH * chunk;
+                const unsigned row = (d[q].meta >> 24) & 1u ? 4u * H : (unsigned)H;
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     const int b = b0 + n;
                     if (ok[u] && b < a.B)
-                        *reinterpret_cast<float4 *>(d[q].base + (size_t)((unsigned)(b * T + t)) * (unsigned)d[q].row_bytes) = v[u][n];
+                        *reinterpret_cast<float4 *>(sv_base + d[q].dst + (size_t)((unsigned)(b * T + t)) * row) = v[u][n];
                 }
             }
         }
@@ -451,8 +461,8 @@ __device__ __forceinline__ void saver_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
         }
         flush(n_steps / SCH - 1, b0, 0, SPIECES);          // last chunk (its LDS image is complete: barrier above)
         if (a.head_train) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail reads the top rows back
-        step_barrier<false>(prof);                          // keep the ring intact until it has been read
-        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, b0);
+        if (a.head_train) tail_all<NB>(a, sm, threadIdx.x, b0);
+        else step_barrier<false>(prof);                     // keep the ring intact until it has been read
     }
     prof_store(a.dbg, prof);
 }
@@ -480,11 +490,11 @@ __device__ __forceinline__ void pool_init(PoolRun &p, const Lstm2FwdArgs &a, con
 __device__ __forceinline__ void pool_reset(PoolRun &p) { p.mrun = -INFINITY; p.den = 0.f; p.pooled = 0.f; p.skip = true; }
 
 template <int STAGE, int NB>
-__device__ __forceinline__ void pool_stage(PoolRun &p, FSmem<NB> &sm, const int chunk, const int lane, const int T, float *sc_out) {
+__device__ __forceinline__ void pool_stage(PoolRun &p, FSmem<NB> &sm, const int chunk, const int lane, const int T, float *sc_out, const int n = 0) {
     const int kq = lane >> 3, part = lane & 7;
     if (STAGE == 0) {            // scores of the chunk's 8 steps
         const int t = SCH * chunk + kq - 2;               // layer-1 time index of ring slot kq of this chunk
-        const float *rec = &sm.sv[(chunk & 1) * SCH + kq][0][1][288];
+        const float *rec = &sm.sv[(chunk & 1) * SCH + kq][n][1][288];
         float sc = 0.f;
 #pragma unroll
         for (int u = 0; u < 6; ++u) sc = fmaf(p.awp[u], rec[6 * part + u], sc);
@@ -504,39 +514,53 @@ __device__ __forceinline__ void pool_stage(PoolRun &p, FSmem<NB> &sm, const int 
         if (p.skip) return;
         const float ps = rows_combine_sum(p.pkv + row_ror<8>(p.pkv));
         p.den = fmaf(p.den, p.scale, ps);
-        if (part == 0) sm.pk[0][kq] = p.pkv;
+        if (part == 0) sm.pk[n][kq] = p.pkv;
     } else {                     // weighted sum of the 8 rows (pk was published by the barrier after stage 2)
         if (p.skip) return;
         float acc = p.pooled * p.scale;
         if (lane < H) {
 #pragma unroll
-            for (int k = 0; k < SCH; ++k) acc = fmaf(sm.pk[0][k], sm.sv[(chunk & 1) * SCH + k][0][1][288 + lane], acc);
+            for (int k = 0; k < SCH; ++k) acc = fmaf(sm.pk[n][k], sm.sv[(chunk & 1) * SCH + k][n][1][288 + lane], acc);
         }
         p.pooled = acc;
     }
 }
 
-// the time loop of a pooling wave: one stage of chunk (m0/8 - 1) per step, then the last chunk in one go
+// the time loop of a pooling wave: one stage of chunk (m0/8 - 1) per step -- trial 0 in steps 0..3 of the 8, trial 1 (two trials
+// per workgroup) in steps 4..7: the chunk's ring half is not rewritten before the next 8 steps -- then the last chunk in one go
 template <int NB>
-__device__ __forceinline__ void pool_loop(PoolRun &p, FSmem<NB> &sm, const int lane, const int T, const int n_steps, float *sc_out,
+__device__ __forceinline__ void pool_loop(PoolRun (&p)[NB], FSmem<NB> &sm, const int lane, const int T, const int n_steps, const bool keep_scores,
                                           Prof &prof) {
+    static_assert(NB <= 2, "one pooling stage per step: 4 stages x NB trials per 8-step chunk");
     for (int m0 = 0; m0 < n_steps; m0 += SCH) {
         const int done = m0 / SCH - 1;
-        if (done >= 0) pool_stage<0, NB>(p, sm, done, lane, T, sc_out);
-        step_barrier<false, S_SLEEP>(prof);
-        if (done >= 0) pool_stage<1, NB>(p, sm, done, lane, T, sc_out);
-        step_barrier<false, S_SLEEP>(prof);
-        if (done >= 0) pool_stage<2, NB>(p, sm, done, lane, T, sc_out);
-        step_barrier<false, S_SLEEP>(prof);
-        if (done >= 0) pool_stage<3, NB>(p, sm, done, lane, T, sc_out);
 #pragma unroll
-        for (int k = 3; k < SCH; ++k) step_barrier<false, S_SLEEP>(prof);
+        for (int n = 0; n < 2; ++n) {
+            if (n < NB) {
+                float *sc_out = keep_scores ? sm.sc[n < NB ? n : 0] : nullptr;
+                if (done >= 0) pool_stage<0, NB>(p[n < NB ? n : 0], sm, done, lane, T, sc_out, n);
+                step_barrier<false, S_SLEEP>(prof);
+                if (done >= 0) pool_stage<1, NB>(p[n < NB ? n : 0], sm, done, lane, T, sc_out, n);
+                step_barrier<false, S_SLEEP>(prof);
+                if (done >= 0) pool_stage<2, NB>(p[n < NB ? n : 0], sm, done, lane, T, sc_out, n);
+                step_barrier<false, S_SLEEP>(prof);
+                if (done >= 0) pool_stage<3, NB>(p[n < NB ? n : 0], sm, done, lane, T, sc_out, n);
+                step_barrier<false, S_SLEEP>(prof);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) step_barrier<false, S_SLEEP>(prof);
+            }
+        }
     }
     const int last = n_steps / SCH - 1;
-    pool_stage<0, NB>(p, sm, last, lane, T, sc_out);
-    pool_stage<1, NB>(p, sm, last, lane, T, sc_out);
-    pool_stage<2, NB>(p, sm, last, lane, T, sc_out);
-    pool_stage<3, NB>(p, sm, last, lane, T, sc_out);     // same wave: the LDS queue is in order, the reads see pk
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        float *sc_out = keep_scores ? sm.sc[n] : nullptr;
+        pool_stage<0, NB>(p[n], sm, last, lane, T, sc_out, n);
+        pool_stage<1, NB>(p[n], sm, last, lane, T, sc_out, n);
+        pool_stage<2, NB>(p[n], sm, last, lane, T, sc_out, n);
+        pool_stage<3, NB>(p[n], sm, last, lane, T, sc_out, n);     // same wave: the LDS queue is in order, the reads see pk
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -549,16 +573,16 @@ template <int NB>
 __device__ __forceinline__ void pool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int lane, const int n_steps) {
     static_assert(NB == 1, "inference tail is built for one trial per workgroup");
     const int T = a.T, K = a.K, F = a.F;
-    PoolRun pr;
-    pool_init<NB>(pr, a, lane);
+    PoolRun pr[NB];
+    pool_init<NB>(pr[0], a, lane);
     Prof prof = prof_init(a.dbg);
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b = grp;
-        pool_reset(pr);
+        pool_reset(pr[0]);
         step_barrier<false>(prof);
-        pool_loop<NB>(pr, sm, lane, T, n_steps, nullptr, prof);
-        const float pooled = pr.pooled, den = pr.den;
+        pool_loop<NB>(pr, sm, lane, T, n_steps, false, prof);
+        const float pooled = pr[0].pooled, den = pr[0].den;
         // ---- LayerNorm (biased variance, eps in the sqrt), fc.0 -> RReLU(eval) -> fc.3, softmax over classes ----
         const float p = lane < H ? pooled / den : 0.f;
         const float mu = wave_sum(p) * (1.0f / H);
@@ -618,8 +642,9 @@ __device__ __forceinline__ float tail_block_sum(float v, float *red, const int t
 // every wave of the workgroup calls this after the ring-drain barrier of trial b (the barrier also published the
 // tpool wave's LDS vectors and, with the saver's vmcnt(0), the top rows in memory)
 template <int NB>
-__device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b) {
+__device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b, const int n) {
     const int T = a.T;
+    float *sc = sm.sc[n];
     if (ablated(a.ablate, 256)) return;
     // without the residual extension the attention input IS the layer-1 output: that sequence is not saved twice
     const float *top = (a.top ? a.top : a.hseq1) + (size_t)b * T * H;
@@ -631,7 +656,7 @@ __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm,
         const int t = tid + q * NT_TRAIN;
         al[q] = 0.f; dd[q] = 0.f;
         if (t < T) {
-            al[q] = __expf(sm.sc[t] - mx) * rden;
+            al[q] = __expf(sc[t] - mx) * rden;
             const float4 *row = reinterpret_cast<const float4 *>(top + (size_t)t * H);
             float d0 = 0.f, d1 = 0.f;
 #pragma unroll 3                                               // (the role's weights stay live across the tail: keep it lean)
@@ -654,7 +679,7 @@ __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm,
             a.alpha[(size_t)b * T + t] = al[q];
             a.dscore[(size_t)b * T + t] = ds;
             *reinterpret_cast<float4 *>(a.adpack + ((size_t)b * T + t) * 4) = make_float4(al[q], ds, 0.f, 0.f);
-            sm.sc[t] = ds;                                   // the raw score is no longer needed
+            sc[t] = ds;                                      // the raw score is no longer needed
             lb += ds;
         }
     }
@@ -667,10 +692,10 @@ __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm,
         float s0 = 0.f, s1 = 0.f;
         int t = part;
         for (; t + TT_PARTS < T; t += 2 * TT_PARTS) {
-            s0 = fmaf(sm.sc[t], top[(size_t)t * H + j], s0);
-            s1 = fmaf(sm.sc[t + TT_PARTS], top[(size_t)(t + TT_PARTS) * H + j], s1);
+            s0 = fmaf(sc[t], top[(size_t)t * H + j], s0);
+            s1 = fmaf(sc[t + TT_PARTS], top[(size_t)(t + TT_PARTS) * H + j], s1);
         }
-        if (t < T) s0 = fmaf(sm.sc[t], top[(size_t)t * H + j], s0);
+        if (t < T) s0 = fmaf(sc[t], top[(size_t)t * H + j], s0);
         sm.part[part][j] = s0 + s1;
     }
     __syncthreads();
@@ -683,12 +708,25 @@ __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, FSmem<NB> &sm,
     __syncthreads();                                          // sc / part / red are reused by the next trial
 }
 
+// What every wave but the train-pooling wave does after the last step of a trial group: for each trial of the group, meet the
+// pooling wave (which has just run that trial's dense head alone and left dpooled / the softmax statistics in LDS), then take
+// part in the trial's tail.  The first of these barriers is also the "save ring drained" barrier of the group.
+template <int NB>
+__device__ __forceinline__ void tail_all(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int tid, const int b0) {
+#pragma unroll 1
+    for (int n = 0; n < NB; ++n) {
+        __syncthreads();
+        if (b0 + n < a.B) train_tail<NB>(a, sm, tid, b0 + n, n);   // (workgroup-uniform: the padding trial of an odd batch's last group has no tail)
+    }
+}
+
 template <int NB>
 __device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm, const int lane, const int n_steps) {
-    static_assert(NB == 1, "the fused head is built for one trial per workgroup");
     const int T = a.T, K = a.K, F = a.F;
-    PoolRun pr;
-    pool_init<NB>(pr, a, lane);
+    PoolRun pr[NB];
+    pool_init<NB>(pr[0], a, lane);
+#pragma unroll
+    for (int n = 1; n < NB; ++n) pr[n] = pr[0];
     // head weights: staged once per workgroup (LDS), per-lane vectors in registers
     for (int e = lane; e < F * H; e += 64) { const int f = e / H; sm.w0[f * TT_W0S + (e - f * H)] = a.fc0_w[e]; }
     for (int e = lane; e < K * F; e += 64) sm.w3[e] = a.fc3_w[e];
@@ -697,88 +735,102 @@ __device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
     Prof prof = prof_init(a.dbg);
     const int ngrp = (a.B + NB - 1) / NB;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
-        const int b = grp;
+        const int b0 = grp * NB;
         // per-trial scalars, fetched while the recurrence runs
-        float sl_f = (lane < F && a.rrelu_slope) ? a.rrelu_slope[(size_t)b * F + lane] : a.eval_slope;
-        float mk_f = (lane < F && a.drop_head) ? a.drop_head[(size_t)b * F + lane] : 1.f;
-        if (a.rng.on && lane < F) {                           // same values as nsd_train_masks streams base+1 / base+2
-            const uint64_t idx = (uint64_t)b * F + lane;
-            const float u = (float)(nsd_rand_u32(a.rng.seed, a.rng.base + 1u, idx) >> 8) * (1.0f / 16777216.0f);
-            sl_f = 0.125f + ((float)(1.0 / 3.0) - 0.125f) * u;
-            mk_f = nsd_rand_u32(a.rng.seed, a.rng.base + 2u, idx) >= a.rng.thr_head ? a.rng.keep_head : 0.f;
+        float sl_fv[NB], mk_fv[NB];
+        int labelv[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int b = b0 + n < a.B ? b0 + n : a.B - 1;      // (a padding trial of the last group: computed, never written)
+            float sl_f = (lane < F && a.rrelu_slope) ? a.rrelu_slope[(size_t)b * F + lane] : a.eval_slope;
+            float mk_f = (lane < F && a.drop_head) ? a.drop_head[(size_t)b * F + lane] : 1.f;
+            if (a.rng.on && lane < F) {                           // same values as nsd_train_masks streams base+1 / base+2
+                const uint64_t idx = (uint64_t)b * F + lane;
+                const float u = (float)(nsd_rand_u32(a.rng.seed, a.rng.base + 1u, idx) >> 8) * (1.0f / 16777216.0f);
+                sl_f = 0.125f + ((float)(1.0 / 3.0) - 0.125f) * u;
+                mk_f = nsd_rand_u32(a.rng.seed, a.rng.base + 2u, idx) >= a.rng.thr_head ? a.rng.keep_head : 0.f;
+            }
+            sl_fv[n] = sl_f; mk_fv[n] = mk_f; labelv[n] = a.labels[b];
+            pool_reset(pr[n]);
         }
-        const int label = a.labels[b];
-        pool_reset(pr);
         step_barrier<false>(prof);
-        pool_loop<NB>(pr, sm, lane, T, n_steps, sm.sc, prof);
-        const float pooled = pr.pooled, den = pr.den, mrun = pr.mrun;
-        // ---- forward of the dense head (same formulas as head_train_kernel) ----
-        const bool vb = b < a.B && !ablated(a.ablate, 512);
-        const float rden = 1.0f / den;
-        const float p = lane < H ? pooled * rden : 0.f;
-        if (lane < H && vb) a.pooled[(size_t)b * H + lane] = p;
-        const float mu = wave_sum(p) * (1.0f / H);
-        const float dlt = lane < H ? p - mu : 0.f;
-        const float rstd = 1.0f / sqrtf(wave_sum(dlt * dlt) * (1.0f / H) + 1e-5f);
-        const float xh = dlt * rstd;
-        const float ln = fmaf(xh, lnw, lnb);
-        if (lane < H) { sm.vx[lane] = xh; sm.vln[lane] = ln; }
-        float pre = 0.f, z = 0.f;                             // (same wave: LDS queue in order, no barrier needed)
-        if (lane < F) {
-            float acc = b0v;
-            const float *w = &sm.w0[lane * TT_W0S];
+        pool_loop<NB>(pr, sm, lane, T, n_steps, true, prof);
+        // ---- per trial: the dense head by this wave alone, then the workgroup's tail (the first barrier is also "ring drained") ----
+#pragma unroll 1
+        for (int n = 0; n < NB; ++n) {
+            const int b = b0 + n;
+            const float sl_f = n == 0 ? sl_fv[0] : sl_fv[NB - 1], mk_f = n == 0 ? mk_fv[0] : mk_fv[NB - 1];
+            const int label = n == 0 ? labelv[0] : labelv[NB - 1];
+            const float pooled = n == 0 ? pr[0].pooled : pr[NB - 1].pooled, den = n == 0 ? pr[0].den : pr[NB - 1].den;
+            const float mrun = n == 0 ? pr[0].mrun : pr[NB - 1].mrun;
+            // ---- forward of the dense head (same formulas as head_train_kernel) ----
+            const bool vb = b < a.B && !ablated(a.ablate, 512);
+            const float rden = 1.0f / den;
+            const float p = lane < H ? pooled * rden : 0.f;
+            if (lane < H && vb) a.pooled[(size_t)b * H + lane] = p;
+            const float mu = wave_sum(p) * (1.0f / H);
+            const float dlt = lane < H ? p - mu : 0.f;
+            const float rstd = 1.0f / sqrtf(wave_sum(dlt * dlt) * (1.0f / H) + 1e-5f);
+            const float xh = dlt * rstd;
+            const float ln = fmaf(xh, lnw, lnb);
+            if (lane < H) { sm.vx[lane] = xh; sm.vln[lane] = ln; }
+            float pre = 0.f, z = 0.f;                             // (same wave: LDS queue in order, no barrier needed)
+            if (lane < F) {
+                float acc = b0v;
+                const float *w = &sm.w0[lane * TT_W0S];
 #pragma unroll 8
-            for (int j = 0; j < H; ++j) acc = fmaf(w[j], sm.vln[j], acc);
-            pre = acc;
-            if (vb) a.fc0_pre[(size_t)b * F + lane] = acc;
-            z = (acc >= 0.f ? acc : acc * sl_f) * mk_f;
-            sm.vz[lane] = z;
+                for (int j = 0; j < H; ++j) acc = fmaf(w[j], sm.vln[j], acc);
+                pre = acc;
+                if (vb) a.fc0_pre[(size_t)b * F + lane] = acc;
+                z = (acc >= 0.f ? acc : acc * sl_f) * mk_f;
+                sm.vz[lane] = z;
+            }
+            float lg = -INFINITY;
+            if (lane < K) {
+                float acc = b3v;
+                for (int f = 0; f < F; ++f) acc = fmaf(sm.w3[lane * F + f], sm.vz[f], acc);
+                lg = acc;
+                if (vb) a.logits[(size_t)b * K + lane] = acc;
+            }
+            // ---- mean cross-entropy: dlogits = (softmax - onehot) * scale, without cancellation for the label ----
+            const float m2 = wave_max(lg);
+            const float e = lane < K ? expf(lg - m2) : 0.f;
+            const float d = wave_sum(e);
+            const float rest = wave_sum(lane == label ? 0.f : e);
+            const float dl = (lane == label ? -rest / d : e / d) * a.scale;
+            if (lane < K) sm.vdl[lane] = dl;
+            if (lane == label && vb) a.loss[b] = -((lg - m2) - logf(d));
+            // ---- backward of the dense head ----
+            float *slab = a.hslabs + (size_t)(vb ? b : 0) * a.Ph;
+            float dz = 0.f;
+            if (lane < F) {
+                for (int k = 0; k < K; ++k) dz = fmaf(sm.w3[k * F + lane], sm.vdl[k], dz);
+                dz *= mk_f;
+                dz = pre >= 0.f ? dz : dz * sl_f;
+                sm.vdz[lane] = dz;
+                if (vb) slab[a.o_fc0_b + lane] = dz;
+            }
+            if (vb) {
+                for (int e2 = lane; e2 < K * F; e2 += 64) slab[a.o_fc3_w + e2] = sm.vdl[e2 / F] * sm.vz[e2 % F];
+                if (lane < K) slab[a.o_fc3_b + lane] = dl;
+                for (int e2 = lane; e2 < F * H; e2 += 64) { const int f = e2 / H; slab[a.o_fc0_w + e2] = sm.vdz[f] * sm.vln[e2 - f * H]; }
+            }
+            float dxh = 0.f;
+            if (lane < H) {
+                float dv = 0.f;
+                for (int f = 0; f < F; ++f) dv = fmaf(sm.w0[f * TT_W0S + lane], sm.vdz[f], dv);
+                if (vb) { slab[a.o_ln_w + lane] = dv * xh; slab[a.o_ln_b + lane] = dv; }
+                dxh = dv * lnw;
+            }
+            const float m1 = wave_sum(dxh) * (1.0f / H);
+            const float m2b = wave_sum(dxh * xh) * (1.0f / H);
+            const float dpl = lane < H ? rstd * (dxh - m1 - xh * m2b) : 0.f;
+            sm.dp[lane] = dpl;
+            if (lane < H && vb) a.dpooled[(size_t)b * H + lane] = dpl;
+            if (lane == 0) { sm.md[0] = mrun; sm.md[1] = rden; }
+            __syncthreads();                                       // n == 0: ring drained; publishes dp / md / sc of trial n
+            if (b < a.B) train_tail<NB>(a, sm, threadIdx.x, b, n);
         }
-        float lg = -INFINITY;
-        if (lane < K) {
-            float acc = b3v;
-            for (int f = 0; f < F; ++f) acc = fmaf(sm.w3[lane * F + f], sm.vz[f], acc);
-            lg = acc;
-            if (vb) a.logits[(size_t)b * K + lane] = acc;
-        }
-        // ---- mean cross-entropy: dlogits = (softmax - onehot) * scale, without cancellation for the label ----
-        const float m2 = wave_max(lg);
-        const float e = lane < K ? expf(lg - m2) : 0.f;
-        const float d = wave_sum(e);
-        const float rest = wave_sum(lane == label ? 0.f : e);
-        const float dl = (lane == label ? -rest / d : e / d) * a.scale;
-        if (lane < K) sm.vdl[lane] = dl;
-        if (lane == label && vb) a.loss[b] = -((lg - m2) - logf(d));
-        // ---- backward of the dense head ----
-        float *slab = a.hslabs + (size_t)b * a.Ph;
-        float dz = 0.f;
-        if (lane < F) {
-            for (int k = 0; k < K; ++k) dz = fmaf(sm.w3[k * F + lane], sm.vdl[k], dz);
-            dz *= mk_f;
-            dz = pre >= 0.f ? dz : dz * sl_f;
-            sm.vdz[lane] = dz;
-            if (vb) slab[a.o_fc0_b + lane] = dz;
-        }
-        if (vb) {
-            for (int e2 = lane; e2 < K * F; e2 += 64) slab[a.o_fc3_w + e2] = sm.vdl[e2 / F] * sm.vz[e2 % F];
-            if (lane < K) slab[a.o_fc3_b + lane] = dl;
-            for (int e2 = lane; e2 < F * H; e2 += 64) { const int f = e2 / H; slab[a.o_fc0_w + e2] = sm.vdz[f] * sm.vln[e2 - f * H]; }
-        }
-        float dxh = 0.f;
-        if (lane < H) {
-            float dv = 0.f;
-            for (int f = 0; f < F; ++f) dv = fmaf(sm.w0[f * TT_W0S + lane], sm.vdz[f], dv);
-            if (vb) { slab[a.o_ln_w + lane] = dv * xh; slab[a.o_ln_b + lane] = dv; }
-            dxh = dv * lnw;
-        }
-        const float m1 = wave_sum(dxh) * (1.0f / H);
-        const float m2b = wave_sum(dxh * xh) * (1.0f / H);
-        const float dpl = lane < H ? rstd * (dxh - m1 - xh * m2b) : 0.f;
-        sm.dp[lane] = dpl;
-        if (lane < H && vb) a.dpooled[(size_t)b * H + lane] = dpl;
-        if (lane == 0) { sm.md[0] = mrun; sm.md[1] = rden; }
-        step_barrier<false>(prof);                             // ring drained; publishes dp / md / sc
-        train_tail<NB>(a, sm, threadIdx.x, b);
     }
     prof_store(a.dbg, prof);
 }
@@ -792,26 +844,50 @@ __device__ __forceinline__ void spare_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
     Prof prof = prof_init(a.dbg);
     const int T = a.T;
     const int ngrp = (a.B + NB - 1) / NB;
+    constexpr int XPL = NB * XCH * 8 / 64;                        // x floats per lane and chunk (4 per trial)
+    constexpr int MPL = NB * 384 / 64;                            // explicit-multiplier float4 per lane and chunk (6 per trial)
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b0 = grp * NB;
         uint64_t idx[NB];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) idx[n] = ((uint64_t)(grp * NB + n) * T + XCH) * H + lane;      // row t = XCH
+        for (int n = 0; n < NB; ++n) idx[n] = ((uint64_t)(b0 + n) * T + XCH) * H + lane;      // row t = XCH
         step_barrier<false>(prof);
-        for (int m = 0; m < n_steps; ++m) {
-            if (a.rng.on && lane < H) {
-                const int t = m + XCH;
+        for (int m0 = 0; m0 < n_steps; m0 += XCH) {
+            // the next chunk of x (and of the explicit multipliers when the streams are not drawn here): requested now, written to
+            // the other half of the staging buffers before the last barrier of this chunk
+            float xr[XPL]; float4 mr[MPL];
 #pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    float v = 1.f;
-                    if (grp * NB + n < a.B && t < T) v = nsd_rand_u32(a.rng.seed, a.rng.base, idx[n]) < a.rng.thr_lstm ? 0.f : a.rng.keep_lstm;
-                    sm.ms[((m / XCH) & 1) ^ 1][n][m & (XCH - 1)][lane] = v;
-                    idx[n] += H;
-                }
+            for (int q = 0; q < XPL; ++q) xr[q] = chunk_x_at<NB>(a, b0, lane + 64 * q, m0 + XCH);
+            if (!a.rng.on) {
+#pragma unroll
+                for (int q = 0; q < MPL; ++q) mr[q] = chunk_mask_at(a, b0, lane + 64 * q, m0 + XCH);
             }
-            step_barrier<false, S_SLEEP>(prof);
+            const int cb = (m0 / XCH) & 1;
+            for (int k = 0; k < XCH; ++k) {
+                const int m = m0 + k;
+                if (a.rng.on && lane < H) {
+                    const int t = m + XCH;
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        float v = 1.f;
+                        if (b0 + n < a.B && t < T) v = nsd_rand_u32(a.rng.seed, a.rng.base, idx[n]) < a.rng.thr_lstm ? 0.f : a.rng.keep_lstm;
+                        sm.ms[cb ^ 1][n][k][lane] = v;
+                        idx[n] += H;
+                    }
+                }
+                if (k == XCH - 1) {
+#pragma unroll
+                    for (int q = 0; q < XPL; ++q) (&sm.xs[cb ^ 1][0][0][0])[lane + 64 * q] = xr[q];
+                    if (!a.rng.on) {
+#pragma unroll
+                        for (int q = 0; q < MPL; ++q) *reinterpret_cast<float4 *>(&sm.ms[cb ^ 1][0][0][0] + 4 * (lane + 64 * q)) = mr[q];
+                    }
+                }
+                step_barrier<false, S_SLEEP>(prof);
+            }
         }
-        step_barrier<false>(prof);
-        if (a.head_train) train_tail<NB>(a, sm, threadIdx.x, grp * NB);
+        if (a.head_train) tail_all<NB>(a, sm, threadIdx.x, b0);
+        else step_barrier<false>(prof);
     }
 }
 
@@ -830,12 +906,25 @@ __global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
     // i.e. ~155 / 150 / 135 / 135 VALU instructions per step and SIMD, instead of one SIMD carrying an L1, an L0 and
     // a P wave (~180).  s_setprio follows the critical path: L1 > L0 > P > the rest.
     const int g = wave & 3, q = wave >> 2;
+#ifdef NSD_FWD48_ONLY_ROLE                                     // resource probe (never built into the library): one role alone
+    if (NSD_FWD48_ONLY_ROLE == 1) p_role<NB>(a, sm, q * 64 + lane, n_steps);
+    else if (NSD_FWD48_ONLY_ROLE == 2) l1_role<NB>(a, sm, g * 64 + lane, n_steps);
+    else if (NSD_FWD48_ONLY_ROLE == 3) l0_role<NB>(a, sm, g * 64 + lane, n_steps);
+    else if (NSD_FWD48_ONLY_ROLE == 4) saver_role<NB>(a, sm, lane, n_steps);
+    else if (NSD_FWD48_ONLY_ROLE == 5) tpool_role<NB>(a, sm, lane, n_steps);
+    else spare_role<NB>(a, sm, lane, n_steps);
+    return;
+#endif
     if (g == 3)      { __builtin_amdgcn_s_setprio(1); p_role<NB>(a, sm, q * 64 + lane, n_steps); }
     else if (q == 0) { __builtin_amdgcn_s_setprio(3); l1_role<NB>(a, sm, g * 64 + lane, n_steps); }
     else if (q == 1) { __builtin_amdgcn_s_setprio(2); l0_role<NB>(a, sm, g * 64 + lane, n_steps); }
     else if (g == 0) {
-        if (a.logits_out) pool_role<NB>(a, sm, lane, n_steps);
-        else              saver_role<NB>(a, sm, lane, n_steps);
+        if constexpr (NB == 1) {
+            if (a.logits_out) pool_role<NB>(a, sm, lane, n_steps);
+            else              saver_role<NB>(a, sm, lane, n_steps);
+        } else {
+            saver_role<NB>(a, sm, lane, n_steps);               // (inference runs one trial per workgroup: nothing but its latency matters there)
+        }
     }
     else if (g == 1 && a.head_train) tpool_role<NB>(a, sm, lane, n_steps);
     else spare_role<NB>(a, sm, lane, n_steps);
@@ -844,15 +933,18 @@ __global__ __launch_bounds__(NT) void lstm2_fwd48_kernel(Lstm2FwdArgs a) {
 }  // namespace
 
 int nsd_lstm2_fwd48_launch(const Lstm2FwdArgs &a, int nb, int grid, hipStream_t st) {
-    // one trial per workgroup: the save ring and the register budget are sized for NB = 1; larger batches loop
-    if (nb != 1) { nsd_set_error("lstm2_fwd48: NB=%d not built", nb); return NSD_E_INVALID; }
+    // one trial per workgroup (latency: batches up to one trial per CU, and inference), or two trials per workgroup advancing in
+    // lock step (throughput: larger training batches -- two independent dependent chains per wave fill each other's issue gaps)
+    if (nb != 1 && nb != 2) { nsd_set_error("lstm2_fwd48: NB=%d not built", nb); return NSD_E_INVALID; }
+    if (nb == 2 && a.logits_out) { nsd_set_error("lstm2_fwd48: the inference tail runs one trial per workgroup"); return NSD_E_INVALID; }
     if (a.head_train) {
         if (!nsd_lstm2_fwd48_head_train_fits(a.T, a.F, a.K) || !(a.top || a.hseq1) || a.logits_out) {
             nsd_set_error("lstm2_fwd48: fused train head needs T<=%d, F<=64, K<=%d and the training workspace", TT_TMAX, TT_KMAX);
             return NSD_E_INVALID;
         }
     }
-    hipLaunchKernelGGL((lstm2_fwd48_kernel<1>), dim3(grid), dim3(NT), 0, st, a);
+    if (nb == 2) hipLaunchKernelGGL((lstm2_fwd48_kernel<2>), dim3(grid), dim3(NT), 0, st, a);
+    else         hipLaunchKernelGGL((lstm2_fwd48_kernel<1>), dim3(grid), dim3(NT), 0, st, a);
     NSD_CHECK_LAUNCH("lstm2_fwd48");
     return NSD_OK;
 }

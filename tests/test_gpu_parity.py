@@ -916,3 +916,53 @@ def test_train_cli_kfold_reports_mean_and_sd_without_epoch_selection(nsd, dev, t
     assert done["acc_val_mean"] == pytest.approx(np.mean([r["acc_val_last_epoch"] for r in folds]), abs=1e-3)
     assert done["acc_val_mean"] > 0.45 and done["acc_val_sd"] >= 0.0 and done["shipped"]["trained_on"] == 179
     nsd.SimplePredictor(out, sr=125, preprocess="identity")                 # strict=True load
+
+
+# ---------------------------------------------------------------------------------------------------
+# two trials per workgroup in the H = 48 forward kernel (training batches with at least two trials per CU)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,residual", [(2, 5, False), (7, 33, False), (9, 250, True), (513, 40, False), (1024, 250, False)])
+def test_two_trials_per_workgroup_forward_equals_the_one_trial_kernel_bitwise(nsd, dev, ref_state, B, T, residual, monkeypatch):
+    """lstm2_fwd48_kernel<2> advances two trials in lock step through the same roles (both layers, the input projection, the save
+    ring, attention pooling along the recurrence, the fused head / CE / head backward and the tail, in-kernel random streams):
+    every number it leaves -- logits, the whole training workspace (activations, alpha, dscore, dpooled, loss, head slabs) and the
+    gradients computed from it -- equals the one-trial instantiation's bit for bit, for odd batches too (a padding trial in the
+    last group), with explicit masks, with the streams drawn in the kernel, and through the two-launch (unfused head) route."""
+    from nsd_amd import ops
+    spec = ops.ModelSpec()
+    flat = _t(orc.flatten_state(ref_state, D), dev)
+    x, y = _t(synth_x(B, T, seed=B + T), dev), _t(synth_labels(B, seed=B + T).astype(np.int32), dev)
+    dl, sl, dh = (_t(m, dev) for m in counter_masks(B, T, 48, 32, seed=3 * B + T))
+    rng = dict(seed=0x1234ABCD, base_stream=44, p_lstm=0.6, p_head=0.6)
+    variants = [dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh, fused_head=True), dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh, fused_head=False)]
+    if ops.rng_path(spec, B, T) and not residual:
+        variants.append(dict(rng=rng))
+    for kw in variants:
+        res = {}
+        for nb in ("1", "2"):
+            monkeypatch.setenv("NSD_FWD48_NB", nb)
+            ws = ops.new_workspace(spec, B, T, dev)
+            ws.fill_(float("nan"))
+            logits = torch.full((B, spec.K), float("nan"), device=dev)
+            grads = torch.empty_like(flat)
+            ops.train_step_grads(spec, flat, x, ws, y, logits, grads, residual=residual, **kw)
+            torch.cuda.synchronize()
+            res[nb] = (logits.clone(), grads.clone(), ws.clone())
+        monkeypatch.delenv("NSD_FWD48_NB")
+        (l1, g1, w1), (l2, g2, w2) = res["1"], res["2"]
+        assert torch.isfinite(l1).all() and torch.isfinite(g1).all()
+        assert torch.equal(l1, l2), (kw.keys(), (l1 - l2).abs().max().item())
+        assert torch.equal(g1, g2), (kw.keys(), (g1 - g2).abs().max().item())
+        same = (w1 == w2) | (torch.isnan(w1) & torch.isnan(w2))            # (regions neither kernel writes stay NaN in both)
+        assert bool(same.all()), int((~same).sum().item())
+    # and against the oracle on the explicit-mask route, through the two-trial kernel
+    if B <= 600:
+        monkeypatch.setenv("NSD_FWD48_NB", "2")
+        flat_np = orc.flatten_state(ref_state, D)
+        xn, yn = synth_x(B, T, seed=B + T), synth_labels(B, seed=B + T)
+        dln, sln, dhn = counter_masks(B, T, 48, 32, seed=3 * B + T)
+        loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, xn, yn, D, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn, residual=residual)
+        loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, xn, yn, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn, residual=residual)
+        monkeypatch.delenv("NSD_FWD48_NB")
+        assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
+        _grad_close(grads, g_ref, D, rtol=3e-4)
