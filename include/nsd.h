@@ -240,6 +240,8 @@ int nsd_adam_step_dev(int64_t n, float *p, const float *g, float *m, float *v, f
  *   epilogue 0: C fp32 [M][ldc]; splits > 1 writes split z to C + z*M*ldc (the caller sums the parts)
  *            1: C bf16 [M][ldc]
  *            2: C bf16 as 32x32 accumulator tiles [N/32][M/32][64][16] (+ bias[m]): the layout the scan kernels' lanes load
+ *            3: the same tiles with the register group first, [N/32][M/32][4][64][4]: element (g, lane, e) is tile row
+ *               8 g + 4 (lane >> 5) + e, column lane & 31 (what lane `lane` of wave g of a backward scan owns, 8 contiguous bytes)
  * Contiguous dimensions and leading dimensions must be multiples of 8 elements.
  */
 int nsd_gemm_bf16(const void *A, int64_t lda, int32_t a_kmajor, const void *B, int64_t ldb, int32_t b_kmajor, int64_t b_shift,

@@ -93,6 +93,8 @@ enum GemmEpi {
     GEMM_EPI_F32 = 0,        // C fp32 [M][ldc]; split z writes to C + z * M * ldc
     GEMM_EPI_BF16 = 1,       // C bf16 [M][ldc]
     GEMM_EPI_TILE_BF16 = 2,  // C bf16 in 32x32 accumulator tiles: [N/32][M/32][64 lanes][16]  (+ bias[m])  -- what the scan's lanes load
+    GEMM_EPI_TILE_WAVE_BF16 = 3,  // the same tiles, register group j = r / 4 first: [N/32][M/32][4][64 lanes][4] -- the 8 bytes a lane of
+                                  // consumer wave j of a scan needs (4 adjacent rows = units, one column = trial) are contiguous over the lanes
 };
 struct GemmArgs {
     const bf16_t *A, *B;

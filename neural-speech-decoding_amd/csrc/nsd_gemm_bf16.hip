@@ -77,6 +77,49 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const bf16_t *S, const int base, c
     return cat_tr(lds_read_tr16(a), lds_read_tr16(a + 4 * LDT));
 }
 
+// epilogue shared by the kernels: the wave's MI x NJ accumulator tiles starting at (mb0, nb0)
+template <int EPI, int MI, int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&acc)[MI][NJ], const int mb0, const int nb0, const int lane) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int mb = mb0 + 32 * i, nb = nb0 + 32 * j;
+            const int n = nb + (lane & 31);
+            if (EPI == GEMM_EPI_TILE_BF16 || EPI == GEMM_EPI_TILE_WAVE_BF16) {
+                if (mb + 32 <= g.M && nb + 32 <= g.N) {            // whole tiles only (M, N multiples of 32 on these routes)
+                    unsigned w[8];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float b0 = g.bias ? g.bias[mb + mfma32_row(r, lane)] : 0.f;
+                        const float b1 = g.bias ? g.bias[mb + mfma32_row(r + 1, lane)] : 0.f;
+                        w[r >> 1] = pack_bf16x2(acc[i][j][r] + b0, acc[i][j][r + 1] + b1);
+                    }
+                    bf16_t *tile = reinterpret_cast<bf16_t *>(g.C) + ((long)(nb >> 5) * (g.M >> 5) + (mb >> 5)) * 1024;
+                    if (EPI == GEMM_EPI_TILE_BF16) {
+                        *reinterpret_cast<u32x4 *>(tile + lane * 16) = u32x4{w[0], w[1], w[2], w[3]};
+                        *reinterpret_cast<u32x4 *>(tile + lane * 16 + 8) = u32x4{w[4], w[5], w[6], w[7]};
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2 *>(tile + q * 256 + lane * 4) = u32x2{w[2 * q], w[2 * q + 1]};
+                    }
+                }
+            } else {
+                if (n >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + mfma32_row(r, lane);
+                    if (m >= g.M) continue;
+                    if (EPI == GEMM_EPI_F32)
+                        (reinterpret_cast<float *>(g.C) + (long)blockIdx.z * g.M * g.ldc)[(long)m * g.ldc + n] =
+                            acc[i][j][r] + (g.add ? g.add[(long)m * g.ldc + n] : 0.f);
+                    else
+                        reinterpret_cast<bf16_t *>(g.C)[(long)m * g.ldc + n] = (bf16_t)acc[i][j][r];
+                }
+            }
+        }
+}
+
 template <bool AK, bool BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
     __shared__ __align__(16) unsigned char smem[2 * OPBYTES];
@@ -121,79 +164,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
             }
         }
     }
-    // ---- epilogue ---------------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int mb = m0 + 64 * wm + 32 * i, nb = n0 + 64 * wn + 32 * j;
-            const int n = nb + (lane & 31);
-            if (EPI == GEMM_EPI_TILE_BF16) {
-                if (mb + 32 <= g.M && nb + 32 <= g.N) {            // whole tiles only (M, N multiples of 32 on this route)
-                    unsigned w[8];
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const float b0 = g.bias ? g.bias[mb + mfma32_row(r, lane)] : 0.f;
-                        const float b1 = g.bias ? g.bias[mb + mfma32_row(r + 1, lane)] : 0.f;
-                        w[r >> 1] = pack_bf16x2(acc[i][j][r] + b0, acc[i][j][r + 1] + b1);
-                    }
-                    bf16_t *dst = reinterpret_cast<bf16_t *>(g.C) + (((long)(nb >> 5) * (g.M >> 5) + (mb >> 5)) * 64 + lane) * 16;
-                    *reinterpret_cast<u32x4 *>(dst) = u32x4{w[0], w[1], w[2], w[3]};
-                    *reinterpret_cast<u32x4 *>(dst + 8) = u32x4{w[4], w[5], w[6], w[7]};
-                }
-            } else {
-                if (n >= g.N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + mfma32_row(r, lane);
-                    if (m >= g.M) continue;
-                    if (EPI == GEMM_EPI_F32)
-                        (reinterpret_cast<float *>(g.C) + (long)blockIdx.z * g.M * g.ldc)[(long)m * g.ldc + n] =
-                            acc[i][j][r] + (g.add ? g.add[(long)m * g.ldc + n] : 0.f);
-                    else
-                        reinterpret_cast<bf16_t *>(g.C)[(long)m * g.ldc + n] = (bf16_t)acc[i][j][r];
-                }
-            }
-        }
-}
-
-
-// epilogue of the 256 x 256 kernels: the wave's 4 x 2 accumulator tiles starting at (mb0, nb0)
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&acc)[4][2], const int mb0, const int nb0, const int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int mb = mb0 + 32 * i, nb = nb0 + 32 * j;
-            const int n = nb + (lane & 31);
-            if (EPI == GEMM_EPI_TILE_BF16) {
-                if (mb + 32 <= g.M && nb + 32 <= g.N) {
-                    unsigned w[8];
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const float b0 = g.bias ? g.bias[mb + mfma32_row(r, lane)] : 0.f;
-                        const float b1 = g.bias ? g.bias[mb + mfma32_row(r + 1, lane)] : 0.f;
-                        w[r >> 1] = pack_bf16x2(acc[i][j][r] + b0, acc[i][j][r + 1] + b1);
-                    }
-                    bf16_t *dst = reinterpret_cast<bf16_t *>(g.C) + (((long)(nb >> 5) * (g.M >> 5) + (mb >> 5)) * 64 + lane) * 16;
-                    *reinterpret_cast<u32x4 *>(dst) = u32x4{w[0], w[1], w[2], w[3]};
-                    *reinterpret_cast<u32x4 *>(dst + 8) = u32x4{w[4], w[5], w[6], w[7]};
-                }
-            } else {
-                if (n >= g.N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + mfma32_row(r, lane);
-                    if (m >= g.M) continue;
-                    if (EPI == GEMM_EPI_F32)
-                        (reinterpret_cast<float *>(g.C) + (long)blockIdx.z * g.M * g.ldc)[(long)m * g.ldc + n] =
-                            acc[i][j][r] + (g.add ? g.add[(long)m * g.ldc + n] : 0.f);
-                    else
-                        reinterpret_cast<bf16_t *>(g.C)[(long)m * g.ldc + n] = (bf16_t)acc[i][j][r];
-                }
-            }
-        }
+    gemm_epilogue<EPI, 2, 2>(g, acc, m0 + 64 * wm, n0 + 64 * wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -337,39 +308,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
             __syncthreads();
         }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int mb = m0 + 128 * wm + 32 * i, nb = n0 + 64 * wn + 32 * j;
-            const int n = nb + (lane & 31);
-            if (EPI == GEMM_EPI_TILE_BF16) {
-                if (mb + 32 <= g.M && nb + 32 <= g.N) {
-                    unsigned w[8];
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const float b0 = g.bias ? g.bias[mb + mfma32_row(r, lane)] : 0.f;
-                        const float b1 = g.bias ? g.bias[mb + mfma32_row(r + 1, lane)] : 0.f;
-                        w[r >> 1] = pack_bf16x2(acc[i][j][r] + b0, acc[i][j][r + 1] + b1);
-                    }
-                    bf16_t *dst = reinterpret_cast<bf16_t *>(g.C) + (((long)(nb >> 5) * (g.M >> 5) + (mb >> 5)) * 64 + lane) * 16;
-                    *reinterpret_cast<u32x4 *>(dst) = u32x4{w[0], w[1], w[2], w[3]};
-                    *reinterpret_cast<u32x4 *>(dst + 8) = u32x4{w[4], w[5], w[6], w[7]};
-                }
-            } else {
-                if (n >= g.N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + mfma32_row(r, lane);
-                    if (m >= g.M) continue;
-                    if (EPI == GEMM_EPI_F32)
-                        (reinterpret_cast<float *>(g.C) + (long)blockIdx.z * g.M * g.ldc)[(long)m * g.ldc + n] =
-                            acc[i][j][r] + (g.add ? g.add[(long)m * g.ldc + n] : 0.f);
-                    else
-                        reinterpret_cast<bf16_t *>(g.C)[(long)m * g.ldc + n] = (bf16_t)acc[i][j][r];
-                }
-            }
-        }
+    gemm_epilogue<EPI, 4, 2>(g, acc, m0 + 128 * wm, n0 + 64 * wn, lane);
 }
 
 template <bool AK, bool BK, int EPI>
@@ -393,6 +332,7 @@ int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
     case GEMM_EPI_F32: return launch_one<AK, BK, GEMM_EPI_F32>(g, grid, st);
     case GEMM_EPI_BF16: return launch_one<AK, BK, GEMM_EPI_BF16>(g, grid, st);
     case GEMM_EPI_TILE_BF16: return launch_one<AK, BK, GEMM_EPI_TILE_BF16>(g, grid, st);
+    case GEMM_EPI_TILE_WAVE_BF16: return launch_one<AK, BK, GEMM_EPI_TILE_WAVE_BF16>(g, grid, st);
     default: nsd_set_error("gemm_bf16: unknown epilogue %d", g.epi); return NSD_E_INVALID;
     }
 }
@@ -568,7 +508,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmArgs g) {
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (out-of-range requests of the last chunks: nothing may be in flight when the LDS is released)
     }
-    gemm_epilogue<EPI>(g, acc, m0 + 128 * wm, n0 + 64 * wn, lane);
+    gemm_epilogue<EPI, 4, 2>(g, acc, m0 + 128 * wm, n0 + 64 * wn, lane);
 }
 
 template <int EPI, int SA, int SB>
@@ -593,6 +533,7 @@ int launch_stages(const GemmArgs &g, const dim3 grid, hipStream_t st) {
     case GEMM_EPI_F32: return launch_one<GEMM_EPI_F32, SA, SB>(g, grid, st);
     case GEMM_EPI_BF16: return launch_one<GEMM_EPI_BF16, SA, SB>(g, grid, st);
     case GEMM_EPI_TILE_BF16: return launch_one<GEMM_EPI_TILE_BF16, SA, SB>(g, grid, st);
+    case GEMM_EPI_TILE_WAVE_BF16: return launch_one<GEMM_EPI_TILE_WAVE_BF16, SA, SB>(g, grid, st);
     default: nsd_set_error("gemm_bf16: unknown epilogue %d", g.epi); return NSD_E_INVALID;
     }
 }
@@ -612,6 +553,7 @@ int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
     case GEMM_EPI_F32: hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK, GEMM_EPI_F32>), grid, dim3(256), 0, st, g); break;
     case GEMM_EPI_BF16: hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK, GEMM_EPI_BF16>), grid, dim3(256), 0, st, g); break;
     case GEMM_EPI_TILE_BF16: hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK, GEMM_EPI_TILE_BF16>), grid, dim3(256), 0, st, g); break;
+    case GEMM_EPI_TILE_WAVE_BF16: hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK, GEMM_EPI_TILE_WAVE_BF16>), grid, dim3(256), 0, st, g); break;
     default: nsd_set_error("gemm_bf16: unknown epilogue %d", g.epi); return NSD_E_INVALID;
     }
     NSD_CHECK_LAUNCH("gemm_bf16_kernel");
@@ -633,7 +575,7 @@ int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
                       g.M, g.N, g.K, g.lda, g.ldb);
         return NSD_E_INVALID;
     }
-    if (g.epi == GEMM_EPI_TILE_BF16 && (g.M % 32 || g.N % 32)) { nsd_set_error("gemm_bf16: tile output needs M, N multiples of 32"); return NSD_E_INVALID; }
+    if ((g.epi == GEMM_EPI_TILE_BF16 || g.epi == GEMM_EPI_TILE_WAVE_BF16) && (g.M % 32 || g.N % 32)) { nsd_set_error("gemm_bf16: tile output needs M, N multiples of 32"); return NSD_E_INVALID; }
     const int splits = (g.epi == GEMM_EPI_F32 && g.splits > 1) ? g.splits : 1;
     if (g.b_shift != 0 && !g.b_kmajor) { nsd_set_error("gemm_bf16: b_shift needs a k-major B"); return NSD_E_INVALID; }
     if (g.b_period < 0 || (g.b_period > 0 && (g.K >= (1L << 31) || g.b_shift >= g.b_period || -g.b_shift >= g.b_period))) { nsd_set_error("gemm_bf16: bad b_period"); return NSD_E_INVALID; }

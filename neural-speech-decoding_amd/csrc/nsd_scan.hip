@@ -306,7 +306,10 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 // TOP: the layer under the head (upstream term from alpha / dscore / dpooled) or a lower layer (from din).  A template parameter,
 // not a run-time branch: with the branch inside load_saved hipcc merges the two arms through copies and guards them with
 // vmcnt(2) right behind the loads -- a full HBM latency per 32-trial half and step (11 500 of 20 000 cycles at H = 512).
-template <int H, int NT, bool TOP>
+// DINT (lower layers): the upstream gradient comes as bf16 accumulator tiles written by the input-gradient GEMM in the order this
+// kernel's lanes own them (8 contiguous bytes per lane, 512 per wave instruction) instead of row-major fp32, where a lane's 16
+// bytes sat in a row of their own: 64 line requests per instruction, ~2 300 cycles of a 16 300-cycle step at H = 512.
+template <int H, int NT, bool TOP, bool DINT>
 __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     // The recurrent term dh_rec = W_hh^T da_{t+1} is exchanged as a reduce-scatter of bf16 partial sums (design and ring layout:
     // nsd_scan2.hip, "backward"): the workgroup multiplies its OWN 128 gate columns of da (from LDS, K = 128) into partial dh
@@ -373,6 +376,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
         u32x4 gq[NT][2];
         u32x2 cq[NT], cpq[NT];
         f32x4 dv[NT];
+        u32x2 dvt[NT];
         float al[NT], ds[NT];
     };
     auto t_of = [&](const int s) { return dir == 0 ? T - 1 - s : s; };   // reverse of the forward order
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             const bool first = dir == 0 ? t == 0 : t == T - 1;
             v.cpq[nt] = first ? u32x2{0u, 0u} : ld_stream<u32x2>(a.cs[dir] + saved_cs(blk + 4 * (tprev - t), lane));
             if constexpr (TOP) { v.al[nt] = ld_stream<float>(a.alpha + row); v.ds[nt] = ld_stream<float>(a.dscore + row); }
+            else if constexpr (DINT) v.dvt[nt] = ld_stream<u32x2>(a.din_tiles + ((((long)((b0 >> 5) + nt) * T + t) * (a.D * P) + dir * P + me.p) * 1024 + wave * 256 + lane * 4));
             else v.dv[nt] = ld_stream<f32x4>(a.din + row * ld + dir * H + u0);
         }
     };
@@ -414,8 +419,13 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) m[j] = nsd_rand_u32(a.rng.seed, a.rng.base, base + j) >= a.rng.thr_lstm ? a.rng.keep_lstm : 0.f;
                 }
+                if constexpr (DINT) {
+                    dup[nt][0] = bf16_lo(sv.dvt[nt][0]) * m[0]; dup[nt][1] = bf16_hi(sv.dvt[nt][0]) * m[1];
+                    dup[nt][2] = bf16_lo(sv.dvt[nt][1]) * m[2]; dup[nt][3] = bf16_hi(sv.dvt[nt][1]) * m[3];
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dup[nt][j] = sv.dv[nt][j] * m[j];
+                    for (int j = 0; j < 4; ++j) dup[nt][j] = sv.dv[nt][j] * m[j];
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dup[nt][j] = fmaf(sv.al[nt], dpl[nt][j], sv.ds[nt] * aw[j]);
@@ -580,12 +590,15 @@ int launch_fwd_h(const ScanFwdArgs &a, int MG, const dim3 grid, hipStream_t st) 
 }
 template <int H>
 int launch_bwd_h(const ScanBwdArgs &a, int MG, const dim3 grid, hipStream_t st) {
-    if (a.din == nullptr) {
-        if (MG == 32) hipLaunchKernelGGL((scan_bwd_kernel<H, 1, true>), grid, dim3(256), 0, st, a);
-        else          hipLaunchKernelGGL((scan_bwd_kernel<H, 2, true>), grid, dim3(256), 0, st, a);
+    if (a.din == nullptr && a.din_tiles == nullptr) {
+        if (MG == 32) hipLaunchKernelGGL((scan_bwd_kernel<H, 1, true, false>), grid, dim3(256), 0, st, a);
+        else          hipLaunchKernelGGL((scan_bwd_kernel<H, 2, true, false>), grid, dim3(256), 0, st, a);
+    } else if (a.din_tiles != nullptr) {
+        if (MG == 32) hipLaunchKernelGGL((scan_bwd_kernel<H, 1, false, true>), grid, dim3(256), 0, st, a);
+        else          hipLaunchKernelGGL((scan_bwd_kernel<H, 2, false, true>), grid, dim3(256), 0, st, a);
     } else {
-        if (MG == 32) hipLaunchKernelGGL((scan_bwd_kernel<H, 1, false>), grid, dim3(256), 0, st, a);
-        else          hipLaunchKernelGGL((scan_bwd_kernel<H, 2, false>), grid, dim3(256), 0, st, a);
+        if (MG == 32) hipLaunchKernelGGL((scan_bwd_kernel<H, 1, false, false>), grid, dim3(256), 0, st, a);
+        else          hipLaunchKernelGGL((scan_bwd_kernel<H, 2, false, false>), grid, dim3(256), 0, st, a);
     }
     NSD_CHECK_LAUNCH("scan_bwd_kernel");
     return NSD_OK;

@@ -95,7 +95,9 @@ struct ScanBwdArgs {
     bf16_t *da;                              // [T*Bp][D*4H]
     float *dbp;                              // [D][groups_total][4H] bias-gradient partials, one row per batch tile (unit-major columns)
     bf16_t *xch;                             // partial-sum ring [2][D][groups_total][P][P][NT][4][64 x 8 B] (nsd_scan.hip)
-    const float *din;                        // [T*Bp][ld] gradient w.r.t. this layer's (multiplied) output, or null (top layer)
+    const float *din;                        // [T*Bp][ld] fp32 gradient w.r.t. this layer's (multiplied) output (residual extension), or null
+    const bf16_t *din_tiles;                 // the same gradient as bf16 accumulator tiles of the transposed product, register-group major:
+                                             // [T*Bp/32][D*H/32][4 consumer waves][64 lanes][4 units] (GEMM_EPI_TILE_WAVE_BF16), or null
     float *dres;                             // [T*Bp][ld] residual extension: d(linked output) * multiplier, added to the input gradient; or null
     const float *alpha, *dscore;             // [T*Bp] (top layer)
     const float *dpooled;                    // [Bp][ld]

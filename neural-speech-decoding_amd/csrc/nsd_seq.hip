@@ -96,7 +96,7 @@ SeqWs make_ws(const SeqDims &s) {
     for (int d = 0; d < s.D; ++d) w.xproj[d] = take(R * G * 2);
     w.da = take(R * s.D * G * 2);
     w.da2 = s.fused2 ? take(R * G * 2) : 0;                  // fused two-layer scans: layer 1's da next to layer 0's
-    w.din[0] = take(R * DH * 4);
+    w.din[0] = take(R * DH * (s.residual ? 4 : 2));             // bf16 owner-ordered tiles; row-major fp32 with the residual extension
     w.din[1] = s.residual ? take(R * DH * 4) : 0;           // residual extension: d(linked output) passed around the LSTM
     w.alpha = take(R * 4);
     w.dscore = take(R * 4);
@@ -365,7 +365,9 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
                 a.ga[d] = at<bf16_t>(c.ws, c.w.ga[l][d]);
             }
             a.da = at<bf16_t>(c.ws, c.w.da);
-            a.din = l == s.L - 1 ? nullptr : at<float>(c.ws, c.w.din[0]);
+            // the upstream gradient of a lower layer: bf16 tiles in owner order, or (residual extension) row-major fp32
+            a.din = (l == s.L - 1 || !s.residual) ? nullptr : at<float>(c.ws, c.w.din[0]);
+            a.din_tiles = (l == s.L - 1 || s.residual) ? nullptr : at<bf16_t>(c.ws, c.w.din[0]);
             a.dres = (s.residual && l >= 1) ? at<float>(c.ws, c.w.din[1]) : nullptr;
             a.alpha = at<float>(c.ws, c.w.alpha); a.dscore = at<float>(c.ws, c.w.dscore); a.dpooled = at<float>(c.ws, c.w.dpooled);
             a.attn_w = c.params + c.pl.attn_w;
@@ -383,9 +385,17 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
         if (l > 0) {                                             // gradient w.r.t. the layer's input, both directions in one contraction
             GemmArgs g;
             memset(&g, 0, sizeof(g));
-            g.A = at<bf16_t>(c.ws, c.w.da); g.lda = (long)s.D * G; g.B = at<bf16_t>(c.ws, c.w.wxt[l]); g.ldb = (long)s.D * G;
-            g.C = at<float>(c.ws, c.w.din[0]); g.ldc = DH; g.M = (int)R; g.N = DH; g.K = (long)s.D * G; g.splits = 1; g.epi = GEMM_EPI_F32;
-            g.add = s.residual ? at<float>(c.ws, c.w.din[1]) : nullptr;       // residual extension: + d(linked output) of this layer
+            if (s.residual) {                                    // row-major fp32 + d(linked output) of this layer (extension)
+                g.A = at<bf16_t>(c.ws, c.w.da); g.lda = (long)s.D * G; g.B = at<bf16_t>(c.ws, c.w.wxt[l]); g.ldb = (long)s.D * G;
+                g.C = at<float>(c.ws, c.w.din[0]); g.ldc = DH; g.M = (int)R; g.N = DH; g.K = (long)s.D * G; g.splits = 1; g.epi = GEMM_EPI_F32;
+                g.add = at<float>(c.ws, c.w.din[1]);
+            } else {
+                // the TRANSPOSED product d_in^T [D*H, T*Bp] = W_ih^T' . da^T: an accumulator tile is then 32 units x the 32 trials of
+                // one (batch tile, step) -- registers 4j..4j+3 of a lane are what lane (trial, half) of wave j of the lower layer's
+                // backward scan needs -- written as bf16 in that order (the scan's lanes load 8 contiguous bytes)
+                g.A = at<bf16_t>(c.ws, c.w.wxt[l]); g.lda = (long)s.D * G; g.B = at<bf16_t>(c.ws, c.w.da); g.ldb = (long)s.D * G;
+                g.C = at<bf16_t>(c.ws, c.w.din[0]); g.ldc = 0; g.M = DH; g.N = (int)R; g.K = (long)s.D * G; g.splits = 1; g.epi = GEMM_EPI_TILE_WAVE_BF16;
+            }
             ProfScope ps(PK_GEMM_DIN, c.st);
             if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
         }

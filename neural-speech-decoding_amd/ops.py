@@ -363,7 +363,8 @@ def gemm_bf16(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = False, b_kma
               epilogue: int = 0, bias: Optional[torch.Tensor] = None, splits: int = 1) -> torch.Tensor:
     """C[M,N] = A . B on the matrix pipe (nsd_gemm_bf16): bf16 device tensors, fp32 accumulate.
     a: [M,K] (or [K,M] when a_kmajor), b: [N,K] (or [K,N] when b_kmajor).  epilogue 0 -> fp32 [splits,M,N] summed here when
-    splits > 1; 1 -> bf16 [M,N]; 2 -> bf16 accumulator tiles [N/32, M/32, 64, 16] (+ bias[m])."""
+    splits > 1; 1 -> bf16 [M,N]; 2 -> bf16 accumulator tiles [N/32, M/32, 64, 16] (+ bias[m]); 3 -> the same tiles, register group
+    first: [N/32, M/32, 4, 64, 4]."""
     for t, n in ((a, "a"), (b, "b")):
         if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
             raise NsdError(f"gemm_bf16: {n} must be a contiguous bf16 tensor on the MI355X")
@@ -376,8 +377,10 @@ def gemm_bf16(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = False, b_kma
         c = torch.empty((max(splits, 1), M, N), dtype=torch.float32, device=dev)
     elif epilogue == 1:
         c = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    else:
+    elif epilogue == 2:
         c = torch.empty((N // 32, M // 32, 64, 16), dtype=torch.bfloat16, device=dev)
+    else:
+        c = torch.empty((N // 32, M // 32, 4, 64, 4), dtype=torch.bfloat16, device=dev)
     _call("nsd_gemm_bf16", dev, a.data_ptr(), a.shape[1], int(a_kmajor), b.data_ptr(), b.shape[1], int(b_kmajor), int(b_shift),
           c.data_ptr(), N, int(epilogue), _dev_f32(bias, "bias", (M,)), M, N, K, int(splits), STREAM)
     if epilogue == 0:

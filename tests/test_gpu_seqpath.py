@@ -90,6 +90,10 @@ def test_gemm_bf16_split_k_shift_and_tile_epilogue(nsd, dev):
         for mt in range(M // 32):
             want = ref[32 * mt + rows, 32 * nt + cols]
             assert np.abs(tiles[nt, mt] - want).max() <= 2 ** -8 * np.abs(want).max() + 1e-3
+    # register-group-major tiles (epilogue 3: what a backward scan's lanes load): [N/32][M/32][4][64][4] is a permutation of epilogue 2
+    t2 = ops.gemm_bf16(w, xin, epilogue=2, bias=bias)                                  # [N/32, M/32, 64, 16]
+    t3 = ops.gemm_bf16(w, xin, epilogue=3, bias=bias)                                  # [N/32, M/32, 4, 64, 4]
+    assert torch.equal(t3, t2.view(N // 32, M // 32, 64, 4, 4).permute(0, 1, 3, 2, 4).contiguous())
 
 
 @pytest.mark.parametrize("a_kmajor,b_kmajor", [(False, False), (False, True), (True, False), (True, True)])
@@ -120,6 +124,8 @@ def test_gemm_bf16_large_tile_kernel(nsd, dev, a_kmajor, b_kmajor):
         for nt, mt in ((0, 0), (5, 77), (125, 127), (64, 3)):
             w = want[32 * mt + rows, 32 * nt + cols]
             assert (tiles[nt, mt] - w).abs().max().item() <= 2 ** -8 * w.abs().max().item() + 1e-3
+        t3 = ops.gemm_bf16(a[:M2].contiguous(), b[:N2].contiguous(), epilogue=3, bias=bias)
+        assert torch.equal(t3, tiles.to(torch.bfloat16).view(N2 // 32, M2 // 32, 64, 4, 4).permute(0, 1, 3, 2, 4).contiguous())
 
 
 def test_gemm_bf16_large_tile_split_k_shift_period(nsd, dev):
@@ -150,10 +156,16 @@ from nsd_amd import _lib                                  # noqa: E402  (diagnos
 from oracle import nsd_oracle as orc                      # noqa: E402  (test infrastructure: the checker)
 from tests.golden.make_goldens import synth_labels, synth_params, synth_x      # noqa: E402
 
-# bf16 operands / bf16 saved activations, fp32 accumulation: measured agreement with the fp32 oracle is ~1e-2 on logits
-# of magnitude ~1 and a few percent of each gradient tensor's largest element; the bounds below are ~3x that.
+# bf16 operands / bf16 saved activations, fp32 accumulation.  Measured against the fp32 oracles on one MI355X (round 3, this file run
+# with -s: every _grad_check prints its worst tensor): logits 5e-4 .. 6.2e-3; gradients, relative to each tensor's largest element,
+# 0.2 .. 0.5 % for batches of a few hundred trials without dropout (cfg5's kernels at T = 1000: 0.41 %), 2 .. 4.4 % for the small
+# batches (37 .. 70 trials) with dropout p = 0.5 .. 0.6 -- the surviving units carry 2 .. 2.5x weights and one RReLU-kink flip of one
+# trial moves a head tensor by percents (fc.*: up to 8.9 % at B = 1030, T = 3, bounded separately where it occurs).
+# Bounds: ~3x the measured logit error; 1.4x the worst measured small-batch gradient error (a bound of 3x would be 13 %, and would
+# hide a wrong term); the large clean cases carry their own, 3x-measured bound (SEQ_GRAD_RTOL_CLEAN).
 SEQ_LOGIT_TOL = 2e-2
 SEQ_GRAD_RTOL = 6e-2
+SEQ_GRAD_RTOL_CLEAN = 1.5e-2
 
 
 def _flat(state, d, dev):
@@ -899,10 +911,11 @@ def test_cfg5_kernels_thousand_steps_vs_torch(nsd, dev):
     print("cfg5 kernels, B=264 T=1000: errors vs torch:", {k: round(v, 5) for k, v in errs.items()})
     assert status[0] == 0 and status[1] + status[2] == 2 * 2 * 2 * 5, status
     assert errs["logits"] < SEQ_LOGIT_TOL and errs["loss"] < 2e-2
+    assert errs["logits"] < 5e-3                              # (measured 8.2e-4 over 1000 recurrent steps)
     for k, v in errs.items():
         if k in ("logits", "loss"):
             continue
-        assert v <= (1e-4 if k == "attn.bias" else (2 * SEQ_GRAD_RTOL if k.startswith("fc.") else SEQ_GRAD_RTOL)), (k, v)
+        assert v <= (1e-4 if k == "attn.bias" else SEQ_GRAD_RTOL_CLEAN), (k, v)    # measured <= 0.41 %
 
 
 @pytest.mark.timeout(900)
