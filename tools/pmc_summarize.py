@@ -30,6 +30,7 @@ else:
 
 def counters(sub, name):
     files = glob.glob(os.path.join(base, sub, "**", "*counter_collection.csv"), recursive=True)
+    files = sorted(files, key=os.path.getmtime)[-1:]          # the newest pass only (gpurun merges every run's files into gpurun_out/)
     acc = collections.defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -58,9 +59,9 @@ for k in sorted(set(fetch) | set(write)):
 dst = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")
 json.dump(out, open(dst, "w"), indent=1)
 print("wrote", dst)
-stats = glob.glob(os.path.join(base, "trace", "**", "*kernel_stats.csv"), recursive=True)
+stats = sorted(glob.glob(os.path.join(base, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+    shutil.copy(stats[-1], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
     print("wrote", os.path.join("profiles", f"{tag}_kernel_stats.csv"))
 for k, e in out["kernels"].items():
     print(f"  {k:32s} {e['hbm_bytes_per_launch_corrected'] / 1e6:9.1f} MB/launch")
