@@ -40,9 +40,9 @@ template <int VPL, bool TRAIN>
 __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
     // U rows of the trial in flight per lane: the passes over the sequence are latency-bound (one wave per trial, 4 waves per CU at
     // B = 1024), so the bytes in flight set the rate -- 4 rows gave 1.3 TB/s
-    constexpr int DH = 64 * VPL, U = VPL >= 16 ? 4 : (VPL >= 8 ? 8 : 16);
+    constexpr int DH = 64 * VPL, U = VPL >= 16 ? 8 : (VPL >= 8 ? 8 : 16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * 4 + wave;
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;        // one wave per trial; 4, 2 or 1 waves per workgroup (see launch_vpl)
     if (b >= a.B) return;                                       // whole waves leave; nothing below needs the workgroup
     const int c0 = lane * VPL, T = a.T, F = a.F, K = a.K;
     // a scan group of this evaluation (or of an earlier one on this workspace) timed out: the sequence below is garbage
@@ -282,9 +282,13 @@ __global__ __launch_bounds__(256) void head_tm_grads_sum_kernel(const float *par
 
 template <int VPL>
 int launch_vpl(const HeadTmArgs &a, hipStream_t st) {
-    const dim3 grid((a.B + 3) / 4);
-    if (a.train) hipLaunchKernelGGL((head_tm_kernel<VPL, true>), grid, dim3(256), 0, st, a);
-    else         hipLaunchKernelGGL((head_tm_kernel<VPL, false>), grid, dim3(256), 0, st, a);
+    // the passes over the sequence are latency-bound, one wave per trial: with few trials (cfg5: 512 per GPU) four waves per workgroup
+    // put them on half of the CUs -- spread the waves over as many CUs as there are trials
+    const int cus = nsd_num_cus();
+    const int wpw = a.B >= 4 * cus ? 4 : (a.B >= 2 * cus ? 2 : 1);
+    const dim3 grid((a.B + wpw - 1) / wpw);
+    if (a.train) hipLaunchKernelGGL((head_tm_kernel<VPL, true>), grid, dim3(64 * wpw), 0, st, a);
+    else         hipLaunchKernelGGL((head_tm_kernel<VPL, false>), grid, dim3(64 * wpw), 0, st, a);
     NSD_CHECK_LAUNCH("head_tm_kernel");
     return NSD_OK;
 }
