@@ -102,6 +102,12 @@ struct GemmArgs {
     int a_kmajor, b_kmajor;
     long b_shift;            // K-row shift of operand B (k-major B only): row k of A meets row k + b_shift of B; rows shifted out read zero
     long b_period;           // 0: ... out of [0, K); > 0: ... out of row k's own block of b_period rows (tile-major sequences: one batch tile)
+    // optional SECOND k-major source for the columns n >= n_split (a multiple of 256): B2[K][ldb2] with its own shift.  Two weight
+    // gradients that share their A operand -- dW_hh = da^T . h_prev and dW_ih = da^T . in -- are then ONE pass over da (the sequence
+    // does not fit the Infinity Cache: a second launch re-reads it from HBM)
+    const bf16_t *B2;
+    long ldb2, b2_shift;
+    int n_split;
     void *C;
     long ldc;
     const float *bias;       // [M] (GEMM_EPI_TILE_BF16) or null

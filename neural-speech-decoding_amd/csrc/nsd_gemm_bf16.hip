@@ -140,7 +140,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
         for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
 
     auto lda_ = [&](long k0) { return AK ? load_kmajor(g.A, g.lda, m0, g.M, k0, k_hi, 0, 0, g.K, tid) : load_rowmajor(g.A, g.lda, m0, g.M, k0, k_hi, tid); };
-    auto ldb_ = [&](long k0) { return BK ? load_kmajor(g.B, g.ldb, n0, g.N, k0, k_hi, g.b_shift, g.b_period, g.K, tid) : load_rowmajor(g.B, g.ldb, n0, g.N, k0, k_hi, tid); };
+    // (columns from the second source where the tile lies beyond n_split)
+    const bool second = BK && g.B2 != nullptr && n0 >= g.n_split;
+    const bf16_t *Bsrc = second ? g.B2 : g.B;
+    const long ldbs = second ? g.ldb2 : g.ldb, bsh = second ? g.b2_shift : g.b_shift;
+    const int nloc = second ? n0 - g.n_split : n0, ncol = g.B2 == nullptr ? g.N : (second ? g.N - g.n_split : g.n_split);
+    auto ldb_ = [&](long k0) { return BK ? load_kmajor(Bsrc, ldbs, nloc, ncol, k0, k_hi, bsh, g.b_period, g.K, tid) : load_rowmajor(g.B, g.ldb, n0, g.N, k0, k_hi, tid); };
     if (k_lo < k_hi) {
         Pieces pa = lda_(k_lo), pb = ldb_(k_lo);
         for (long k0 = k_lo; k0 < k_hi; k0 += GK) {
@@ -259,7 +264,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
         for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
 
     auto lda_ = [&](long k0) { return AK ? load_kmajor_b(g.A, g.lda, m0, g.M, k0, k_hi, 0, 0, g.K, tid) : load_rowmajor_b(g.A, g.lda, m0, g.M, k0, k_hi, tid); };
-    auto ldb_ = [&](long k0) { return BK ? load_kmajor_b(g.B, g.ldb, n0, g.N, k0, k_hi, g.b_shift, g.b_period, g.K, tid) : load_rowmajor_b(g.B, g.ldb, n0, g.N, k0, k_hi, tid); };
+    const bool second = BK && g.B2 != nullptr && n0 >= g.n_split;
+    const bf16_t *Bsrc = second ? g.B2 : g.B;
+    const long ldbs = second ? g.ldb2 : g.ldb, bsh = second ? g.b2_shift : g.b_shift;
+    const int nloc = second ? n0 - g.n_split : n0, ncol = g.B2 == nullptr ? g.N : (second ? g.N - g.n_split : g.n_split);
+    auto ldb_ = [&](long k0) { return BK ? load_kmajor_b(Bsrc, ldbs, nloc, ncol, k0, k_hi, bsh, g.b_period, g.K, tid) : load_rowmajor_b(g.B, g.ldb, n0, g.N, k0, k_hi, tid); };
     auto put = [&](const int buf, const Pieces &pa, const Pieces &pb) {
         bf16_t *As = reinterpret_cast<bf16_t *>(smem + (size_t)buf * 2 * OPB), *Bs = reinterpret_cast<bf16_t *>(smem + (size_t)buf * 2 * OPB + OPB);
         if (AK) store_kmajor_b(As, pa, tid); else store_rowmajor_b(As, pa, tid);
@@ -579,6 +588,10 @@ int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
     const int splits = (g.epi == GEMM_EPI_F32 && g.splits > 1) ? g.splits : 1;
     if (g.b_shift != 0 && !g.b_kmajor) { nsd_set_error("gemm_bf16: b_shift needs a k-major B"); return NSD_E_INVALID; }
     if (g.b_period < 0 || (g.b_period > 0 && (g.K >= (1L << 31) || g.b_shift >= g.b_period || -g.b_shift >= g.b_period))) { nsd_set_error("gemm_bf16: bad b_period"); return NSD_E_INVALID; }
+    if (g.B2 && (!g.b_kmajor || g.n_split <= 0 || g.n_split >= g.N || g.n_split % 256 || g.ldb2 % 8 || (g.N - g.n_split) % 8)) {
+        nsd_set_error("gemm_bf16: a second B source needs a k-major B and 0 < n_split < N, n_split a multiple of 256");
+        return NSD_E_INVALID;
+    }
     if (g.add && (g.epi != GEMM_EPI_F32 || splits != 1)) { nsd_set_error("gemm_bf16: addend needs the fp32 epilogue without split-K"); return NSD_E_INVALID; }
     GemmArgs a = g;
     a.splits = splits;

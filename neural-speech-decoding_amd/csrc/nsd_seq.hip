@@ -312,18 +312,34 @@ int backward(Ctx &c, const RngArgs &rng, float *grads) {
             g.C = parts; g.M = G; g.K = R; g.epi = GEMM_EPI_F32;
             // recurrent weights: operand h_{t-1} of the direction: one time step = 32 rows away inside the batch tile's block of
             // T * 32 rows (tile-major rows); the step before the first of a tile is zero
-            g.B = at<bf16_t>(c.ws, c.w.hs[l]) + (long)d * H; g.ldb = DH; g.N = H; g.ldc = H;
+            g.B = at<bf16_t>(c.ws, c.w.hs[l]) + (long)d * H; g.ldb = DH;
             g.b_shift = d == 0 ? -32 : 32; g.b_period = (long)s.T * 32;
-            g.splits = split_count(G, H, R);
-            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
-            hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * H + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, H, H,
-                               grads + c.pl.w_hh[l][d]);
-            // input weights
-            g.B = in; g.ldb = Kin; g.N = Kin; g.ldc = Kin; g.b_shift = 0; g.b_period = 0;
-            g.splits = split_count(G, Kin, R);
-            if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
-            hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * I + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, Kin, I,
-                               grads + c.pl.w_ih[l][d]);
+            if (H % 256 == 0 && Kin >= 256 && (G / 256) * ((H + Kin) / 256) <= 16) {
+                // ONE pass over da for both gradients: columns [0, H) meet h_{t-1}, columns [H, H + Kin) the layer's input (da does not
+                // fit the Infinity Cache: as two launches it is read from HBM twice).  Measured: cfg3's layer 1 (1024 x 512, 8 tiles
+                // x 32 slices) 2 x 190 -> 305 us; cfg5's (2048 x 1536: 48 tiles, 5 slices fit the partial-sum buffer) 3.6 -> 4.0 ms,
+                // so only where the fused problem still has few tiles and many slices
+                g.B2 = in; g.ldb2 = Kin; g.b2_shift = 0; g.n_split = H;
+                g.N = H + Kin; g.ldc = H + Kin;
+                g.splits = split_count(G, H + Kin, R);
+                if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+                hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * H + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, H + Kin, H,
+                                   grads + c.pl.w_hh[l][d]);
+                hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * I + 255) / 256)), dim3(256), 0, c.st, parts + H, g.splits, H, H + Kin, I,
+                                   grads + c.pl.w_ih[l][d]);
+            } else {
+                g.N = H; g.ldc = H;
+                g.splits = split_count(G, H, R);
+                if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+                hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * H + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, H, H,
+                                   grads + c.pl.w_hh[l][d]);
+                // input weights
+                g.B = in; g.ldb = Kin; g.N = Kin; g.ldc = Kin; g.b_shift = 0; g.b_period = 0;
+                g.splits = split_count(G, Kin, R);
+                if (const int rc = nsd_gemm_bf16_launch(g, c.st)) return rc;
+                hipLaunchKernelGGL(seq_reduce_dw_kernel, dim3((unsigned)((4L * H * I + 255) / 256)), dim3(256), 0, c.st, parts, g.splits, H, Kin, I,
+                                   grads + c.pl.w_ih[l][d]);
+            }
             hipLaunchKernelGGL(seq_reduce_db_kernel, dim3((G + 255) / 256), dim3(256), 0, c.st, dbp + (long)d * s.groups * G, s.groups, H,
                                grads + c.pl.b_ih[l][d], grads + c.pl.b_hh[l][d]);
             NSD_CHECK_LAUNCH("seq weight gradients");
