@@ -124,6 +124,22 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[nt][j] = 0.f;
     if (tid == 0) s_abort = 0;
+    // The exchange ring validates itself (design: nsd_scan2.hip, forward): |h| < 1, so bit 14 of every bf16 h is free and carries the
+    // TAG of the step that wrote it ((s >> 1) & 1); a consumer loads its pieces until all tags are the expected ones -- no drain, no
+    // flag, no poll.  Both slots start with the tag their first writer will not use, drained before the start barrier.
+    constexpr unsigned TAGBITS = 0x40004000u;
+    constexpr long XB0 = (long)MG * H;
+    {
+        const long slot_stride = (long)a.D * a.groups_total * XB0;
+        bf16_t *r0 = a.xch + ((long)dir * a.groups_total + a.group0 + me.group) * XB0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const long off = ring_h_off(gt, nt, NT, col, hh);
+            st_sc1_u64(r0 + off, ((unsigned long long)TAGBITS << 32) | TAGBITS);
+            st_sc1_u64(r0 + slot_stride + off, ((unsigned long long)TAGBITS << 32) | TAGBITS);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     unsigned *gflags = a.flags + (long)(dir * a.groups + me.group) * GROUP_WORDS;
@@ -182,25 +198,32 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
         f32x16 acc[NT];
         if (s > 0) {
             bf16_t *Bt = Bt2[s & 1];
-            if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
+            // gather h_{t-1} of the whole tile (all H units) from the exchange ring: the block of a batch tile is laid out [gate tile
+            // = 4p + wave][nt][trial][8 units] -- every producer wave writes whole 128-byte lines with one store instruction, and a
+            // consumer's 16-byte pieces are linear in the block (piece e = (unit group) * MG + trial).  The pieces are loaded until
+            // every value carries the tag of step s-1 (bounded; a group that cannot complete reports and leaves).
+            const nsd_rsrc rh = make_rsrc(ring_of(s - 1), (unsigned)(XB * 2));
+            constexpr int PIECES = MG * (H / 8) / 256;
+            const unsigned want = (((s - 1) >> 1) & 1) ? 0x4000u : 0u;
+            u32x4 pv[PIECES];
+            bool ok = false;
+            for (unsigned spins = 0; spins < SPIN_LIMIT && !ok; ++spins) {
+                bool mine = true;
+#pragma unroll
+                for (int i = 0; i < PIECES; ++i) pv[i] = ld_sc1_b128(rh, (unsigned)((tid + 256 * i) * 16));
+#pragma unroll
+                for (int i = 0; i < PIECES; ++i) mine = mine && ((pv[i][0] & 0x4000u) == want) && ((pv[i][2] & 0x4000u) == want);   // (two producer lanes per piece)
+                ok = __all(mine) || (NSD_SCAN_ABLATE & 1) != 0;
+                if (!ok) __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok && lane == 0) {
                 s_abort = 1;                                    // (the wave still walks to the barrier below: the exit is uniform)
                 report_timeout(a.status, ST_FWD_TIMEOUT);
             }
-            // gather h_{t-1} of the whole tile (all H units) from the exchange ring: the block of a batch tile is laid out [gate tile
-            // = 4p + wave][nt][trial][8 units] -- every producer wave writes whole 128-byte lines with one store instruction, and a
-            // consumer's 16-byte pieces are linear in the block (piece e = (unit group) * MG + trial).  Exchanging through hs[t]
-            // itself (8-byte pieces of a line shared by 8 producer waves) makes every gather load wait for lines that are merged
-            // from partial writes beyond the L2.
-            const nsd_rsrc rh = make_rsrc(ring_of(s - 1), (unsigned)(XB * 2));
-            constexpr int PIECES = MG * (H / 8) / 256;
-            u32x4 pv[PIECES];
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i)
-                pv[i] = (NSD_SCAN_ABLATE & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u} : ld_sc1_b128(rh, (unsigned)((tid + 256 * i) * 16));
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
                 const int e = tid + 256 * i, pc = e / MG, row = e % MG;
-                *reinterpret_cast<u32x4 *>(Bt + row * LDB + 8 * pc) = pv[i];
+                *reinterpret_cast<u32x4 *>(Bt + row * LDB + 8 * pc) = u32x4{pv[i][0] & ~TAGBITS, pv[i][1] & ~TAGBITS, pv[i][2] & ~TAGBITS, pv[i][3] & ~TAGBITS};
             }
             __syncthreads();
             if (s_abort) break;                                 // uniform: every thread reads the same word after the barrier
@@ -255,11 +278,10 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
             for (int nt = 0; nt < NT; ++nt) {
                 hw[nt][0] = pack_bf16x2(hv[nt][0], hv[nt][1]);
                 hw[nt][1] = pack_bf16x2(hv[nt][2], hv[nt][3]);
-                st_xchg_u64(same_l2, slot + ring_h_off(gt, nt, NT, col, hh), ((unsigned long long)hw[nt][1] << 32) | hw[nt][0]);
+                const unsigned tag = ((s >> 1) & 1) ? TAGBITS : 0u;
+                st_xchg_u64(same_l2, slot + ring_h_off(gt, nt, NT, col, hh), ((unsigned long long)(hw[nt][1] | tag) << 32) | (hw[nt][0] | tag));
             }
         }
-        if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
         // ---- everything else of the step leaves behind the flag (nobody waits for it inside this launch)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {

@@ -21,7 +21,7 @@ constexpr int ST2_FWD_TIMEOUT = 1, ST2_BWD_TIMEOUT = 2;
 template <int H, int NT>
 __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     constexpr int KS = H / 16, P = H / 32, MG = 32 * NT, LDB = H + 8;
-    constexpr int PIECES = MG * (H / 8) / 256;
+    constexpr int PIECES = MG * (H / 4) / 256;                  // 16-byte granules of the exchange ring per thread (one per producer lane)
     // [buffer s & 1][h0_{s-1} | in1_{s-1} (multiplied h0) | h1_{s-2}][trial][unit]: one barrier per step (see nsd_scan.hip)
     __shared__ __align__(16) bf16_t tiles[2][3][MG * LDB];
     __shared__ int s_abort;
@@ -59,6 +59,25 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         for (int j = 0; j < 4; ++j) { c0[nt][j] = 0.f; c1[nt][j] = 0.f; }
     if (tid == 0) s_abort = 0;
     for (int i = tid; i < 2 * 3 * MG * LDB / 8; i += 256) reinterpret_cast<u32x4 *>(&tiles[0][0][0])[i] = u32x4{0u, 0u, 0u, 0u};
+    // ---- the exchange ring of the group (two slots, step parity): ONE 16-byte granule per producer lane and step,
+    //   [gate tile = 4p + wave][nt][trial][half] x {h0 of the lane's 4 units | h1 of the same units},
+    // and the granule carries its own validity: |h| < 1, so bit 14 of every bf16 h (set only for |x| >= 2) is free -- in the h1 half it
+    // holds the TAG of the step that wrote the granule ((s >> 1) & 1: it flips every time a slot is rewritten), in the h0 half the
+    // keep / drop bit of the unit's dropout multiplier (the multiplied copy layer 1 reads is rebuilt by the consumer, bit-identically).
+    // A consumer simply loads its granules until every tag is the expected one: one L2 round trip behind the slowest producer's
+    // store, where "stores -> drain -> flag -> poll -> loads" was three (round 2: ~3 800 of a step's ~9 900 cycles were protocol).
+    // A lane's 16 bytes are written by one store instruction and read by one load: they arrive together.  The slots start with the
+    // tag their first writer will NOT use (the workspace may hold a previous launch's granules), drained before the start barrier.
+    constexpr unsigned TAGBITS = 0x40004000u;
+    constexpr long XG = (long)MG * H * 2;                       // bf16 elements of one slot: MG * H / 4 granules of 8
+    bf16_t *const ring0 = a.xch + (long)(a.group0 + me.group) * XG, *const ring1 = ring0 + (long)a.groups_total * XG;
+    const long gran_off = (((long)(4 * me.p + wave) * NT) * 32 + col) * 16 + 8 * hh;       // nt = 0; + 512 per nt
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        st_sc1_b128(make_rsrc(ring0, (unsigned)(XG * 2)), (unsigned)((gran_off + 512 * nt) * 2), u32x4{0u, 0u, TAGBITS, TAGBITS});
+        st_sc1_b128(make_rsrc(ring1, (unsigned)(XG * 2)), (unsigned)((gran_off + 512 * nt) * 2), u32x4{0u, 0u, TAGBITS, TAGBITS});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     unsigned *gflags = a.flags + (long)me.group * GROUP_WORDS;
@@ -101,35 +120,42 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         for (int nt = 0; nt < NT; ++nt) drop_mult4(a.rng, masked && a.rng.on && do0, 0, a.B, T, b0 + 32 * nt + col, t0, H, u0, mult[nt]);
         const bf16_t *TA = tiles[s & 1][0], *TB = tiles[s & 1][masked ? 1 : 0], *TC = tiles[s & 1][2];
         if (s >= 1) {
-            if (!(NSD_SCAN_ABLATE & 1) && !wait_group<4 * P>(gflags, (unsigned)s, lane) && lane == 0) {
+            // the granules of step s-1, loaded until every tag says so (bounded: a group that cannot complete reports and leaves)
+            const nsd_rsrc rr = make_rsrc(((s - 1) & 1) ? ring1 : ring0, (unsigned)(XG * 2));
+            const unsigned want = (((s - 1) >> 1) & 1) ? 0x4000u : 0u;
+            u32x4 pg[PIECES];
+            bool ok = false;
+            for (unsigned spins = 0; spins < SPIN_LIMIT && !ok; ++spins) {
+                bool mine = true;
+#pragma unroll
+                for (int i = 0; i < PIECES; ++i) pg[i] = ld_sc1_b128(rr, (unsigned)((tid + 256 * i) * 16));
+#pragma unroll
+                for (int i = 0; i < PIECES; ++i) mine = mine && ((pg[i][2] & 0x4000u) == want);
+                ok = __all(mine) || (NSD_SCAN_ABLATE & 1) != 0;
+                if (!ok) __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok && lane == 0) {
                 s_abort = 1;
                 report_timeout(a.status, ST2_FWD_TIMEOUT);
             }
-            stp.mark(0);
-            // the exchange ring: per tensor and step parity one block of MG*H bf16 per batch tile, laid out [gate tile = 4p+wave]
-            // [tile nt][trial][8 units]: every producer wave writes its 512-byte blocks as WHOLE 128-byte lines with one store
-            // instruction, and a consumer's 16-byte pieces are linear in the block (piece e = (unit group)*MG + trial).
-            // (Exchanging through hs[t] itself -- 8-byte pieces of a line shared by 8 producer waves -- made every gather
-            // load wait ~5 000 cycles: partially written lines are merged beyond the L2.)
-            constexpr long XB = (long)MG * H;                   // elements per block
-            const bf16_t *ring = a.xch + ((long)((s - 1) & 1) * a.groups_total + a.group0 + me.group) * 3 * XB;
-            const nsd_rsrc rr = make_rsrc(ring, (unsigned)(3 * XB * 2));
-            u32x4 pa[PIECES], pb[PIECES], pc[PIECES];
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) {
-                const unsigned off = (unsigned)((tid + 256 * i) * 16);
-                pa[i] = ld_sc1_b128(rr, off);
-                pb[i] = masked ? ld_sc1_b128(rr, (unsigned)(XB * 2) + off) : pa[i];
-                pc[i] = s >= 2 ? ld_sc1_b128(rr, (unsigned)(2 * XB * 2) + off) : u32x4{0u, 0u, 0u, 0u};
-            }
-            stp.mark<true>(6);                                   // (diagnostic build) the gather loads have arrived
+            stp.mark<true>(6);                                   // (diagnostic build) the granules have arrived
             bf16_t *WA = tiles[s & 1][0], *WB = tiles[s & 1][1], *WC = tiles[s & 1][2];
+            const float keep = a.rng.keep_lstm;
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
-                const int e = tid + 256 * i, pc8 = e / MG, row = e % MG;          // piece e of the block: unit group pc8, trial row
-                *reinterpret_cast<u32x4 *>(WA + row * LDB + 8 * pc8) = pa[i];
-                if (masked) *reinterpret_cast<u32x4 *>(WB + row * LDB + 8 * pc8) = pb[i];
-                if (s >= 2) *reinterpret_cast<u32x4 *>(WC + row * LDB + 8 * pc8) = pc[i];
+                const int e = tid + 256 * i, ghh = e & 1, row = ((e >> 6) % NT) * 32 + ((e >> 1) & 31), ggt = (e >> 6) / NT;   // granule e: [gate tile][nt][trial][half]
+                bf16_t *dst = nullptr;
+                const int at = row * LDB + 8 * ggt + 4 * ghh;
+                const unsigned w0 = pg[i][0], w1 = pg[i][1];
+                *reinterpret_cast<u32x2 *>(WA + at) = u32x2{w0 & ~TAGBITS, w1 & ~TAGBITS};
+                if (masked) {
+                    // the multiplied copy, exactly as the producer formed it: bf16(h0) * (keep | 0), rounded to bf16
+                    const unsigned c0 = w0 & ~TAGBITS, c1 = w1 & ~TAGBITS;
+                    *reinterpret_cast<u32x2 *>(WB + at) = u32x2{pack_bf16x2(bf16_lo(c0) * ((w0 & 0x4000u) ? keep : 0.f), bf16_hi(c0) * ((w0 & 0x40000000u) ? keep : 0.f)),
+                                                                pack_bf16x2(bf16_lo(c1) * ((w1 & 0x4000u) ? keep : 0.f), bf16_hi(c1) * ((w1 & 0x40000000u) ? keep : 0.f))};
+                }
+                *reinterpret_cast<u32x2 *>(WC + at) = u32x2{pg[i][2] & ~TAGBITS, pg[i][3] & ~TAGBITS};
+                (void)dst;
             }
             stp.mark(7);                                         // ds_writes done
             __syncthreads();
@@ -186,22 +212,21 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             lw0[nt][1] = pack_bf16x2(bf16_lo(hw0[nt][1]) * mult[nt][2], bf16_hi(hw0[nt][1]) * mult[nt][3]);
         }
         stp.mark(3);
-        // ---- publish h0_t0, its multiplied copy, h1_t1 into the ring slot of this step
+        // ---- publish h0_t0 (+ the keep / drop bits of its multiplied copy) and h1_t1 as ONE tagged granule per lane; no drain, no flag
         {
-            constexpr long XB = (long)MG * H;
-            bf16_t *ring = a.xch + ((long)(s & 1) * a.groups_total + a.group0 + me.group) * 3 * XB;
+            const nsd_rsrc rw = make_rsrc((s & 1) ? ring1 : ring0, (unsigned)(XG * 2));
+            const unsigned tag = ((s >> 1) & 1) ? TAGBITS : 0u;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const long off = ((long)(gt * NT + nt) * 32 + col) * 8 + 4 * hh;       // [gate tile][nt][trial][8 units]
-                if (do0) {
-                    st_xchg_u64(same_l2, ring + off, ((unsigned long long)hw0[nt][1] << 32) | hw0[nt][0]);
-                    if (masked) st_xchg_u64(same_l2, ring + XB + off, ((unsigned long long)lw0[nt][1] << 32) | lw0[nt][0]);
+                unsigned k0 = 0u, k1 = 0u;
+                if (masked) {
+                    k0 = (mult[nt][0] != 0.f ? 0x4000u : 0u) | (mult[nt][1] != 0.f ? 0x40000000u : 0u);
+                    k1 = (mult[nt][2] != 0.f ? 0x4000u : 0u) | (mult[nt][3] != 0.f ? 0x40000000u : 0u);
                 }
-                if (do1) st_xchg_u64(same_l2, ring + 2 * XB + off, ((unsigned long long)hw1[nt][1] << 32) | hw1[nt][0]);
+                const u32x4 gr = {do0 ? (hw0[nt][0] | k0) : 0u, do0 ? (hw0[nt][1] | k1) : 0u, (do1 ? hw1[nt][0] : 0u) | tag, (do1 ? hw1[nt][1] : 0u) | tag};
+                st_ring_b128(same_l2, rw, (unsigned)((gran_off + 512 * nt) * 2), gr);
             }
         }
-        if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
         stp.mark(4);
         // ---- row-major copies (the head reads hs1; the weight-gradient GEMMs read hs0 / lk0 / hs1) and the saves for the
         // backward pass leave behind the flag: nobody waits for them inside this launch
