@@ -33,6 +33,21 @@ __device__ __forceinline__ unsigned pack_bf16x2(const float a, const float b) {
     v[0] = (__bf16)a; v[1] = (__bf16)b;
     return __builtin_bit_cast(unsigned, v);
 }
+// lo += low bf16 of w, hi += high bf16 of w: one v_dot2c_f32_bf16 each (w . (1, 0) and w . (0, 1)) instead of unpack + add
+__device__ __forceinline__ void acc_bf16x2(float &lo, float &hi, const unsigned w) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#ifdef NSD_NO_DOT2
+    lo += __uint_as_float(w << 16); hi += __uint_as_float(w & 0xffff0000u);
+#else
+    // (the selector (1, 0) must come from a register: hipcc encodes 0x00003f80 as the inline constant 1.0, which the instruction reads
+    // as the fp32 pattern 0x3f800000 = (0, 1) -- both sums then take the high half; tools/micro/dot2_check.hip)
+    unsigned sel_lo = 0x00003f80u;
+    asm("" : "+s"(sel_lo));
+    const bf16x2 v = __builtin_bit_cast(bf16x2, w);
+    lo = __builtin_amdgcn_fdot2_f32_bf16(v, __builtin_bit_cast(bf16x2, sel_lo), lo, false);
+    hi = __builtin_amdgcn_fdot2_f32_bf16(v, __builtin_bit_cast(bf16x2, 0x3f800000u), hi, false);
+#endif
+}
 __device__ __forceinline__ float bf16_lo(const unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(const unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 

@@ -17,6 +17,12 @@
 namespace {
 
 constexpr int ST2_FWD_TIMEOUT = 1, ST2_BWD_TIMEOUT = 2;
+#ifndef NSD_LOOK_POS
+#define NSD_LOOK_POS 1
+#endif
+#ifndef NSD_LOOK_DELAY
+#define NSD_LOOK_DELAY 0
+#endif
 
 template <int H, int NT>
 __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
@@ -41,6 +47,18 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             w1[ks] = *reinterpret_cast<const bf16x8 *>(a.wf1 + ro + 16 * ks);
         }
     }
+    // Dropout between the layers: layer 1 reads h0 (x) m * keep.  The consumers of the exchange rebuild h0 (x) m with two bit
+    // operations from the keep / drop bits that travel in the granules, and the scale sits in the weights: W_ih1 * keep, rounded to
+    // bf16 once here (the row-major copy for the weight-gradient GEMM stays bf16(h0 * m * keep), as the producer forms it).
+    if (a.lk0 != nullptr && a.rng.on) {
+        const float keep = a.rng.keep_lstm;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wx[ks][e] = (bf16_t)((float)wx[ks][e] * keep);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(wx[ks]));        // (the scaled rows live in AGPRs like the loaded ones: no copy per MFMA)
     float bias1[16], bias0[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { bias1[r] = a.bsum1[32 * gt + mfma32_row(r, lane)]; bias0[r] = a.bsum0[32 * gt + mfma32_row(r, lane)]; }
@@ -110,6 +128,9 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) xf[nt][k] = wx0[0];        // (defined values in the unused k-steps)
     load_x(0);
+    u32x4 pg[PIECES];                                           // the granules a thread gathers (requested a step ahead, see "publish")
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) pg[i] = u32x4{0u, 0u, 0u, 0u};
     Stamps stp;
     stp.start();
     for (int s = 0; s <= T; ++s) {
@@ -123,16 +144,18 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             // the granules of step s-1, loaded until every tag says so (bounded: a group that cannot complete reports and leaves)
             const nsd_rsrc rr = make_rsrc(((s - 1) & 1) ? ring1 : ring0, (unsigned)(XG * 2));
             const unsigned want = (((s - 1) >> 1) & 1) ? 0x4000u : 0u;
-            u32x4 pg[PIECES];
+            // (the first look was requested right behind the publishing stores of step s-1, ahead of that step's saves)
             bool ok = false;
-            for (unsigned spins = 0; spins < SPIN_LIMIT && !ok; ++spins) {
+            for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
                 bool mine = true;
-#pragma unroll
-                for (int i = 0; i < PIECES; ++i) pg[i] = ld_sc1_b128(rr, (unsigned)((tid + 256 * i) * 16));
 #pragma unroll
                 for (int i = 0; i < PIECES; ++i) mine = mine && ((pg[i][2] & 0x4000u) == want);
                 ok = __all(mine) || (NSD_SCAN_ABLATE & 1) != 0;
-                if (!ok) __builtin_amdgcn_s_sleep(1);
+                if (ok) break;
+                if (NSD_SCAN_STAMPS) stp.acc[0] += 1000;             // (diagnostic build: looks that failed, x 1000)
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int i = 0; i < PIECES; ++i) pg[i] = ld_sc1_b128(rr, (unsigned)((tid + 256 * i) * 16));
             }
             if (!ok && lane == 0) {
                 s_abort = 1;
@@ -140,7 +163,6 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             }
             stp.mark<true>(6);                                   // (diagnostic build) the granules have arrived
             bf16_t *WA = tiles[s & 1][0], *WB = tiles[s & 1][1], *WC = tiles[s & 1][2];
-            const float keep = a.rng.keep_lstm;
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
                 const int e = tid + 256 * i, ghh = e & 1, row = ((e >> 6) % NT) * 32 + ((e >> 1) & 31), ggt = (e >> 6) / NT;   // granule e: [gate tile][nt][trial][half]
@@ -149,10 +171,8 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
                 const unsigned w0 = pg[i][0], w1 = pg[i][1];
                 *reinterpret_cast<u32x2 *>(WA + at) = u32x2{w0 & ~TAGBITS, w1 & ~TAGBITS};
                 if (masked) {
-                    // the multiplied copy, exactly as the producer formed it: bf16(h0) * (keep | 0), rounded to bf16
-                    const unsigned c0 = w0 & ~TAGBITS, c1 = w1 & ~TAGBITS;
-                    *reinterpret_cast<u32x2 *>(WB + at) = u32x2{pack_bf16x2(bf16_lo(c0) * ((w0 & 0x4000u) ? keep : 0.f), bf16_hi(c0) * ((w0 & 0x40000000u) ? keep : 0.f)),
-                                                                pack_bf16x2(bf16_lo(c1) * ((w1 & 0x4000u) ? keep : 0.f), bf16_hi(c1) * ((w1 & 0x40000000u) ? keep : 0.f))};
+                    // h0 (x) m: bit 14 / 30 -> a 16-bit mask per value (the scale keep is in the weights, see the prologue)
+                    *reinterpret_cast<u32x2 *>(WB + at) = u32x2{w0 & ~TAGBITS & (((w0 >> 14) & 0x00010001u) * 0xffffu), w1 & ~TAGBITS & (((w1 >> 14) & 0x00010001u) * 0xffffu)};
                 }
                 *reinterpret_cast<u32x2 *>(WC + at) = u32x2{pg[i][2] & ~TAGBITS, pg[i][3] & ~TAGBITS};
                 (void)dst;
@@ -227,9 +247,23 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
                 st_ring_b128(same_l2, rw, (unsigned)((gran_off + 512 * nt) * 2), gr);
             }
         }
+        // ... and the first look at the group's granules of this step.  Vector memory completes in issue order, so the look goes in
+        // FRONT of most of the step's saves; the other members publish at about the same time and a store needs ~300 cycles to be
+        // visible in the L2, so a few of the saves go first (LOOK_POS) -- a look that comes too early costs a second round trip.
+        auto first_look = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            if (NSD_LOOK_DELAY) __builtin_amdgcn_s_sleep(NSD_LOOK_DELAY);
+            if (s < T) {
+                const nsd_rsrc rn = make_rsrc((s & 1) ? ring1 : ring0, (unsigned)(XG * 2));
+#pragma unroll
+                for (int i = 0; i < PIECES; ++i) pg[i] = ld_sc1_b128(rn, (unsigned)((tid + 256 * i) * 16));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (NSD_LOOK_POS == 0 || !train) first_look();
         stp.mark(4);
         // ---- row-major copies (the head reads hs1; the weight-gradient GEMMs read hs0 / lk0 / hs1) and the saves for the
-        // backward pass leave behind the flag: nobody waits for them inside this launch
+        // backward pass: nobody waits for them inside this launch
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int b = b0 + 32 * nt + col;
@@ -241,17 +275,20 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             if (do1) st_stream<u32x2>(a.hs1 + seq_row(t1, b, T) * H + u0, u32x2{hw1[nt][0], hw1[nt][1]});
         }
         if (train) {
+            if (NSD_LOOK_POS == 1) first_look();
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (do0) {
                     const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t0, wave);
                     st_stream<u32x2>(a.cs0 + saved_cs(blk, lane), u32x2{pack_bf16x2(c0[nt][0], c0[nt][1]), pack_bf16x2(c0[nt][2], c0[nt][3])});
                     bf16_t *gd = a.ga0 + saved_ga(blk, 0, lane);
-                    st_stream<u32x4>(gd, u32x4{pack_bf16x2(g0[nt][0][0], g0[nt][0][1]), pack_bf16x2(g0[nt][0][2], g0[nt][0][3]),
-                                                pack_bf16x2(g0[nt][1][0], g0[nt][1][1]), pack_bf16x2(g0[nt][1][2], g0[nt][1][3])});
-                    st_stream<u32x4>(gd + 512, u32x4{pack_bf16x2(g0[nt][2][0], g0[nt][2][1]), pack_bf16x2(g0[nt][2][2], g0[nt][2][3]),
-                                                      pack_bf16x2(g0[nt][3][0], g0[nt][3][1]), pack_bf16x2(g0[nt][3][2], g0[nt][3][3])});
+                    // (sign of the saved i = the unit's output survived the dropout between the layers: saved_keep_bits)
+                    st_stream<u32x4>(gd, u32x4{pack_bf16x2(g0[nt][0][0], g0[nt][0][1]) | (mult[nt][0] != 0.f ? 0x8000u : 0u), pack_bf16x2(g0[nt][0][2], g0[nt][0][3]),
+                                                pack_bf16x2(g0[nt][1][0], g0[nt][1][1]) | (mult[nt][1] != 0.f ? 0x8000u : 0u), pack_bf16x2(g0[nt][1][2], g0[nt][1][3])});
+                    st_stream<u32x4>(gd + 512, u32x4{pack_bf16x2(g0[nt][2][0], g0[nt][2][1]) | (mult[nt][2] != 0.f ? 0x8000u : 0u), pack_bf16x2(g0[nt][2][2], g0[nt][2][3]),
+                                                      pack_bf16x2(g0[nt][3][0], g0[nt][3][1]) | (mult[nt][3] != 0.f ? 0x8000u : 0u), pack_bf16x2(g0[nt][3][2], g0[nt][3][3])});
                 }
+                if (NSD_LOOK_POS == 2 && nt == NT - 1) first_look();
                 if (do1) {
                     const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t1, wave);
                     st_stream<u32x2>(a.cs1 + saved_cs(blk, lane), u32x2{pack_bf16x2(c1[nt][0], c1[nt][1]), pack_bf16x2(c1[nt][2], c1[nt][3])});
@@ -262,6 +299,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
                                                       pack_bf16x2(g1[nt][3][0], g1[nt][3][1]), pack_bf16x2(g1[nt][3][2], g1[nt][3][3])});
                 }
             }
+            if (NSD_LOOK_POS == 3) first_look();
         }
         stp.mark(5);
     }
@@ -365,44 +403,54 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
         u32x2 cq1[NT], cp1[NT], cq0[NT], cp0[NT];
         float al[NT], ds[NT];
     };
+    // (inside the step loop the requests are unconditional -- clamped addresses, values of an inactive cell are never used and the
+    // "previous c" of t = 0 is zeroed by a select: the compiler's vmcnt for the consume-counter load issued just before them is then
+    // exact.  With conditional requests it assumes the shortest path and the look waits for most of these HBM reads.)
+    // (addresses: a wave-uniform 64-bit base per step -- scalar arithmetic, SGPR base operand -- plus a 32-bit lane offset that never
+    // changes; formed per lane in 64 bits they were ~120 VALU instructions of a step that is bound by instruction issue)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     auto load_saved = [&](const int sx, Saved &v) {
-        const bool d1 = sx < T, d0 = sx >= 1;
-        const int x1 = T - 1 - sx, x0 = T - sx;
+        const int x1 = T - 1 - sx > 0 ? T - 1 - sx : 0, x0 = T - sx < T ? T - sx : T - 1;     // (sx = T: layer 1 is idle; sx = 0: layer 0 is)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int b = b0 + 32 * nt + col;
-            if (d1) {
-                const long row = seq_row(x1, b, T);
-                const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x1, wave);
-                const bf16_t *gs = a.ga1 + saved_ga(blk, 0, lane);
-                v.q1[nt][0] = ld_stream<u32x4>(gs); v.q1[nt][1] = ld_stream<u32x4>(gs + 512);
-                v.cq1[nt] = ld_stream<u32x2>(a.cs1 + saved_cs(blk, lane));
-                v.cp1[nt] = x1 == 0 ? u32x2{0u, 0u} : ld_stream<u32x2>(a.cs1 + saved_cs(blk - 4, lane));   // (step x1 - 1: 4 blocks back)
-                v.al[nt] = ld_stream<float>(a.alpha + row); v.ds[nt] = ld_stream<float>(a.dscore + row);
-            } else {
-                v.q1[nt][0] = u32x4{0u, 0u, 0u, 0u}; v.q1[nt][1] = u32x4{0u, 0u, 0u, 0u}; v.cq1[nt] = u32x2{0u, 0u}; v.cp1[nt] = u32x2{0u, 0u};
-                v.al[nt] = 0.f; v.ds[nt] = 0.f;
+            {
+                const long row_u = (((long)(b0 >> 5) + nt) * T + x1) * 32;
+                const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x1, wave_s);
+                const bf16_t *gs = a.ga1 + blk * 1024, *cs = a.cs1 + blk * 256, *cp = a.cs1 + (x1 == 0 ? blk : blk - 4) * 256;   // (step x1 - 1: 4 blocks back)
+                v.q1[nt][0] = ld_stream<u32x4>(gs + lane * 8); v.q1[nt][1] = ld_stream<u32x4>(gs + 512 + lane * 8);
+                v.cq1[nt] = ld_stream<u32x2>(cs + lane * 4);
+                v.cp1[nt] = ld_stream<u32x2>(cp + lane * 4);
+                v.al[nt] = ld_stream<float>(a.alpha + row_u + col); v.ds[nt] = ld_stream<float>(a.dscore + row_u + col);
             }
-            if (d0) {
-                const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x0, wave);
-                const bf16_t *gs = a.ga0 + saved_ga(blk, 0, lane);
-                v.q0[nt][0] = ld_stream<u32x4>(gs); v.q0[nt][1] = ld_stream<u32x4>(gs + 512);
-                v.cq0[nt] = ld_stream<u32x2>(a.cs0 + saved_cs(blk, lane));
-                v.cp0[nt] = x0 == 0 ? u32x2{0u, 0u} : ld_stream<u32x2>(a.cs0 + saved_cs(blk - 4, lane));
-            } else {
-                v.q0[nt][0] = u32x4{0u, 0u, 0u, 0u}; v.q0[nt][1] = u32x4{0u, 0u, 0u, 0u}; v.cq0[nt] = u32x2{0u, 0u}; v.cp0[nt] = u32x2{0u, 0u};
+            {
+                const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x0, wave_s);
+                const bf16_t *gs = a.ga0 + blk * 1024, *cs = a.cs0 + blk * 256, *cp = a.cs0 + (x0 == 0 ? blk : blk - 4) * 256;
+                v.q0[nt][0] = ld_stream<u32x4>(gs + lane * 8); v.q0[nt][1] = ld_stream<u32x4>(gs + 512 + lane * 8);
+                v.cq0[nt] = ld_stream<u32x2>(cs + lane * 4);
+                v.cp0[nt] = ld_stream<u32x2>(cp + lane * 4);
             }
+        }
+    };
+    // c_{t-1} of t = 0 is the zero state (applied where the set is used)
+    auto fix_saved = [&](const int sx, Saved &v) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (T - 1 - sx <= 0) v.cp1[nt] = u32x2{0u, 0u};
+            if (T - sx <= 0) v.cp0[nt] = u32x2{0u, 0u};
         }
     };
     Saved sv;
     load_saved(0, sv);
+    const float keep0 = a.rng.on ? a.rng.keep_lstm : 1.f;
     Stamps stp;
     stp.start();
+    unsigned long long pass_acc[6] = {0, 0, 0, 0, 0, 0}, pass_last = 0;
     for (int s = 0; s <= T; ++s) {
         const bool do1 = s < T, do0 = s >= 1;
         const int t1 = T - 1 - s, t0 = T - s;
         // ---- ahead of the exchange: everything of the two cells that does not need dh
         CellFac f1[NT], f0[NT];
+        fix_saved(s, sv);
         float dup1[NT][4], m0[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -410,7 +458,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             cell_factors(sv.q0[nt][0], sv.q0[nt][1], sv.cq0[nt], sv.cp0[nt], f0[nt]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) dup1[nt][j] = do1 ? fmaf(sv.al[nt], dpl[nt][j], sv.ds[nt] * aw[j]) : 0.f;
-            drop_mult4(a.rng, a.rng.on != 0 && do0, 0, a.B, T, b0 + 32 * nt + col, t0, H, u0, m0[nt]);
+            saved_keep_bits(sv.q0[nt][0], sv.q0[nt][1], keep0, m0[nt]);      // layer 0's dropout multipliers at t0
             pin(f1[nt]); pin(f0[nt]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { pin(dup1[nt][j]); pin(m0[nt][j]); }
@@ -442,12 +490,9 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             for (int q = 0; q < P; ++q)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    drec1[nt][0] += bf16_lo(v16[q][nt][0]); drec1[nt][1] += bf16_hi(v16[q][nt][0]);
-                    drec1[nt][2] += bf16_lo(v16[q][nt][1]); drec1[nt][3] += bf16_hi(v16[q][nt][1]);
-                    dinx[nt][0] += bf16_lo(v16[q][nt][2]); dinx[nt][1] += bf16_hi(v16[q][nt][2]);
-                    dinx[nt][2] += bf16_lo(v16[q][nt][3]); dinx[nt][3] += bf16_hi(v16[q][nt][3]);
-                    drec0[nt][0] += bf16_lo(v8[q][nt][0]); drec0[nt][1] += bf16_hi(v8[q][nt][0]);
-                    drec0[nt][2] += bf16_lo(v8[q][nt][1]); drec0[nt][3] += bf16_hi(v8[q][nt][1]);
+                    acc_bf16x2(drec1[nt][0], drec1[nt][1], v16[q][nt][0]); acc_bf16x2(drec1[nt][2], drec1[nt][3], v16[q][nt][1]);
+                    acc_bf16x2(dinx[nt][0], dinx[nt][1], v16[q][nt][2]); acc_bf16x2(dinx[nt][2], dinx[nt][3], v16[q][nt][3]);
+                    acc_bf16x2(drec0[nt][0], drec0[nt][1], v8[q][nt][0]); acc_bf16x2(drec0[nt][2], drec0[nt][3], v8[q][nt][1]);
                 }
             // this wave has taken its partial sums of step s-1 out of the ring: the producers may rewrite the slot
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -478,6 +523,24 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             }
         }
         stp.mark(2);
+        // row-major da for the weight-gradient GEMMs: nobody waits for it inside this launch.  Issued right behind the step barrier,
+        // ~3 000 cycles ahead of the drain that precedes the flag (the registers are free during the MFMA stream)
+        auto store_da_rows = [&]() {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned lane_off = (unsigned)(col * G + 4 * u0);             // (the trial's row inside the tile's 32, the lane's 16 gate columns)
+                if (do1) {
+                    bf16_t *d = a.da1 + (((long)(b0 >> 5) + nt) * T + t1) * 32 * G;
+                    st_stream<u32x4>(d + lane_off, u32x4{dw1[nt][0], dw1[nt][1], dw1[nt][2], dw1[nt][3]});
+                    st_stream<u32x4>(d + lane_off + 8, u32x4{dw1[nt][4], dw1[nt][5], dw1[nt][6], dw1[nt][7]});
+                }
+                if (do0) {
+                    bf16_t *d = a.da0 + (((long)(b0 >> 5) + nt) * T + t0) * 32 * G;
+                    st_stream<u32x4>(d + lane_off, u32x4{dw0[nt][0], dw0[nt][1], dw0[nt][2], dw0[nt][3]});
+                    st_stream<u32x4>(d + lane_off + 8, u32x4{dw0[nt][4], dw0[nt][5], dw0[nt][6], dw0[nt][7]});
+                }
+            }
+        };
         if (s < T) {                                            // (after the last step nobody reads a partial sum)
             const int par = s & 1;
             if (NSD_SCAN_ABLATE & 64) load_saved(s + 1, sv);
@@ -493,77 +556,100 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             stp.mark(3);
             // the consume counters of the group, requested now and looked at before the first ring store of the step
             unsigned ackv = ld_sc1_u32(gacks + (lane < 4 * P ? lane : 0));     // (every lane loads: no exec-masked block for the compare to be pulled into)
+            __builtin_amdgcn_sched_barrier(0);                  // FIRST in the queue: its wait must not include the HBM-bound requests below
+            store_da_rows();
             if (!(NSD_SCAN_ABLATE & (8 | 16 | 32 | 64))) load_saved(s + 1, sv);   // (its factors were taken at the top of the step: the registers are free)
             __builtin_amdgcn_sched_barrier(0);
-            // ---- partial sums of dh for every unit of the group from this workgroup's 128 + 128 columns, one consumer (row tile) at
-            // a time: its three accumulator tiles are converted and sent while the next consumer's MFMAs run
-            if (has_rows) {
+            // ---- partial sums of dh for every unit of the group from this workgroup's 128 + 128 columns: 3 RT passes of KS MFMAs
+            // (consumer row tile r = wave + 4 ri: W_hh1^T da1, W_ih1^T da1, W_hh0^T da0), ONE instruction stream in which the wave's
+            // other work rides in the gaps -- a 32x32x16 MFMA occupies the matrix pipe for 64 cycles and the wave for ~8.  Behind
+            // MFMA k of a pass the wave converts a quarter of the PREVIOUS pass's accumulator and sends it (that pass's last MFMA
+            // left the pipe when this pass's second one was issued); 
+            // No run-time branch inside the stream except the consume-counter look, which sits behind a settle (hipcc copies
+            // asm-MFMA accumulators around branches without knowing they may still be in flight).
+            auto stream = [&](auto same_c) {                    // (one copy per exchange mode: the ring stores' cache bits are immediates)
+                constexpr bool SAME = decltype(same_c)::value;
                 const nsd_rsrc rw = make_rsrc(ring0, (unsigned)Ring::SLOT_BYTES);
-                constexpr int NF = KS * NT, D = 3;
-                auto frag = [&](const int layer, const int i) { return *reinterpret_cast<const bf16x8 *>(&dab[par][layer][i / NT][i % NT][lane * 8]); };
+                constexpr int NF = KS * NT, NPASS = 3 * RT, NTOT = NPASS * NF, D = 3;
+                f32x16 aR1[NT], aX0[NT], aR0[NT];
+                unsigned pk1[NT][4][2];
+                auto frag_of = [&](const int i) {
+                    const int ps = i / NF, kk = i % NF;
+                    return *reinterpret_cast<const bf16x8 *>(&dab[par][ps % 3 == 2 ? 0 : 1][kk / NT][kk % NT][lane * 8]);
+                };
+                auto conv = [&](auto psc, auto qc) {             // quarter q (= consumer wave q's units) of the accumulators of pass ps
+                    constexpr int ps = decltype(psc)::value, q = decltype(qc)::value, m = ps % 3;
+                    const int r = wave + 4 * (ps / 3);
 #pragma unroll
-                for (int ri = 0; ri < RT; ++ri) {
-                    const int r = wave + 4 * ri;
-                    f32x16 aR1[NT], aX0[NT], aR0[NT];
-                    bf16x8 g1[D], g0[D];
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (m == 0) {
+                            pk1[nt][q][0] = pack_bf16x2(aR1[nt][4 * q], aR1[nt][4 * q + 1]); pk1[nt][q][1] = pack_bf16x2(aR1[nt][4 * q + 2], aR1[nt][4 * q + 3]);
+                        } else if constexpr (m == 1) {
+                            const u32x4 o16 = {pk1[nt][q][0], pk1[nt][q][1], pack_bf16x2(aX0[nt][4 * q], aX0[nt][4 * q + 1]), pack_bf16x2(aX0[nt][4 * q + 2], aX0[nt][4 * q + 3])};
+                            st_ring_b128(SAME, rw, Ring::off16(r, me.p, nt, q) + 16u * lane, o16);
+                        } else {
+                            const u32x2 o8 = {pack_bf16x2(aR0[nt][4 * q], aR0[nt][4 * q + 1]), pack_bf16x2(aR0[nt][4 * q + 2], aR0[nt][4 * q + 3])};
+                            st_ring_b64(SAME, rw, Ring::off8(r, me.p, nt, q) + 8u * lane, o8);
+                        }
+                    }
+                };
+                bf16x8 f[D];
 #pragma unroll
-                    for (int i = 0; i < D; ++i) { g1[i] = frag(1, i); g0[i] = frag(0, i); }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < D; ++i) f[i] = frag_of(i);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, NTOT>([&](auto ic) {               // (compile-time indices by construction: a rolled loop would select weights and accumulators at run time)
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ps = i / NF, kk = i % NF, ks = kk / NT, nt = kk % NT, ri = ps / 3, m = ps % 3;
+                    if constexpr (ps == 2 && kk == 0) {
+                        // the first ring store of the step follows: every wave of the group must have taken step s-1 out of the slot
 #pragma unroll
-                    for (int i = 0; i < NF; ++i) {
-                        const int ks = i / NT, nt = i % NT;
-                        if (ks == 0) { mfma_new_a(aR1[nt], wq1[ri][ks], g1[i % D]); mfma_new_a(aX0[nt], wqx[ri][ks], g1[i % D]); mfma_new_a(aR0[nt], wq0[ri][ks], g0[i % D]); }
-                        else { mfma_acc_a(aR1[nt], wq1[ri][ks], g1[i % D]); mfma_acc_a(aX0[nt], wqx[ri][ks], g1[i % D]); mfma_acc_a(aR0[nt], wq0[ri][ks], g0[i % D]); }
-                        if (i + D < NF) { g1[i % D] = frag(1, i + D); g0[i % D] = frag(0, i + D); }
+                        for (int n2 = 0; n2 < NT; ++n2) mfma_settle(aR1[n2], aX0[n2]);
+                        pin(ackv);                                       // the compare stays HERE: at the load it would expose an L2 round trip per step
+                        if (!__all(ackv >= (unsigned)s)) {               // (rare: the counters were read ~1 500 cycles after they were written)
+                            if (!wait_group<4 * P>(gacks, (unsigned)s, lane) && lane == 0) { s_abort = 1; report_timeout(a.status, ST2_BWD_TIMEOUT); }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mfma_settle(aR1[nt], aX0[nt], aR0[nt]);
-                    if (ri == 0) pin(ackv);                              // the compare stays HERE: at the load it would expose an L2 round trip per step
-                    if (ri == 0 && !__all(ackv >= (unsigned)s)) {   // (rare: the counters were read ~2 000 cycles after they were written)
-                        if (!wait_group<4 * P>(gacks, (unsigned)s, lane) && lane == 0) { s_abort = 1; report_timeout(a.status, ST2_BWD_TIMEOUT); }
-                    }
-                    if (ri == RT - 1) stp.mark(4);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const u32x4 o16 = {pack_bf16x2(aR1[nt][4 * q], aR1[nt][4 * q + 1]), pack_bf16x2(aR1[nt][4 * q + 2], aR1[nt][4 * q + 3]),
-                                               pack_bf16x2(aX0[nt][4 * q], aX0[nt][4 * q + 1]), pack_bf16x2(aX0[nt][4 * q + 2], aX0[nt][4 * q + 3])};
-                            const u32x2 o8 = {pack_bf16x2(aR0[nt][4 * q], aR0[nt][4 * q + 1]), pack_bf16x2(aR0[nt][4 * q + 2], aR0[nt][4 * q + 3])};
-                            st_ring_b128(same_l2, rw, Ring::off16(r, me.p, nt, q) + 16u * lane, o16);
-                            st_ring_b64(same_l2, rw, Ring::off8(r, me.p, nt, q) + 8u * lane, o8);
-                        }
+                    if constexpr (m == 0) { if constexpr (ks == 0) mfma_new_a(aR1[nt], wq1[ri][ks], f[i % D]); else mfma_acc_a(aR1[nt], wq1[ri][ks], f[i % D]); }
+                    else if constexpr (m == 1) { if constexpr (ks == 0) mfma_new_a(aX0[nt], wqx[ri][ks], f[i % D]); else mfma_acc_a(aX0[nt], wqx[ri][ks], f[i % D]); }
+                    else { if constexpr (ks == 0) mfma_new_a(aR0[nt], wq0[ri][ks], f[i % D]); else mfma_acc_a(aR0[nt], wq0[ri][ks], f[i % D]); }
+                    if constexpr (i + D < NTOT) f[i % D] = frag_of(i + D);
                     __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                stp.mark(4);
+                    if constexpr (ps >= 1 && kk >= 1 && kk <= 4) {
+                        if constexpr (kk == 1) {
+#pragma unroll
+                            for (int n2 = 0; n2 < NT; ++n2) {
+                                if constexpr ((ps - 1) % 3 == 0) mfma_fence(aR1[n2]); else if constexpr ((ps - 1) % 3 == 1) mfma_fence(aX0[n2]); else mfma_fence(aR0[n2]);
+                            }
+                        }
+                        conv(std::integral_constant<int, ps - 1>{}, std::integral_constant<int, kk - 1>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (NSD_SCAN_STAMPS != 0 && kk == NF - 1) {       // (diagnostic build: cycles of each pass, behind the stamps proper)
+                        const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+                        pass_acc[ps < 6 ? ps : 5] += t_ - pass_last; pass_last = t_;
+                    }
+                    if constexpr (NSD_SCAN_STAMPS != 0 && i == 0) pass_last = __builtin_amdgcn_s_memtime();
+                });
+#pragma unroll
+                for (int n2 = 0; n2 < NT; ++n2) mfma_settle(aR0[n2]);
+                static_for<0, 4>([&](auto qc) { conv(std::integral_constant<int, NPASS - 1>{}, qc); });
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (has_rows) {
+                if (same_l2) stream(std::true_type{}); else stream(std::false_type{});
             }
+            stp.mark(4);
             if (NSD_SCAN_ABLATE & 32) load_saved(s + 1, sv);
             stp.mark(5);
             if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
             stp.mark(6);
         }
-        __builtin_amdgcn_sched_barrier(0);                      // (hipcc otherwise hoists these HBM-bound stores ahead of the ring stores)
-        if ((NSD_SCAN_ABLATE & 16) && s < T) load_saved(s + 1, sv);
-        // ---- row-major da for the weight-gradient GEMMs: behind the flag, nobody waits for it inside this launch
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int rb = b0 + 32 * nt + col;
-            if (do1) {
-                bf16_t *d = a.da1 + seq_row(t1, rb, T) * G + 4 * u0;
-                st_stream<u32x4>(d, u32x4{dw1[nt][0], dw1[nt][1], dw1[nt][2], dw1[nt][3]});
-                st_stream<u32x4>(d + 8, u32x4{dw1[nt][4], dw1[nt][5], dw1[nt][6], dw1[nt][7]});
-            }
-            if (do0) {
-                bf16_t *d = a.da0 + seq_row(t0, rb, T) * G + 4 * u0;
-                st_stream<u32x4>(d, u32x4{dw0[nt][0], dw0[nt][1], dw0[nt][2], dw0[nt][3]});
-                st_stream<u32x4>(d + 8, u32x4{dw0[nt][4], dw0[nt][5], dw0[nt][6], dw0[nt][7]});
-            }
-        }
+        if (s == T) store_da_rows();
     }
     stp.store(a.status, blockIdx.x == 0 && tid == 0);
+    if (NSD_SCAN_STAMPS && blockIdx.x == 0 && tid == 0) for (int i = 0; i < 6; ++i) reinterpret_cast<unsigned long long *>(a.status + 20)[i] = pass_acc[i];
     // ---- bias gradients of this batch tile, both layers
 #pragma unroll
     for (int k = 0; k < 16; ++k) {

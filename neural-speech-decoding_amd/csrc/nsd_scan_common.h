@@ -1,6 +1,7 @@
 // nsd_scan_common.h -- what the persistent scan kernels share (nsd_scan.hip: one layer per launch; nsd_scan2.hip: two
 // unidirectional layers skewed by one step in one launch): group geometry, the flag protocol, exchange stores.
 #pragma once
+#include <type_traits>
 #include "nsd_seq.h"
 
 // timing experiments only (make ABL=n -> libnsd_hip_abl.so, never shipped): bit 0 skip the flag wait, bit 1 skip the tile
@@ -16,6 +17,12 @@
 #endif
 
 namespace {
+
+// a loop whose index is a compile-time constant inside the body: f(std::integral_constant<int, I>) for I = I0 .. N-1
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 struct Stamps {
     unsigned long long last, acc[8];
@@ -140,6 +147,8 @@ __device__ __forceinline__ void mfma_new_a(f32x16 &acc, const bf16x8 &w, const b
 __device__ __forceinline__ void mfma_settle(f32x16 &a0) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0)); }
 __device__ __forceinline__ void mfma_settle(f32x16 &a0, f32x16 &a1) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0), "+a"(a1)); }
 __device__ __forceinline__ void mfma_settle(f32x16 &a0, f32x16 &a1, f32x16 &a2) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0), "+a"(a1), "+a"(a2)); }
+// (an accumulator whose last MFMA was issued at least one other MFMA ago: only the ordering of the reads is left to state)
+__device__ __forceinline__ void mfma_fence(f32x16 &a0) { asm volatile("s_nop 7" : "+a"(a0)); }
 __device__ __forceinline__ void mfma_lead_in() { asm volatile("s_nop 7" ::: "memory"); }             // VALU-written accumulator -> first MFMA
 
 // Software-pipelined form for a whole step: NS operand streams (weight rows w[st], LDS tile tile[st]) feeding accumulators
@@ -216,7 +225,7 @@ __device__ __forceinline__ void cell_factors(const u32x4 gq0, const u32x4 gq1, c
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned w0 = j < 2 ? gq0[2 * (j & 1)] : gq1[2 * (j & 1)], w1 = j < 2 ? gq0[2 * (j & 1) + 1] : gq1[2 * (j & 1) + 1];
-        const float ig = bf16_lo(w0), fg = bf16_hi(w0), gg = bf16_lo(w1), og = bf16_hi(w1);
+        const float ig = fabsf(bf16_lo(w0)), fg = bf16_hi(w0), gg = bf16_lo(w1), og = bf16_hi(w1);   // (the sign of a saved i is not part of the gate: saved_keep_bits)
         const float tc = fast_tanh(cv[j]);
         f.A[j] = og * (1.f - tc * tc);                 // d c_t / d h_t (through tanh(c_t))
         f.Fi[j] = gg * ig * (1.f - ig);
@@ -225,6 +234,12 @@ __device__ __forceinline__ void cell_factors(const u32x4 gq0, const u32x4 gq1, c
         f.Fo[j] = tc * og * (1.f - og);
         f.fg[j] = fg;
     }
+}
+// The saved input gate i = sigmoid(.) > 0 has a free sign bit.  The fused forward scan stores there whether the unit's OUTPUT survived the
+// dropout between the layers (set = kept), so the backward scan needs no random stream: multiplier = bit ? keep : 0.
+__device__ __forceinline__ void saved_keep_bits(const u32x4 gq0, const u32x4 gq1, const float keep, float (&m)[4]) {
+    m[0] = (gq0[0] & 0x8000u) ? keep : 0.f; m[1] = (gq0[2] & 0x8000u) ? keep : 0.f;
+    m[2] = (gq1[0] & 0x8000u) ? keep : 0.f; m[3] = (gq1[2] & 0x8000u) ? keep : 0.f;
 }
 // The factors are computed AHEAD of the exchange on purpose.  Where their only use sits inside a conditional block behind the
 // poll, the optimizer sinks the whole computation (tanh, the products, the dropout stream) into that block -- onto the critical
@@ -258,6 +273,12 @@ __device__ __forceinline__ void drop_mult4(const RngArgs &rng, const bool on, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = nsd_rand_u32(rng.seed, rng.base, base + j) >= rng.thr_lstm ? rng.keep_lstm : 0.f;
     }
+}
+
+// one multiplier, branch-free (for use between MFMAs); the same stream as drop_mult4
+__device__ __forceinline__ float drop_mult1(const RngArgs &rng, const bool on, const uint64_t index) {
+    const float kept = nsd_rand_u32(rng.seed, rng.base, index) >= rng.thr_lstm ? rng.keep_lstm : 0.f;
+    return on ? kept : 1.f;
 }
 
 }  // namespace

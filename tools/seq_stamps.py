@@ -11,7 +11,7 @@ flat = (torch.rand(spec.param_count, device=dev) * 2 - 1) / 16
 x = 2.7 * torch.randn(B, T, 8, device=dev)
 y = torch.randint(0, 5, (B,), device=dev, dtype=torch.int32)
 ws = ops.seq_workspace(spec, B, T, dev)
-names = ["poll", "barrier (wait for the other waves)", "mfma", "cells", "publish(store+drain+flag)", "saves+rotate", "gather loads -> arrival", "ds_write"]
+names = ["failed looks x 1000", "barrier (wait for the other waves)", "mfma", "cells", "publish (tagged granule stores, no drain)", "saves+rotate", "spin on the tagged granules -> arrival", "ds_write"]
 for mode in ("infer", "train"):
     for _ in range(3):
         if mode == "infer":
@@ -34,6 +34,9 @@ tot = acc.sum()
 print(f"backward scan: total/step {tot / (T + 1):.0f}")
 for n, v in zip(["poll", "partial-sum loads + add", "cells (dh-dependent part)", "own da -> LDS + barrier", "MFMA (48) + saved-set request", "convert + ring stores", "drain + flag", "row-major stores + cell factors of the next step"], acc):
     print(f"   {n:50s} {v / (T + 1):9.1f}  ({100.0 * v / max(tot, 1):5.1f} %)")
+
+pa = ws[256:384].cpu().numpy().view(np.int32)[20:32].view(np.uint64)
+print("   MFMA stream by pass (cycles / step):", " ".join(f"{v / (T + 1):7.1f}" for v in pa))
 
 # ---- single-layer kernels (cfg5 shape: H = 512, bidirectional, 64-trial tiles): backward scan of the LAST launch (layer 0)
 if "--cfg5" in sys.argv:
