@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
             const int b = b0 + 32 * nt + col;
             const long row = seq_row(t, b, a.T);
             st_stream<u32x2>(a.hs + row * ld + dir * H + u0, u32x2{hw[nt][0], hw[nt][1]});
+            float m[4] = {1.f, 1.f, 1.f, 1.f};
             if (a.lk) {
-                float m[4] = {1.f, 1.f, 1.f, 1.f};
                 if (a.rng.on && b < a.B) {
                     const uint64_t base = (((uint64_t)a.layer * a.B + b) * a.T + t) * (uint64_t)ld + (uint64_t)(dir * H + u0);
 #pragma unroll
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 unsigned gw[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    gw[2 * j] = pack_bf16x2(gi[nt][j], gf[nt][j]);
+                    gw[2 * j] = pack_bf16x2(gi[nt][j], gf[nt][j]) | (m[j] != 0.f ? 0x8000u : 0u);   // (sign of the saved i: the output survived the dropout behind this layer -- saved_keep_bits)
                     gw[2 * j + 1] = pack_bf16x2(gg[nt][j], go[nt][j]);
                 }
                 bf16_t *gd = a.ga[dir] + saved_ga(blk, 0, lane);
@@ -402,22 +402,23 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
         float al[NT], ds[NT];
     };
     auto t_of = [&](const int s) { return dir == 0 ? T - 1 - s : s; };   // reverse of the forward order
+    // (addresses: a wave-uniform 64-bit base per step -- scalar arithmetic, SGPR base operand -- plus a 32-bit lane offset)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     auto load_saved = [&](const int s, Saved &v) {
         const int t = t_of(s), tprev = dir == 0 ? t - 1 : t + 1;         // tprev: earlier in forward time (c_{t-1})
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int b = b0 + 32 * nt + col;
-            const long row = seq_row(t, b, T);
-            const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t, wave);
-            const bf16_t *gs = a.ga[dir] + saved_ga(blk, 0, lane);
-            v.gq[nt][0] = ld_stream<u32x4>(gs);
-            v.gq[nt][1] = ld_stream<u32x4>(gs + 512);
-            v.cq[nt] = ld_stream<u32x2>(a.cs[dir] + saved_cs(blk, lane));
+            const long row_u = (((long)(b0 >> 5) + nt) * T + t) * 32;    // seq_row(t, b0 + 32 nt + col) = row_u + col
+            const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t, wave_s);
+            const bf16_t *gs = a.ga[dir] + blk * 1024;
+            v.gq[nt][0] = ld_stream<u32x4>(gs + lane * 8);
+            v.gq[nt][1] = ld_stream<u32x4>(gs + 512 + lane * 8);
+            v.cq[nt] = ld_stream<u32x2>(a.cs[dir] + blk * 256 + lane * 4);
             const bool first = dir == 0 ? t == 0 : t == T - 1;
-            v.cpq[nt] = first ? u32x2{0u, 0u} : ld_stream<u32x2>(a.cs[dir] + saved_cs(blk + 4 * (tprev - t), lane));
-            if constexpr (TOP) { v.al[nt] = ld_stream<float>(a.alpha + row); v.ds[nt] = ld_stream<float>(a.dscore + row); }
-            else if constexpr (DINT) v.dvt[nt] = ld_stream<u32x2>(a.din_tiles + ((((long)((b0 >> 5) + nt) * T + t) * (a.D * P) + dir * P + me.p) * 1024 + wave * 256 + lane * 4));
-            else v.dv[nt] = ld_stream<f32x4>(a.din + row * ld + dir * H + u0);
+            v.cpq[nt] = first ? u32x2{0u, 0u} : ld_stream<u32x2>(a.cs[dir] + (blk + 4 * (tprev - t)) * 256 + lane * 4);
+            if constexpr (TOP) { v.al[nt] = ld_stream<float>(a.alpha + row_u + col); v.ds[nt] = ld_stream<float>(a.dscore + row_u + col); }
+            else if constexpr (DINT) v.dvt[nt] = ld_stream<u32x2>(a.din_tiles + ((((long)((b0 >> 5) + nt) * T + t) * (a.D * P) + dir * P + me.p) * 1024 + wave_s * 256) + lane * 4);
+            else v.dv[nt] = ld_stream<f32x4>(a.din + row_u * ld + (unsigned)(col * (int)ld + dir * H + u0));
         }
     };
     Saved sv;
@@ -435,12 +436,8 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             const long row = seq_row(t, b, T);
             cell_factors(sv.gq[nt][0], sv.gq[nt][1], sv.cq[nt], sv.cpq[nt], fc[nt]);
             if constexpr (!TOP) {
-                float m[4] = {1.f, 1.f, 1.f, 1.f};
-                if (a.rng.on && b < a.B) {
-                    const uint64_t base = (((uint64_t)a.layer * a.B + b) * T + t) * (uint64_t)ld + (uint64_t)(dir * H + u0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) m[j] = nsd_rand_u32(a.rng.seed, a.rng.base, base + j) >= a.rng.thr_lstm ? a.rng.keep_lstm : 0.f;
-                }
+                float m[4];
+                saved_keep_bits(sv.gq[nt][0], sv.gq[nt][1], a.rng.on ? a.rng.keep_lstm : 1.f, m);   // (the forward scan left them in the saved gates)
                 if constexpr (DINT) {
                     dup[nt][0] = bf16_lo(sv.dvt[nt][0]) * m[0]; dup[nt][1] = bf16_hi(sv.dvt[nt][0]) * m[1];
                     dup[nt][2] = bf16_lo(sv.dvt[nt][1]) * m[2]; dup[nt][3] = bf16_hi(sv.dvt[nt][1]) * m[3];
@@ -479,8 +476,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                 for (int q = 0; q < P; ++q)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        drec[nt][0] += bf16_lo(v16[q][2 * nt]); drec[nt][1] += bf16_hi(v16[q][2 * nt]);
-                        drec[nt][2] += bf16_lo(v16[q][2 * nt + 1]); drec[nt][3] += bf16_hi(v16[q][2 * nt + 1]);
+                        acc_bf16x2(drec[nt][0], drec[nt][1], v16[q][2 * nt]); acc_bf16x2(drec[nt][2], drec[nt][3], v16[q][2 * nt + 1]);
                     }
             } else {
                 u32x2 v8[P][NT];
@@ -492,8 +488,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
                 for (int q = 0; q < P; ++q)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        drec[nt][0] += bf16_lo(v8[q][nt][0]); drec[nt][1] += bf16_hi(v8[q][nt][0]);
-                        drec[nt][2] += bf16_lo(v8[q][nt][1]); drec[nt][3] += bf16_hi(v8[q][nt][1]);
+                        acc_bf16x2(drec[nt][0], drec[nt][1], v8[q][nt][0]); acc_bf16x2(drec[nt][2], drec[nt][3], v8[q][nt][1]);
                     }
             }
             // this wave has taken its partial sums of step s-1 out of the ring: the producers may rewrite the slot
@@ -577,9 +572,10 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
         // ---- row-major da_t for the weight-gradient / input-gradient GEMMs: behind the flag
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            bf16_t *d = a.da + seq_row(t, b0 + 32 * nt + col, T) * ldda + dir * G + 4 * u0;
-            st_stream<u32x4>(d, u32x4{dw[nt][0], dw[nt][1], dw[nt][2], dw[nt][3]});
-            st_stream<u32x4>(d + 8, u32x4{dw[nt][4], dw[nt][5], dw[nt][6], dw[nt][7]});
+            bf16_t *d = a.da + (((long)(b0 >> 5) + nt) * T + t) * 32 * ldda;
+            const unsigned lane_off = (unsigned)(col * (int)ldda + dir * G + 4 * u0);
+            st_stream<u32x4>(d + lane_off, u32x4{dw[nt][0], dw[nt][1], dw[nt][2], dw[nt][3]});
+            st_stream<u32x4>(d + lane_off + 8, u32x4{dw[nt][4], dw[nt][5], dw[nt][6], dw[nt][7]});
         }
     }
     stp.store(a.status, blockIdx.x == 0 && tid == 0);
