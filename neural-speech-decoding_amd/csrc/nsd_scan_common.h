@@ -141,7 +141,7 @@ __device__ __forceinline__ void mfma_acc_v(f32x16 &acc, const bf16x8 &w, const b
     asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(f));
 }
 __device__ __forceinline__ void mfma_new_a(f32x16 &acc, const bf16x8 &w, const bf16x8 &f) {       // acc = w . f
-    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(w), "v"(f));
+    asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc) : "a"(w), "v"(f));     // (early clobber: the result must not share registers with the operands)
 }
 // (the accumulators are operands of the statement: a register read of one cannot be scheduled above it)
 __device__ __forceinline__ void mfma_settle(f32x16 &a0) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0)); }
