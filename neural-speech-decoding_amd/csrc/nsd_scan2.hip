@@ -12,7 +12,6 @@
 //    input-gradient GEMM, no din round trip.
 //  * the layer-0 input projection W_ih0 x_t (K = channels padded to 16, at most 64) is one to four MFMAs per step inside the scan.
 // Semantics as everywhere: torch.nn.LSTM(num_layers=2, dropout=p) of Neuro-Alpha-App/Utilities/lstm_eeg_model.py:16-22,34.
-#include <cstdlib>
 #include "nsd_scan_common.h"
 
 namespace {
@@ -704,8 +703,6 @@ int nsd_scan2_fwd_launch(const Scan2FwdArgs &a, int H, int MG, hipStream_t st) {
     }
 }
 int nsd_scan2_bwd_launch(const Scan2BwdArgs &a, int H, int MG, hipStream_t st) {
-    static const int w8 = [] { const char *e = getenv("NSD_SCAN2_BWD8"); return e ? atoi(e) : 0; }();     // (per-process switch while both kernels are kept)
-    if (w8 && nsd_scan2_bwd8_supported(H, MG)) return nsd_scan2_bwd8_launch(a, H, MG, st);
     if (!nsd_scan2_supported(H, MG) || a.groups * (H / 32) > nsd_num_cus()) { nsd_set_error("scan2_bwd: unsupported geometry H=%d MG=%d groups=%d", H, MG, a.groups); return NSD_E_INVALID; }
     const dim3 grid(a.groups * (H / 32) - a.diag_short_grid);
     switch (H) {

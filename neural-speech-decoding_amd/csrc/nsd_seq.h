@@ -146,8 +146,6 @@ struct Scan2BwdArgs {
 bool nsd_scan2_supported(int H, int MG);
 int nsd_scan2_fwd_launch(const Scan2FwdArgs &a, int H, int MG, hipStream_t st);
 int nsd_scan2_bwd_launch(const Scan2BwdArgs &a, int H, int MG, hipStream_t st);
-bool nsd_scan2_bwd8_supported(int H, int MG);                                                  // nsd_scan2_w8.hip: eight waves per workgroup
-int nsd_scan2_bwd8_launch(const Scan2BwdArgs &a, int H, int MG, hipStream_t st);
 int nsd_scan_fwd_launch(const ScanFwdArgs &a, int H, int MG, hipStream_t st);
 int nsd_scan_bwd_launch(const ScanBwdArgs &a, int H, int MG, hipStream_t st);
 bool nsd_scan_supported(int H);
