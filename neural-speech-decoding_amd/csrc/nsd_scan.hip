@@ -13,11 +13,16 @@
 //
 // Exchange.  Each step every workgroup needs h_{t-1} of ALL H units of its batch tile: the members of a group exchange their
 // 32-unit slices through a small ring (two slots, step parity) in which every producer wave owns whole 128-byte lines
-// (nsd_scan_common.h); hs[t] itself is written row-major behind the flag for the GEMMs and the head.  The storing wave drains
-// vmcnt and publishes the step count in ITS OWN flag word (4 words per workgroup, no workgroup barrier on the publishing side);
-// every consuming wave polls all 4P words of its group with sc1 loads (one word per lane) and only then issues its sc1 loads
-// of the tile (guide: Guideline 16 R1 with sc1 loads in place of the acquire fence; every handed-off byte is stored and loaded
-// sc1 in the write-through mode, every flag follows the drain of the stores it stands for).
+// (nsd_scan_common.h); hs[t] itself is written row-major for the GEMMs and the head.
+// Forward scans (round 3): the ring validates itself.  |h| < 1, so bit 14 of every bf16 h is free and carries the TAG of the step that
+// wrote it ((s >> 1) & 1: it flips every time a parity slot is rewritten); a consuming wave loads its 16-byte pieces until every
+// value carries the expected tag and strips the bits on the way into LDS -- no drain of the stores, no flag, no poll: one L2 round
+// trip behind the slowest producer instead of three.  Both slots start with the tag their first writer will not use.
+// Backward scans: the storing wave drains vmcnt and publishes the step count in ITS OWN flag word (4 words per workgroup, no
+// workgroup barrier on the publishing side); every consuming wave polls all 4P words of its group with sc1 loads (one word per
+// lane) and only then issues its sc1 loads (guide: Guideline 16 R1 with sc1 loads in place of the acquire fence; every handed-off
+// byte is stored and loaded sc1 in the write-through mode, every flag follows the drain of the stores it stands for); the
+// partial-sum ring has ONE slot, guarded by consume counters (nsd_scan2.hip, "backward").
 // Same-XCD shortcut: before the first step the members of a group exchange their XCC ids (HW_REG_XCC_ID) through the slow
 // protocol -- which doubles as a start barrier: nobody enters the time loop before every member is resident.  When all ids
 // are equal the group shares ONE L2, and the exchange switches to plain stores (kept in that L2; vmcnt is acknowledged by

@@ -1,7 +1,8 @@
 // nsd_scan2.hip -- TWO unidirectional LSTM layers in one persistent launch, layer 1 one time step behind layer 0 (BASELINE
-// cfg3: L = 2).  Same grouping, register residency and flag protocol as nsd_scan.hip (read its header first); what changes:
+// cfg3: L = 2).  Same grouping, register residency and exchange protocols as nsd_scan.hip (read its header first: the forward
+// scans exchange self-validating tagged granules, the backward scans flags + consume counters); what changes:
 //
-//  * a workgroup owns its 32 hidden units in BOTH layers and holds W_hh0, W_ih1 and W_hh1 rows in VGPRs (192 registers per
+//  * a workgroup owns its 32 hidden units in BOTH layers and holds W_hh0, W_ih1 and W_hh1 rows in AGPRs (192 registers per
 //    lane at H = 256).  At macro step s layer 0 advances to t = s and layer 1 to t = s - 1: both need only what the group
 //    published at the end of step s - 1 (h0_{s-1}, its multiplied copy when dropout is on, h1_{s-2}), so the stack costs
 //    T + 1 exchanges instead of 2 T, and layer 1's input projection W_ih1 . in1_t runs inside the scan (no GEMM, no
