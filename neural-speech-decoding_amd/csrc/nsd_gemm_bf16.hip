@@ -587,7 +587,8 @@ int nsd_gemm_bf16_launch(const GemmArgs &g, hipStream_t st) {
     if ((g.epi == GEMM_EPI_TILE_BF16 || g.epi == GEMM_EPI_TILE_WAVE_BF16) && (g.M % 32 || g.N % 32)) { nsd_set_error("gemm_bf16: tile output needs M, N multiples of 32"); return NSD_E_INVALID; }
     const int splits = (g.epi == GEMM_EPI_F32 && g.splits > 1) ? g.splits : 1;
     if (g.b_shift != 0 && !g.b_kmajor) { nsd_set_error("gemm_bf16: b_shift needs a k-major B"); return NSD_E_INVALID; }
-    if (g.b_period < 0 || (g.b_period > 0 && (g.K >= (1L << 31) || g.b_shift >= g.b_period || -g.b_shift >= g.b_period))) { nsd_set_error("gemm_bf16: bad b_period"); return NSD_E_INVALID; }
+    // (|b_shift| == b_period is legal: no row has a partner inside its block -- one time step per batch tile -- and the product is zero)
+    if (g.b_period < 0 || (g.b_period > 0 && (g.K >= (1L << 31) || g.b_shift > g.b_period || -g.b_shift > g.b_period))) { nsd_set_error("gemm_bf16: bad b_period"); return NSD_E_INVALID; }
     if (g.B2 && (!g.b_kmajor || g.n_split <= 0 || g.n_split >= g.N || g.n_split % 256 || g.ldb2 % 8 || (g.N - g.n_split) % 8)) {
         nsd_set_error("gemm_bf16: a second B source needs a k-major B and 0 < n_split < N, n_split a multiple of 256");
         return NSD_E_INVALID;
