@@ -783,6 +783,37 @@ def test_backward_twice_after_one_forward(nsd, dev, H, L, D, B, T):
     assert torch.equal(ga, gb)
 
 
+@pytest.mark.parametrize("H,L,D", [(64, 2, 1), (256, 2, 1), (128, 2, 2), (512, 1, 2)])
+def test_seq_edge_batches_and_steps(nsd, dev, H, L, D):
+    """One trial, one short of a tile, exactly a tile, one over, two tiles and one -- with 1 and 3 time steps, every scan kernel family
+    (fused stack, layer by layer, bidirectional, the 64-trial tiles of H = 512): no time-out, finite, the same bits when evaluated
+    again, and a trial's logits do not depend on which batch it sits in (the padding trials of a tile take part in every MFMA)."""
+    from nsd_amd import ops
+    K = 3
+    st = synth_params(8, H, L, K, seed=7 * H + D, D=D)
+    spec = ops.ModelSpec(C=8, H=H, L=L, K=K, D=D)
+    flat = _flat_from_state(spec, st, dev)
+    rng = dict(seed=11, base_stream=8, p_lstm=0.5, p_head=0.5)
+    for T in (1, 3):
+        x_all = torch.from_numpy(synth_x(65, T, seed=H + T)).to(dev)
+        y_all = torch.from_numpy(synth_labels(65, K, seed=T)).to(dev)
+        ref_logits, _ = ops.seq_infer(spec, flat, x_all)
+        assert torch.isfinite(ref_logits).all()
+        for B in (1, 31, 32, 33, 65):
+            xt, yt = x_all[:B].contiguous(), y_all[:B].contiguous()
+            ws = ops.seq_workspace(spec, B, T, dev)
+            lg, pr = ops.seq_infer(spec, flat, xt, ws)
+            assert ops.seq_status(ws) == 0
+            assert torch.equal(lg, ref_logits[:B]), (T, B)                      # batch invariance, bitwise
+            assert torch.allclose(pr.sum(-1), torch.ones(B, device=dev), atol=1e-5)
+            ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng)
+            g1 = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng).clone()
+            ops.seq_train_fwd(spec, flat, xt, yt, ws, rng=rng)
+            g2 = ops.seq_train_bwd(spec, flat, ws, B, T, rng=rng)
+            assert ops.seq_status(ws) == 0 and torch.isfinite(g1).all() and g1.abs().max().item() > 0, (T, B)
+            assert torch.equal(g1, g2), (T, B)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("fused", [True, False])
 def test_scan_timeout_is_reported_everywhere(nsd, dev, fused):
