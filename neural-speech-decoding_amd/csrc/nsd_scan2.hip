@@ -21,6 +21,12 @@ constexpr int ST2_FWD_TIMEOUT = 1, ST2_BWD_TIMEOUT = 2;
 #ifndef NSD_LOOK_POS
 #define NSD_LOOK_POS 1
 #endif
+// In inference a step has no saves between its publishing store and the first look at the group's granules: without a pause 0.7 looks
+// per step come too early and cost a second L2 round trip and 32 KB per CU of L2 traffic each (counted in the diagnostic build).
+// s_sleep 4 (256 cycles): 1 024 windows x 250 steps in 886-891 us against 907-922 without, 920 at 6-8, 935 at 12.
+#ifndef NSD_LOOK_DELAY_INFER
+#define NSD_LOOK_DELAY_INFER 4
+#endif
 #ifndef NSD_LOOK_DELAY
 #define NSD_LOOK_DELAY 0
 #endif
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         auto first_look = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             if (NSD_LOOK_DELAY) __builtin_amdgcn_s_sleep(NSD_LOOK_DELAY);
+            else if (!train) __builtin_amdgcn_s_sleep(NSD_LOOK_DELAY_INFER);   // (inference: nothing separates the publish from the look -- see NSD_LOOK_DELAY_INFER)
             if (s < T) {
                 const nsd_rsrc rn = make_rsrc((s & 1) ? ring1 : ring0, (unsigned)(XG * 2));
 #pragma unroll
