@@ -409,7 +409,9 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
     auto t_of = [&](const int s) { return dir == 0 ? T - 1 - s : s; };   // reverse of the forward order
     // (addresses: a wave-uniform 64-bit base per step -- scalar arithmetic, SGPR base operand -- plus a 32-bit lane offset)
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    auto load_saved = [&](const int s, Saved &v) {
+    // (the cell state is read once: c_t of a step is the c_{t-1} the step before it used, carried in registers)
+    auto load_saved = [&](const int s, Saved &v, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
         const int t = t_of(s), tprev = dir == 0 ? t - 1 : t + 1;         // tprev: earlier in forward time (c_{t-1})
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             const bf16_t *gs = a.ga[dir] + blk * 1024;
             v.gq[nt][0] = ld_stream<u32x4>(gs + lane * 8);
             v.gq[nt][1] = ld_stream<u32x4>(gs + 512 + lane * 8);
-            v.cq[nt] = ld_stream<u32x2>(a.cs[dir] + blk * 256 + lane * 4);
+            if constexpr (FIRST) v.cq[nt] = ld_stream<u32x2>(a.cs[dir] + blk * 256 + lane * 4); else v.cq[nt] = v.cpq[nt];
             const bool first = dir == 0 ? t == 0 : t == T - 1;
             v.cpq[nt] = first ? u32x2{0u, 0u} : ld_stream<u32x2>(a.cs[dir] + (blk + 4 * (tprev - t)) * 256 + lane * 4);
             if constexpr (TOP) { v.al[nt] = ld_stream<float>(a.alpha + row_u + col); v.ds[nt] = ld_stream<float>(a.dscore + row_u + col); }
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
         }
     };
     Saved sv;
-    load_saved(0, sv);
+    load_saved(0, sv, std::true_type{});
     Stamps stp;
     stp.start();
     for (int s = 0; s < T; ++s) {
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(const ScanBwdArgs a) {
             // the consume counters of the group, requested now and looked at before the first ring store of the step (the MFMAs of
             // a consumer's row tile lie in between): every member must have taken step s-1's sums before the slot is rewritten
             unsigned ackv = ld_sc1_u32(gacks + (lane < 4 * P ? lane : 0));     // (every lane loads: no exec-masked block for the compare to be pulled into)
-            load_saved(s + 1, sv);
+            load_saved(s + 1, sv, std::false_type{});
             __builtin_amdgcn_sched_barrier(0);
             if (has_rows) {
                 const nsd_rsrc rw = make_rsrc(ring0, (unsigned)SLOT_BYTES);

@@ -417,24 +417,28 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
     // (addresses: a wave-uniform 64-bit base per step -- scalar arithmetic, SGPR base operand -- plus a 32-bit lane offset that never
     // changes; formed per lane in 64 bits they were ~120 VALU instructions of a step that is bound by instruction issue)
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    auto load_saved = [&](const int sx, Saved &v) {
+    // (the cell state is read ONCE: c_t of a step is the c_{t-1} the step before it used -- carried in registers; only the very first
+    // set loads a c_t.  Layer 0 is idle at step 0, and the "c_{t-1}" it loads there is c0[T-1], exactly step 1's c_t.)
+    auto load_saved = [&](const int sx, Saved &v, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
         const int x1 = T - 1 - sx > 0 ? T - 1 - sx : 0, x0 = T - sx < T ? T - sx : T - 1;     // (sx = T: layer 1 is idle; sx = 0: layer 0 is)
+        const int xp1 = T - 2 - sx > 0 ? T - 2 - sx : 0, xp0 = T - 1 - sx > 0 ? T - 1 - sx : 0;   // c_{t-1}: t1 - 1, t0 - 1 (zeroed by fix_saved where t = 0)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             {
                 const long row_u = (((long)(b0 >> 5) + nt) * T + x1) * 32;
                 const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x1, wave_s);
-                const bf16_t *gs = a.ga1 + blk * 1024, *cs = a.cs1 + blk * 256, *cp = a.cs1 + (x1 == 0 ? blk : blk - 4) * 256;   // (step x1 - 1: 4 blocks back)
+                const bf16_t *gs = a.ga1 + blk * 1024, *cp = a.cs1 + saved_block((b0 >> 5) + nt, P, me.p, T, xp1, wave_s) * 256;
                 v.q1[nt][0] = ld_stream<u32x4>(gs + lane * 8); v.q1[nt][1] = ld_stream<u32x4>(gs + 512 + lane * 8);
-                v.cq1[nt] = ld_stream<u32x2>(cs + lane * 4);
+                if constexpr (FIRST) v.cq1[nt] = ld_stream<u32x2>(a.cs1 + blk * 256 + lane * 4); else v.cq1[nt] = v.cp1[nt];
                 v.cp1[nt] = ld_stream<u32x2>(cp + lane * 4);
                 v.al[nt] = ld_stream<float>(a.alpha + row_u + col); v.ds[nt] = ld_stream<float>(a.dscore + row_u + col);
             }
             {
                 const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, x0, wave_s);
-                const bf16_t *gs = a.ga0 + blk * 1024, *cs = a.cs0 + blk * 256, *cp = a.cs0 + (x0 == 0 ? blk : blk - 4) * 256;
+                const bf16_t *gs = a.ga0 + blk * 1024, *cp = a.cs0 + saved_block((b0 >> 5) + nt, P, me.p, T, xp0, wave_s) * 256;
                 v.q0[nt][0] = ld_stream<u32x4>(gs + lane * 8); v.q0[nt][1] = ld_stream<u32x4>(gs + 512 + lane * 8);
-                v.cq0[nt] = ld_stream<u32x2>(cs + lane * 4);
+                if constexpr (FIRST) v.cq0[nt] = u32x2{0u, 0u}; else v.cq0[nt] = v.cp0[nt];
                 v.cp0[nt] = ld_stream<u32x2>(cp + lane * 4);
             }
         }
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
         }
     };
     Saved sv;
-    load_saved(0, sv);
+    load_saved(0, sv, std::true_type{});
     const float keep0 = a.rng.on ? a.rng.keep_lstm : 1.f;
     Stamps stp;
     stp.start();
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
         };
         if (s < T) {                                            // (after the last step nobody reads a partial sum)
             const int par = s & 1;
-            if (NSD_SCAN_ABLATE & 64) load_saved(s + 1, sv);
+            if (NSD_SCAN_ABLATE & 64) load_saved(s + 1, sv, std::false_type{});
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
             unsigned ackv = ld_sc1_u32(gacks + (lane < 4 * P ? lane : 0));     // (every lane loads: no exec-masked block for the compare to be pulled into)
             __builtin_amdgcn_sched_barrier(0);                  // FIRST in the queue: its wait must not include the HBM-bound requests below
             store_da_rows();
-            if (!(NSD_SCAN_ABLATE & (8 | 16 | 32 | 64))) load_saved(s + 1, sv);   // (its factors were taken at the top of the step: the registers are free)
+            if (!(NSD_SCAN_ABLATE & (8 | 16 | 32 | 64))) load_saved(s + 1, sv, std::false_type{});   // (its factors were taken at the top of the step: the registers are free)
             __builtin_amdgcn_sched_barrier(0);
             // ---- partial sums of dh for every unit of the group from this workgroup's 128 + 128 columns: 3 RT passes of KS MFMAs
             // (consumer row tile r = wave + 4 ri: W_hh1^T da1, W_ih1^T da1, W_hh0^T da0), ONE instruction stream in which the wave's
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(256) void scan2_bwd_kernel(const Scan2BwdArgs a) {
                 if (same_l2) stream(std::true_type{}); else stream(std::false_type{});
             }
             stp.mark(4);
-            if (NSD_SCAN_ABLATE & 32) load_saved(s + 1, sv);
+            if (NSD_SCAN_ABLATE & 32) load_saved(s + 1, sv, std::false_type{});
             stp.mark(5);
             if (!(NSD_SCAN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_xchg_u32(same_l2, gflags + 4 * me.p + wave, (unsigned)(s + 1));
