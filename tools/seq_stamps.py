@@ -32,7 +32,7 @@ for _ in range(3):
 acc = ws[256:384].cpu().numpy().view(np.int32)[4:20].view(np.uint64)
 tot = acc.sum()
 print(f"backward scan: total/step {tot / (T + 1):.0f}")
-for n, v in zip(["poll", "partial-sum loads + add", "cells (dh-dependent part)", "own da -> LDS + barrier", "MFMA (48) + saved-set request", "convert + ring stores", "drain + flag", "row-major stores + cell factors of the next step"], acc):
+for n, v in zip(["poll", "partial-sum loads + add + consume counter", "cells (dh-dependent part)", "own da -> LDS + barrier", "requests (consume counters, da rows, saved set) + MFMA stream (48) with conversions and ring stores", "-", "drain + flag", "cell factors of the step (top of the loop)"], acc):
     print(f"   {n:50s} {v / (T + 1):9.1f}  ({100.0 * v / max(tot, 1):5.1f} %)")
 
 pa = ws[256:384].cpu().numpy().view(np.int32)[20:32].view(np.uint64)
