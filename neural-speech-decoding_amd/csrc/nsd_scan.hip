@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     auto ring_of = [&](const int step) { return a.xch + (((long)(step & 1) * a.D + dir) * a.groups_total + a.group0 + me.group) * XB; };
     const int u0 = 8 * gt + 4 * hh;                            // first of this lane's 4 units
     const bool train = a.cs[0] != nullptr;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave), gt_s = 4 * me.p + wave_s;     // (wave-uniform copies for address bases)
 
     // input projection: accumulator tiles from the hoisted GEMM, or (INPROJ) x_t of the tile as MFMA B fragments (lane (trial,
     // hh): channels 16k + 8hh .. + 7).  Either way the data of step s+1 is requested AFTER the tile gather of step s has landed
@@ -171,15 +172,17 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     auto load_xp = [&](const int t) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            // (addresses: wave-uniform 64-bit base + 32-bit lane offset, as in the backward scans)
             if constexpr (INPROJ) {
-                const bf16_t *src = a.xbf + seq_row(t, b0 + 32 * nt + col, a.T) * CP + 8 * hh;
+                const bf16_t *src = a.xbf + (((long)(b0 >> 5) + nt) * a.T + t) * 32 * CP;
+                const unsigned lo = (unsigned)(col * CP + 8 * hh);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < ks0) xf[nt][k] = ld_stream<bf16x8>(src + 16 * k);
+                    if (k < ks0) xf[nt][k] = ld_stream<bf16x8>(src + lo + 16 * k);
             } else {
-                const bf16_t *src = a.xproj[dir] + ((((long)((b0 >> 5) + nt) * a.T + t) * (G >> 5) + gt) * 64 + lane) * 16;
-                xp[nt][0] = ld_stream<u32x4>(src);
-                xp[nt][1] = ld_stream<u32x4>(src + 8);
+                const bf16_t *src = a.xproj[dir] + ((((long)((b0 >> 5) + nt) * a.T + t) * (G >> 5) + gt_s) * 64) * 16;
+                xp[nt][0] = ld_stream<u32x4>(src + lane * 16);
+                xp[nt][1] = ld_stream<u32x4>(src + lane * 16 + 8);
             }
         }
     };
@@ -291,8 +294,9 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int b = b0 + 32 * nt + col;
-            const long row = seq_row(t, b, a.T);
-            st_stream<u32x2>(a.hs + row * ld + dir * H + u0, u32x2{hw[nt][0], hw[nt][1]});
+            const long row_u = (((long)(b0 >> 5) + nt) * a.T + t) * 32;                 // seq_row(t, b) = row_u + col
+            const unsigned lane_off = (unsigned)(col * (int)ld + dir * H + u0);
+            st_stream<u32x2>(a.hs + row_u * ld + lane_off, u32x2{hw[nt][0], hw[nt][1]});
             float m[4] = {1.f, 1.f, 1.f, 1.f};
             if (a.lk) {
                 if (a.rng.on && b < a.B) {
@@ -303,25 +307,25 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 // the multiplier acts on the value the next layer really reads: the bf16 h (+ the residual input, extension)
                 float h0 = bf16_lo(hw[nt][0]), h1 = bf16_hi(hw[nt][0]), h2 = bf16_lo(hw[nt][1]), h3 = bf16_hi(hw[nt][1]);
                 if (a.res) {
-                    const u32x2 rv2 = ld_stream<u32x2>(a.res + row * ld + dir * H + u0);
+                    const u32x2 rv2 = ld_stream<u32x2>(a.res + row_u * ld + lane_off);
                     h0 += bf16_lo(rv2[0]); h1 += bf16_hi(rv2[0]); h2 += bf16_lo(rv2[1]); h3 += bf16_hi(rv2[1]);
                 }
                 u32x2 v = {pack_bf16x2(h0 * m[0], h1 * m[1]), pack_bf16x2(h2 * m[2], h3 * m[3])};
-                st_stream<u32x2>(a.lk + row * ld + dir * H + u0, v);
+                st_stream<u32x2>(a.lk + row_u * ld + lane_off, v);
             }
             if (train) {
                 u32x2 cv = {pack_bf16x2(c[nt][0], c[nt][1]), pack_bf16x2(c[nt][2], c[nt][3])};
-                const long blk = saved_block((b0 >> 5) + nt, P, me.p, a.T, t, wave);
-                st_stream<u32x2>(a.cs[dir] + saved_cs(blk, lane), cv);
+                const long blk = saved_block((b0 >> 5) + nt, P, me.p, a.T, t, wave_s);
+                st_stream<u32x2>(a.cs[dir] + blk * 256 + lane * 4, cv);
                 unsigned gw[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     gw[2 * j] = pack_bf16x2(gi[nt][j], gf[nt][j]) | (m[j] != 0.f ? 0x8000u : 0u);   // (sign of the saved i: the output survived the dropout behind this layer -- saved_keep_bits)
                     gw[2 * j + 1] = pack_bf16x2(gg[nt][j], go[nt][j]);
                 }
-                bf16_t *gd = a.ga[dir] + saved_ga(blk, 0, lane);
-                st_stream<u32x4>(gd, u32x4{gw[0], gw[1], gw[2], gw[3]});
-                st_stream<u32x4>(gd + 512, u32x4{gw[4], gw[5], gw[6], gw[7]});
+                bf16_t *gd = a.ga[dir] + blk * 1024;
+                st_stream<u32x4>(gd + lane * 8, u32x4{gw[0], gw[1], gw[2], gw[3]});
+                st_stream<u32x4>(gd + 512 + lane * 8, u32x4{gw[4], gw[5], gw[6], gw[7]});
             }
         }
     }

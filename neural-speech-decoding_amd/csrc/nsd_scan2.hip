@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     const bool same_l2 = rv == 1 && a.allow_l2_mode != 0;
     if (tid == 0 && me.p == 0) atomicAdd(a.status + (rv == 1 ? 2 : 3), 1);
     const int u0 = 8 * gt + 4 * hh;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);    // (wave-uniform copy for address bases)
     const bool train = a.cs0 != nullptr, masked = a.lk0 != nullptr;
     const int T = a.T;
 
@@ -123,11 +124,12 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     bf16x8 xf[NT][4];
     auto load_x = [&](const int t) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const bf16_t *src = a.xbf + seq_row(t, b0 + 32 * nt + col, T) * CP + 8 * hh;
+        for (int nt = 0; nt < NT; ++nt) {                       // (wave-uniform 64-bit base + 32-bit lane offset, as in the backward scan)
+            const bf16_t *src = a.xbf + (((long)(b0 >> 5) + nt) * T + t) * 32 * CP;
+            const unsigned lo = (unsigned)(col * CP + 8 * hh);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (k < ks0) xf[nt][k] = ld_stream<bf16x8>(src + 16 * k);
+                if (k < ks0) xf[nt][k] = ld_stream<bf16x8>(src + lo + 16 * k);
         }
     };
 #pragma unroll
@@ -274,22 +276,22 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         // backward pass: nobody waits for them inside this launch
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int b = b0 + 32 * nt + col;
+            const unsigned lane_off = (unsigned)(col * H + u0);
+            const long row0 = (((long)(b0 >> 5) + nt) * T + t0) * 32, row1 = (((long)(b0 >> 5) + nt) * T + t1) * 32;    // seq_row(t, b) = row + col
             if (do0 && train) {
-                const long row = seq_row(t0, b, T);
-                st_stream<u32x2>(a.hs0 + row * H + u0, u32x2{hw0[nt][0], hw0[nt][1]});
-                if (masked) st_stream<u32x2>(a.lk0 + row * H + u0, u32x2{lw0[nt][0], lw0[nt][1]});
+                st_stream<u32x2>(a.hs0 + row0 * H + lane_off, u32x2{hw0[nt][0], hw0[nt][1]});
+                if (masked) st_stream<u32x2>(a.lk0 + row0 * H + lane_off, u32x2{lw0[nt][0], lw0[nt][1]});
             }
-            if (do1) st_stream<u32x2>(a.hs1 + seq_row(t1, b, T) * H + u0, u32x2{hw1[nt][0], hw1[nt][1]});
+            if (do1) st_stream<u32x2>(a.hs1 + row1 * H + lane_off, u32x2{hw1[nt][0], hw1[nt][1]});
         }
         if (train) {
             if (NSD_LOOK_POS == 1) first_look();
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (do0) {
-                    const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t0, wave);
-                    st_stream<u32x2>(a.cs0 + saved_cs(blk, lane), u32x2{pack_bf16x2(c0[nt][0], c0[nt][1]), pack_bf16x2(c0[nt][2], c0[nt][3])});
-                    bf16_t *gd = a.ga0 + saved_ga(blk, 0, lane);
+                    const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t0, wave_s);
+                    st_stream<u32x2>(a.cs0 + blk * 256 + lane * 4, u32x2{pack_bf16x2(c0[nt][0], c0[nt][1]), pack_bf16x2(c0[nt][2], c0[nt][3])});
+                    bf16_t *gd = a.ga0 + blk * 1024 + lane * 8;
                     // (sign of the saved i = the unit's output survived the dropout between the layers: saved_keep_bits)
                     st_stream<u32x4>(gd, u32x4{pack_bf16x2(g0[nt][0][0], g0[nt][0][1]) | (mult[nt][0] != 0.f ? 0x8000u : 0u), pack_bf16x2(g0[nt][0][2], g0[nt][0][3]),
                                                 pack_bf16x2(g0[nt][1][0], g0[nt][1][1]) | (mult[nt][1] != 0.f ? 0x8000u : 0u), pack_bf16x2(g0[nt][1][2], g0[nt][1][3])});
@@ -298,9 +300,9 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
                 }
                 if (NSD_LOOK_POS == 2 && nt == NT - 1) first_look();
                 if (do1) {
-                    const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t1, wave);
-                    st_stream<u32x2>(a.cs1 + saved_cs(blk, lane), u32x2{pack_bf16x2(c1[nt][0], c1[nt][1]), pack_bf16x2(c1[nt][2], c1[nt][3])});
-                    bf16_t *gd = a.ga1 + saved_ga(blk, 0, lane);
+                    const long blk = saved_block((b0 >> 5) + nt, P, me.p, T, t1, wave_s);
+                    st_stream<u32x2>(a.cs1 + blk * 256 + lane * 4, u32x2{pack_bf16x2(c1[nt][0], c1[nt][1]), pack_bf16x2(c1[nt][2], c1[nt][3])});
+                    bf16_t *gd = a.ga1 + blk * 1024 + lane * 8;
                     st_stream<u32x4>(gd, u32x4{pack_bf16x2(g1[nt][0][0], g1[nt][0][1]), pack_bf16x2(g1[nt][0][2], g1[nt][0][3]),
                                                 pack_bf16x2(g1[nt][1][0], g1[nt][1][1]), pack_bf16x2(g1[nt][1][2], g1[nt][1][3])});
                     st_stream<u32x4>(gd + 512, u32x4{pack_bf16x2(g1[nt][2][0], g1[nt][2][1]), pack_bf16x2(g1[nt][2][2], g1[nt][2][3]),
