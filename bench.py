@@ -19,8 +19,10 @@ gradient is summed with ONE RCCL all-reduce per step):
 spawns one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and waits for them; rank 0 prints the line.
 
 ONE JSON line on rank 0.  Besides the driver's contract it carries
-  other_configs (default run only: cfg2 on one GPU) the same measurement -- value, ms_per_step, roofline, kernels_us -- for cfg3,
-                cfg4's per-GPU share and cfg5's per-GPU share, a few steps each, so that every BASELINE config is driver-timed
+  other_configs (default config cfg2, any N) the same measurement -- value, ms_per_step, roofline, kernels_us -- for cfg3, cfg4
+                (1024 trials per GPU: global 8192 at N = 8 = BASELINE configs[3]) and cfg5 (512 per GPU = configs[4]), a few steps
+                each, so that every BASELINE config is driver-timed; a failure there is recorded as {"error": ...} in its place
+  ranks_seen    SUM all-reduce of 1 over the process group: the number of ranks the collective library (RCCL) really joined
   preheat_steps untimed steps run before the W warm-up steps (GPU clock ramp)
   step_ms_events    median / min of the per-step duration measured with HIP events on the launch stream (second loop)
   roofline      dominant kernel (longest average launch): algorithmic FLOP per launch / its launch time measured live with
@@ -99,8 +101,9 @@ def recorded_traffic(config: str, precision: str, kernel: str, B: int, T: int):
         e = j.get("kernels", {}).get(kernel)
         if e:
             best = (e["hbm_bytes_per_launch_corrected"], f"profiles/{os.path.basename(p)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                                                         f"separate passes; kernel sources sha256 {want[:12]})")
-    return best or (None, "no recorded PMC pass for this config / batch")
+                                                         f"separate passes; kernel sources sha256 {want[:12]})",
+                    e.get("rocprof_avg_us"))
+    return best or (None, "no recorded PMC pass for this config / batch", None)
 
 
 def algorithmic(cfg, B, T):
@@ -168,11 +171,14 @@ class _StubTrainer:
     """NSD_BENCH_STUB=1 (CPU test of the launcher / rendezvous / timing / reporting code, tests/test_ddp_gloo_cpu.py): the step
     is one small all-reduce over the process group and nothing else.  The line it produces says "data": "stub"."""
 
-    def __init__(self, world):
+    def __init__(self, world, name=""):
         self.t = torch.zeros(1024)
         self.world = world
+        self.fail = os.environ.get("NSD_BENCH_STUB_FAIL") == name        # test hook of the stub only: this config's step raises
 
     def step(self, x, y):
+        if self.fail:
+            raise MemoryError("stub: forced failure of this config")
         if self.world > 1:
             dist.all_reduce(self.t)
         time.sleep(0.001)
@@ -189,8 +195,13 @@ def _sync(stub):
         torch.cuda.synchronize()
 
 
+class ScanFailure(RuntimeError):
+    """A scan group of the sequence-batched path timed out on SOME rank.  Raised on EVERY rank in the same place (the ranks agree
+    on the status with one MAX all-reduce first), so the callers may treat it as a collective event."""
+
+
 def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extras, cpu_baseline, stub=False):
-    """Measure one config; returns the output dict on rank 0 (None elsewhere).  Raises SystemExit(3) on EVERY rank when a scan
+    """Measure one config; returns the output dict on rank 0 (None elsewhere).  Raises ScanFailure on EVERY rank when a scan
     group timed out on any rank."""
     cfg = CONFIGS[name]
     small = cfg["precision"] == "fp32"
@@ -203,7 +214,7 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extr
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     weights = "seeded default init (torch.manual_seed(4321))"
     if stub:
-        model, trainer, x, y = None, _StubTrainer(world), None, None
+        model, trainer, x, y = None, _StubTrainer(world, name), None, None
     else:
         torch.manual_seed(4321)                   # identical initial weights on every rank (the Trainer broadcasts rank 0's anyway)
         model = nsd_amd.EEG_LSTM(C, H, L, K, dropout=0.60, precision=cfg["precision"], bidirectional=cfg["bidirectional"])
@@ -229,12 +240,7 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extr
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             st = int(t.item())
         if st != 0:
-            if rank == 0:
-                print(f"bench.py: scan status {st} {where} (a scan group timed out on some rank): results invalid", file=sys.stderr)
-            if world > 1:
-                dist.barrier()
-                dist.destroy_process_group()
-            raise SystemExit(3)
+            raise ScanFailure(f"{name}: scan status {st} {where} (a scan group timed out on some rank): results invalid")
 
     do_step = lambda: trainer.step(x, y)
     # clock ramp: the GPU reaches its sustained clock only after some tens of milliseconds of load; run the same step untimed
@@ -293,10 +299,14 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extr
                 ops.seq_profile(False)
             check_status("after the per-kernel timing loop")
 
+    ranks_seen = 1
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if not stub else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        ones = torch.ones(1, dtype=torch.int32, device=dev if not stub else "cpu")      # what the collective library itself saw
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
 
     out = None
     if rank == 0:
@@ -309,7 +319,7 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extr
             "value": round(value, 1), "unit": "trials/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "stub" if stub else "synthetic",
-            "preheat_steps": preheat,
+            "preheat_steps": preheat, "ranks_seen": ranks_seen,
             "config": {"workload": f"{cfg['text']}, batch {B}/GPU", "name": name,
                        "batch_per_gpu": B, "global_batch": B * world, "T": T, "C": C, "H": H, "L": L, "K": K,
                        "bidirectional": cfg["bidirectional"], "weights": weights, "parallelism": f"dp{world}",
@@ -339,7 +349,7 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extr
             fl = alg["fwd_flop"] if dom == fwd_key else alg["bwd_flop"]
             by = alg["fwd_bytes"] if dom == fwd_key else alg["bwd_bytes"]
             tf, gbs = fl / t_s / 1e12, by / t_s / 1e9
-            traffic, tsrc = recorded_traffic(name, cfg["precision"], names[dom], B, T)
+            traffic, tsrc, rocprof_us = recorded_traffic(name, cfg["precision"], names[dom], B, T)
             out["roofline"] = {
                 "kernel": names[dom], "bound": bound, "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(tf / peak, 4), "traffic": traffic, "traffic_source": tsrc,
@@ -347,7 +357,15 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extr
                 "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": by},
                 "note": why,
+                # which library the HIP events were taken on: the fp32 path's C calls are one kernel each and are timed on the
+                # PRODUCT library; the bf16 path's per-kernel events exist only in the diagnostic twin (same kernel objects)
+                "timed_on": "libnsd_hip.so (HIP events around the one-kernel C call)" if small else
+                            "libnsd_hip_diag.so (the product's kernel objects; per-kernel HIP events compiled into the orchestration)",
             }
+            if rocprof_us:                                  # rocprofv3's average of the PRODUCT library's kernel, same sources
+                tfr = fl / (rocprof_us * 1e-6) / 1e12
+                out["roofline"]["rocprof_product"] = {"avg_launch_us": rocprof_us, "achieved": round(tfr, 3), "frac": round(tfr / peak, 4),
+                                                      "source": tsrc.split(" ")[0].replace("hbm_traffic.json", "kernel_stats.csv")}
             if traffic:
                 out["roofline"]["traffic_over_algorithmic"] = round(traffic / by, 2)
                 out["roofline"]["hbm"]["measured_traffic_GBps"] = round(traffic / t_s / 1e9, 1)
@@ -486,19 +504,52 @@ def main():
         dev = torch.device("cuda", local)
         nsd_amd.load_library()
 
-    out = run_config(args.config, args, rank, local, world, dev, steps, warmup, preheat, extras=not args.no_extras,
-                     cpu_baseline=not args.no_cpu_baseline, stub=stub)
+    def leave(code):
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(code)
 
-    # the driver runs `bench.py --gpus 1 --steps K --warmup W` = cfg2; the other BASELINE configs ride in the same line so that
-    # their numbers are driver-timed too (a few steps each, no CPU leg: ~10 s in all)
-    if (world == 1 and args.config == "cfg2" and not args.no_other_configs and not stub and args.batch_per_gpu is None
-            and args.T is None and not args.no_kernel_timing):
+    try:
+        out = run_config(args.config, args, rank, local, world, dev, steps, warmup, preheat, extras=not args.no_extras,
+                         cpu_baseline=not args.no_cpu_baseline, stub=stub)
+    except ScanFailure as e:                        # raised on every rank in the same place: leave together
+        if rank == 0:
+            print(f"bench.py: {e}", file=sys.stderr)
+        leave(3)
+
+    # the driver runs `bench.py --gpus N --steps K --warmup W` = cfg2; the other BASELINE configs ride in the same line so that
+    # their numbers are driver-timed too (a few steps each, no CPU leg: ~15 s in all) -- at EVERY N: with N ranks cfg4's line is
+    # BASELINE configs[3] as stated (1024 trials per GPU = global 8192 at N = 8) and cfg5's is configs[4] (512 per GPU).  A failure
+    # in one of them must not cost the headline: it is recorded in its place and the cfg2 line is printed regardless.
+    if args.config == "cfg2" and not args.no_other_configs and args.batch_per_gpu is None and args.T is None and not args.no_kernel_timing:
         others = {}
-        for name, (k, w, ph) in (("cfg3", (20, 5, 10)), ("cfg4", (100, 20, 200)), ("cfg5", (8, 2, 3))):
-            o = run_config(name, args, rank, local, world, dev, k, w, ph, extras=False, cpu_baseline=False)
-            others[name] = {key: o[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "step_ms_events",
-                                                    "roofline", "kernels_us", "step_frac_of_peak", "step_hbm_frac") if key in o}
-        out["other_configs"] = others
+        plan = (("cfg3", (20, 5, 10)), ("cfg4", (100, 20, 200)), ("cfg5", (8, 2, 3)))
+        if stub:
+            plan = tuple((n, (2, 1, 1)) for n, _ in plan)
+        for name, (k, w, ph) in plan:
+            try:
+                o = run_config(name, args, rank, local, world, dev, k, w, ph, extras=False, cpu_baseline=False, stub=stub)
+                if rank == 0:
+                    others[name] = {key: o[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "ranks_seen", "dtype",
+                                                            "config", "step_ms_events", "roofline", "kernels_us", "step_frac_of_peak",
+                                                            "step_hbm_frac") if key in o}
+            except ScanFailure as e:                # collective: every rank is here, the next config can run
+                others[name] = {"error": str(e)}
+            except BaseException as e:              # noqa: BLE001 -- incl. SystemExit / KeyboardInterrupt / out-of-memory
+                others[name] = {"error": f"{type(e).__name__}: {e}"[:500]}
+                if not stub:
+                    with contextlib.suppress(Exception):
+                        torch.cuda.empty_cache()
+                if world > 1:
+                    # a rank-local failure: the other ranks may be inside a collective of the step this rank left, so no further
+                    # config can be measured.  Rank 0 still prints what it has; everyone leaves without another collective.
+                    if rank == 0:
+                        out["other_configs"] = others
+                        print(json.dumps(out), flush=True)
+                    os._exit(4)
+        if rank == 0:
+            out["other_configs"] = others
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -272,10 +272,16 @@ int nsd_gemm_bf16(const void *A, int64_t lda, int32_t a_kmajor, const void *B, i
  *     forward, bit 1 a backward scan).  nsd_seq_workspace_init zeroes it: call it once after allocating the workspace (an
  *     uninitialised header reads as a failure).  No forward / backward call ever clears it.
  *   - logits, probs and the per-trial loss of an evaluation on a workspace that reports a time-out are NaN.
- *   nsd_seq_status      BLOCKING: status_out[4] = {code of the last evaluation OR the sticky word (0 = ok), the sticky word alone,
+ * Non-finite values (a NaN / Inf window, NaN / Inf or diverged weights) propagate as in the reference's torch.nn.LSTM
+ * (lstm_eeg_model.py:34): the logits / probs / loss of the affected trials are NaN, the other trials of the batch are
+ * untouched, gradients of a batch with such a trial are NaN.  They are reported as status bit 2 (value 4) of the evaluation
+ * -- NOT sticky, no time-out, no waiting -- and nsd_seq_guard raises its flag for that step, so the guarded Adam update
+ * does not write NaN into the parameters.
+ *   nsd_seq_status      BLOCKING: status_out[4] = {code of the last evaluation OR the sticky word (0 = ok; bits 0 / 1 time-outs,
+ *                       bit 2 non-finite activations in the last evaluation), the sticky word alone,
  *                       scan groups (over all scan launches since the last nsd_seq_train_fwd / nsd_seq_infer) whose workgroups
  *                       all reported ONE XCD, groups spread over several}
- *   nsd_seq_guard       enqueued: flag_out[0] (device fp32) = 1 if the workspace reports a time-out, else 0.  Append it to the
+ *   nsd_seq_guard       enqueued: flag_out[0] (device fp32) = 1 if the workspace reports a time-out or non-finite activations, else 0.  Append it to the
  *                       gradient vector that is all-reduced and hand it to nsd_adam_step_guarded: every rank then skips the
  *                       update when any rank's gradient is garbage.
  */

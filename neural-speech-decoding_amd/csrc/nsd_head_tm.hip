@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void head_tm_kernel(const HeadTmArgs a) {
     if (b >= a.B) return;                                       // whole waves leave; nothing below needs the workgroup
     const int c0 = lane * VPL, T = a.T, F = a.F, K = a.K;
     // a scan group of this evaluation (or of an earlier one on this workspace) timed out: the sequence below is garbage
-    const bool bad = a.status != nullptr && (a.status[0] | a.status[-NSD_SEQ_HEADER_WORDS]) != 0;
+    const bool bad = a.status != nullptr && ((a.status[0] | a.status[-NSD_SEQ_HEADER_WORDS]) & NSD_SEQ_ST_TIMEOUT_MASK) != 0;
     float aw[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) aw[v] = a.attn_w[c0 + v];

@@ -124,10 +124,16 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
         for (int ks = 0; ks < KS; ++ks) w[ks] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ks);
     }
     float c[NT][4];
+    unsigned poison[NT];                                        // non-finite h of this lane's units of trial (nt, col): see nsd_scan2.hip, forward
+    bool wbad = false;                                          // (W_hh . h_{-1} is skipped at s = 0: a non-finite row is NaN at once in the reference)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int ks = 0; ks < KS; ++ks) wbad = wbad || frag_nonfinite(w[ks]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        poison[nt] = wbad ? 0x7FC07FC0u : 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[nt][j] = 0.f;
+    }
     if (tid == 0) s_abort = 0;
     // The exchange ring validates itself (design: nsd_scan2.hip, forward): |h| < 1, so bit 14 of every bf16 h is free and carries the
     // TAG of the step that wrote it ((s >> 1) & 1); a consumer loads its pieces until all tags are the expected ones -- no drain, no
@@ -287,7 +293,13 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 hw[nt][0] = pack_bf16x2(hv[nt][0], hv[nt][1]);
                 hw[nt][1] = pack_bf16x2(hv[nt][2], hv[nt][3]);
                 const unsigned tag = ((s >> 1) & 1) ? TAGBITS : 0u;
-                st_xchg_u64(same_l2, slot + ring_h_off(gt, nt, NT, col, hh), ((unsigned long long)(hw[nt][1] | tag) << 32) | (hw[nt][0] | tag));
+                // a non-finite h carries bit 14 by itself: the lane is poisoned for this trial from here on -- zeros with the right tag
+                // into the ring, NaN into the row-major sequence (the next layer's projection / the head turn the trial's logits into
+                // NaN, as torch's nn.LSTM does), NSD_SEQ_ST_NONFINITE into the status word
+                if (((hw[nt][0] | hw[nt][1]) & TAGBITS) != 0u) poison[nt] = 0x7FC07FC0u;
+                const unsigned p0 = poison[nt] ? 0u : hw[nt][0], p1 = poison[nt] ? 0u : hw[nt][1];
+                st_xchg_u64(same_l2, slot + ring_h_off(gt, nt, NT, col, hh), ((unsigned long long)(p1 | tag) << 32) | (p0 | tag));
+                hw[nt][0] |= poison[nt]; hw[nt][1] |= poison[nt];
             }
         }
         // ---- everything else of the step leaves behind the flag (nobody waits for it inside this launch)
@@ -328,6 +340,12 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
                 st_stream<u32x4>(gd + 512 + lane * 8, u32x4{gw[4], gw[5], gw[6], gw[7]});
             }
         }
+    }
+    {
+        bool any = false;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) any = any || poison[nt] != 0u;
+        if (__any(any) && lane == 0) atomicOr(a.status, NSD_SEQ_ST_NONFINITE);
     }
 }
 

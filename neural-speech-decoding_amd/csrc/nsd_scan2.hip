@@ -93,6 +93,12 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     // store, where "stores -> drain -> flag -> poll -> loads" was three (round 2: ~3 800 of a step's ~9 900 cycles were protocol).
     // A lane's 16 bytes are written by one store instruction and read by one load: they arrive together.  The slots start with the
     // tag their first writer will NOT use (the workspace may hold a previous launch's granules), drained before the start barrier.
+    // NON-FINITE h (a NaN / Inf window, diverged or NaN weights: torch's nn.LSTM of lstm_eeg_model.py:34 propagates them) has bit 14
+    // set by itself -- 0x7FC0, 0x7F80 -- and would read as a wrong tag (a consumer spinning to the time-out) or, masked, as 1.5.  A
+    // producer lane therefore checks its packed words: once one of its values of a trial is not finite the lane is POISONED for that
+    // trial -- it publishes zeros (right tag: nobody waits, nobody computes on a fake finite value that matters) and writes NaN into
+    // every row-major h it owns from then on, so the head's pooling turns all logits of THAT trial into NaN exactly as the
+    // reference does, the weight gradients become NaN as the reference's do, and the evaluation's status word gets NSD_SEQ_ST_NONFINITE.
     constexpr unsigned TAGBITS = 0x40004000u;
     constexpr long XG = (long)MG * H * 2;                       // bf16 elements of one slot: MG * H / 4 granules of 8
     bf16_t *const ring0 = a.xch + (long)(a.group0 + me.group) * XG, *const ring1 = ring0 + (long)a.groups_total * XG;
@@ -140,6 +146,16 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     u32x4 pg[PIECES];                                           // the granules a thread gathers (requested a step ahead, see "publish")
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) pg[i] = u32x4{0u, 0u, 0u, 0u};
+    unsigned poison[NT];                                        // 0, or 0x7FC07FC0 once a value of this lane's units of trial (nt, col) was not finite
+    {
+        // W_hh0 . h_{-1} is not formed at s = 0 (h_{-1} = 0): a non-finite W_hh0 row would go unnoticed for a step where the reference
+        // has NaN at once (W_hh1 and W_ih1 meet their zero / first tiles in the MFMAs of s = 1: IEEE does the rest)
+        bool wbad = false;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wbad = wbad || frag_nonfinite(w0[ks]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) poison[nt] = wbad ? 0x7FC07FC0u : 0u;
+    }
     Stamps stp;
     stp.start();
     for (int s = 0; s <= T; ++s) {
@@ -239,6 +255,8 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             // the multiplier acts on the value layer 1 really reads: the bf16 h0
             lw0[nt][0] = pack_bf16x2(bf16_lo(hw0[nt][0]) * mult[nt][0], bf16_hi(hw0[nt][0]) * mult[nt][1]);
             lw0[nt][1] = pack_bf16x2(bf16_lo(hw0[nt][1]) * mult[nt][2], bf16_hi(hw0[nt][1]) * mult[nt][3]);
+            // |h| <= 1 for finite arithmetic: bit 14 of a packed h is set only by Inf / NaN (see the ring's description above)
+            if (((hw0[nt][0] | hw0[nt][1] | hw1[nt][0] | hw1[nt][1]) & TAGBITS) != 0u) poison[nt] = 0x7FC07FC0u;
         }
         stp.mark(3);
         // ---- publish h0_t0 (+ the keep / drop bits of its multiplied copy) and h1_t1 as ONE tagged granule per lane; no drain, no flag
@@ -252,7 +270,8 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
                     k0 = (mult[nt][0] != 0.f ? 0x4000u : 0u) | (mult[nt][1] != 0.f ? 0x40000000u : 0u);
                     k1 = (mult[nt][2] != 0.f ? 0x4000u : 0u) | (mult[nt][3] != 0.f ? 0x40000000u : 0u);
                 }
-                const u32x4 gr = {do0 ? (hw0[nt][0] | k0) : 0u, do0 ? (hw0[nt][1] | k1) : 0u, (do1 ? hw1[nt][0] : 0u) | tag, (do1 ? hw1[nt][1] : 0u) | tag};
+                const bool pub0 = do0 && poison[nt] == 0u, pub1 = do1 && poison[nt] == 0u;
+                const u32x4 gr = {pub0 ? (hw0[nt][0] | k0) : 0u, pub0 ? (hw0[nt][1] | k1) : 0u, (pub1 ? hw1[nt][0] : 0u) | tag, (pub1 ? hw1[nt][1] : 0u) | tag};
                 st_ring_b128(same_l2, rw, (unsigned)((gran_off + 512 * nt) * 2), gr);
             }
         }
@@ -279,10 +298,10 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             const unsigned lane_off = (unsigned)(col * H + u0);
             const long row0 = (((long)(b0 >> 5) + nt) * T + t0) * 32, row1 = (((long)(b0 >> 5) + nt) * T + t1) * 32;    // seq_row(t, b) = row + col
             if (do0 && train) {
-                st_stream<u32x2>(a.hs0 + row0 * H + lane_off, u32x2{hw0[nt][0], hw0[nt][1]});
-                if (masked) st_stream<u32x2>(a.lk0 + row0 * H + lane_off, u32x2{lw0[nt][0], lw0[nt][1]});
+                st_stream<u32x2>(a.hs0 + row0 * H + lane_off, u32x2{hw0[nt][0] | poison[nt], hw0[nt][1] | poison[nt]});
+                if (masked) st_stream<u32x2>(a.lk0 + row0 * H + lane_off, u32x2{lw0[nt][0] | poison[nt], lw0[nt][1] | poison[nt]});
             }
-            if (do1) st_stream<u32x2>(a.hs1 + row1 * H + lane_off, u32x2{hw1[nt][0], hw1[nt][1]});
+            if (do1) st_stream<u32x2>(a.hs1 + row1 * H + lane_off, u32x2{hw1[nt][0] | poison[nt], hw1[nt][1] | poison[nt]});
         }
         if (train) {
             if (NSD_LOOK_POS == 1) first_look();
@@ -312,6 +331,12 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
             if (NSD_LOOK_POS == 3) first_look();
         }
         stp.mark(5);
+    }
+    {
+        bool any = false;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) any = any || poison[nt] != 0u;
+        if (__any(any) && lane == 0) atomicOr(a.status, NSD_SEQ_ST_NONFINITE);
     }
     stp.store(a.status, blockIdx.x == 0 && tid == 0);
 }

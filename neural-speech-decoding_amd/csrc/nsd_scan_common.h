@@ -51,7 +51,7 @@ constexpr int ST_FWD_TIMEOUT = 1, ST_BWD_TIMEOUT = 2;
 // a scan group gave up: the code goes into the status word of the evaluation AND into the workspace's sticky word (never cleared
 // by a forward call: the caller sees the failure whenever it looks, and the guarded Adam update skips until it does)
 __device__ __forceinline__ void report_timeout(int *status, const int code) {
-    atomicExch(status, code);
+    atomicOr(status, code);
     atomicOr(status - NSD_SEQ_HEADER_WORDS, code);
 }
 constexpr int GROUP_WORDS = NSD_SEQ_GROUP_WORDS, ACK_WORD = NSD_SEQ_ACK_WORD;                   // flag words per group: [0,64) one per wave of every member, [64,80) XCC ids
@@ -178,6 +178,16 @@ __device__ __forceinline__ void mfma_pipe(const bf16x8 *const (&w)[NS], const bf
     for (int st = 0; st < NS; ++st)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) mfma_settle(acc_of(st, nt));   // (an accumulator fed by two streams is named twice: harmless)
+}
+
+// true when one of the 8 bf16 values of a weight fragment is Inf / NaN (exponent all ones).  Prologue only: the forward scans skip the
+// recurrent product of the first step (h_{-1} = 0), where torch's nn.LSTM forms W_hh . 0 and gets NaN from a non-finite weight.
+__device__ __forceinline__ bool frag_nonfinite(const bf16x8 &w) {
+    const u32x4 d = __builtin_bit_cast(u32x4, w);
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bad = bad || (d[i] & 0x7F80u) == 0x7F80u || (d[i] & 0x7F800000u) == 0x7F800000u;
+    return bad;
 }
 
 // ---- exchange rings -------------------------------------------------------------------------------------------------------

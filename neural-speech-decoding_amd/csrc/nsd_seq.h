@@ -31,6 +31,10 @@ __host__ __device__ __forceinline__ long seq_row(const int t, const int b, const
 // every forward call): [0] status, [2] / [3] scan groups on one XCD / spread, [4..] diagnostic stamps.
 // flag words per scan group: [0,64) one publish counter per wave of every member, [64,80) XCC ids of the members (rendezvous),
 // [128,192) one consume counter ("ack") per wave of every member -- the backward partial-sum ring has ONE slot (nsd_scan2.hip)
+// status bits: 1 / 2 a forward / backward scan group timed out (also ORed into the sticky word); 4 = a forward scan met a NaN / Inf
+// hidden state (per evaluation, NOT sticky: the affected trials' logits are NaN as in the reference, the others are valid)
+#define NSD_SEQ_ST_TIMEOUT_MASK 3
+#define NSD_SEQ_ST_NONFINITE 4
 #define NSD_SEQ_GROUP_WORDS 256
 #define NSD_SEQ_ACK_WORD 128
 #define NSD_SEQ_HEADER_BYTES 256

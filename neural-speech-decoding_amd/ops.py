@@ -406,9 +406,13 @@ def _seq_rng(rng: Optional[dict]):
                             float(rng["p_head"])))
 
 
+SEQ_ST_TIMEOUT_MASK, SEQ_ST_NONFINITE = 3, 4
+
+
 def seq_status(ws: torch.Tensor, detail: bool = False):
     """0 = ok; bit 0 / bit 1 = a forward / backward scan group timed out, in the last evaluation or (sticky) in any evaluation
-    since the workspace was created: results invalid.  detail=True: (status, groups that ran on one XCD, groups spread over
+    since the workspace was created: results invalid; bit 2 (SEQ_ST_NONFINITE, last evaluation only) = a forward scan met a NaN / Inf
+    hidden state: the logits of the affected trials are NaN, as the reference's are.  detail=True: (status, groups that ran on one XCD, groups spread over
     several XCDs) counted over the scan launches since the last forward.  Synchronises."""
     out = (C.c_int32 * 4)(-1, 0, 0, 0)
     _call("nsd_seq_status", ws.device, ws.data_ptr(), out, STREAM)
@@ -416,14 +420,20 @@ def seq_status(ws: torch.Tensor, detail: bool = False):
 
 
 def seq_guard(ws: torch.Tensor, flag: torch.Tensor) -> None:
-    """flag[0] (device fp32) = 1 if `ws` reports a scan time-out (last evaluation or sticky), else 0.  Enqueued, no sync."""
+    """flag[0] (device fp32) = 1 if `ws` reports a scan time-out (last evaluation or sticky) or non-finite activations in the last
+    evaluation, else 0.  Enqueued, no sync."""
     _call("nsd_seq_guard", ws.device, ws.data_ptr(), _dev_f32(flag, "flag"), STREAM)
 
 
-def seq_raise_on_timeout(ws: torch.Tensor, what: str) -> None:
-    """Synchronises; raises NsdError when `ws` reports a scan time-out."""
+def seq_raise_on_timeout(ws: torch.Tensor, what: str, nonfinite: bool = False) -> None:
+    """Synchronises; raises NsdError when `ws` reports a scan time-out, or (nonfinite=True: what a training loop wants to know)
+    non-finite activations in the last evaluation."""
     st = seq_status(ws)
-    if st != 0:
+    if nonfinite and (st & SEQ_ST_NONFINITE) and not (st & SEQ_ST_TIMEOUT_MASK):
+        raise NsdError(f"{what}: non-finite activations (NaN / Inf hidden state) in the last evaluation of the sequence-batched path "
+                       f"(status {st}): a NaN / Inf window or diverged / NaN weights.  The affected trials' logits and the gradients "
+                       "are NaN as in the reference; the guarded Adam update was skipped")
+    if st & SEQ_ST_TIMEOUT_MASK:
         stage = " and ".join(n for bit, n in ((1, "forward"), (2, "backward")) if st & bit) or f"code {st}"
         raise NsdError(f"{what}: a {stage} scan group of the sequence-batched path timed out (status {st}): its workgroups were not "
                        "all resident at once (another process on the GPU, a CU mask or a partition mode?).  Results since then "

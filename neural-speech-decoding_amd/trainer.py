@@ -119,6 +119,7 @@ class Trainer:
         self._bufs = {}
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
         self._last_B = 0
+        self._carried_failure = ""       # bf16 path, world > 1: message of a time-out found in a workspace that was replaced
         # hipGraph replay of the step (static-input path): everything that varies per step lives on the device
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.flat.device)
         self._graphs = {}
@@ -182,7 +183,16 @@ class Trainer:
             # sequence-batched path: forward (+ head, CE, head backward), backward (+ all parameter gradients), Adam
             key = ("seq", B, T)
             if key not in self._bufs:
-                self._check_old_workspaces("Trainer.step")     # a reported time-out must not vanish with the buffer
+                # a reported time-out must not vanish with the buffer.  One rank: raise here.  Several ranks: raising on this rank
+                # alone would leave the others waiting in the step's all-reduce, so the old status is carried into the failure
+                # flag that rides that all-reduce (below) and every rank raises in check().
+                if self.world == 1:
+                    self._check_old_workspaces("Trainer.step")
+                else:
+                    try:
+                        self._check_old_workspaces("Trainer.step")
+                    except ops.NsdError as e:
+                        self._carried_failure = str(e)
                 self._bufs = {key: {"ws": ops.seq_workspace(sp, B, T, self.flat.device),
                                     "logits": torch.empty((B, sp.K), dtype=torch.float32, device=self.flat.device)}}
             buf = self._bufs[key]
@@ -193,6 +203,8 @@ class Trainer:
             ops.seq_train_fwd(sp, self.flat, x, y, buf["ws"], rng=rng, scale=scale, logits=buf["logits"])
             ops.seq_train_bwd(sp, self.flat, buf["ws"], B, T, rng=rng, grads=self.grads)
             ops.seq_guard(buf["ws"], self._skip)
+            if self._carried_failure:                          # (seq_guard overwrites the flag with this workspace's status)
+                self._skip.add_(1.0)
             if fuse_adam:
                 self._adam()
             return
@@ -318,7 +330,7 @@ class Trainer:
     def _check_old_workspaces(self, what: str) -> None:
         for key, buf in self._bufs.items():
             if key[0] == "seq":
-                ops.seq_raise_on_timeout(buf["ws"], what)
+                ops.seq_raise_on_timeout(buf["ws"], what, nonfinite=True)
 
     @_on_own_device
     def check(self) -> None:
@@ -328,9 +340,12 @@ class Trainer:
         if self.model.precision != "bf16":
             return
         if float(self._skip.item()) != 0.0:
+            if self._carried_failure:
+                raise ops.NsdError(self._carried_failure)
             self._check_old_workspaces("Trainer")              # this rank's own status, with the stage in the message
-            raise ops.NsdError("Trainer: a scan group of the sequence-batched path timed out on another rank; every rank has "
-                               "skipped its Adam updates since (guarded update).  Results are invalid")
+            raise ops.NsdError("Trainer: a scan group of the sequence-batched path timed out, or met non-finite activations, on another "
+                               "rank; every rank has skipped the guarded Adam update of that step (and, after a time-out, of every "
+                               "step since).  Results are invalid")
         self._check_old_workspaces("Trainer")
 
     @_on_own_device

@@ -174,9 +174,37 @@ def test_bench_starts_its_own_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["data"] == "stub" and out["metric"].startswith("STUB")
     assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"] and out["config"]["parallelism"] == "dp2"
-    assert out["value"] > 0 and out["ms_per_step"] > 0 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and out["scaling"] == "weak" and out["ranks_seen"] == 2
+    # the other BASELINE configs ride in the multi-rank line too: cfg4 = 1024 trials per GPU (global 8192 at 8 ranks), cfg5 = 512 per GPU
+    oc = out["other_configs"]
+    assert set(oc) == {"cfg3", "cfg4", "cfg5"} and not any("error" in v for v in oc.values()), oc
+    assert oc["cfg4"]["config"]["batch_per_gpu"] == 1024 and oc["cfg4"]["config"]["global_batch"] == 1024 * 2
+    assert oc["cfg5"]["config"]["batch_per_gpu"] == 512 and oc["cfg5"]["config"]["global_batch"] == 512 * 2
+    assert all(v["n_gpus"] == 2 and v["ranks_seen"] == 2 for v in oc.values())
     # a mismatching launcher environment is refused (rc 2), not re-launched
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
                         env=env2, capture_output=True, text=True, timeout=120)
     assert r2.returncode == 2 and "WORLD_SIZE=1" in r2.stderr
+
+
+@pytest.mark.timeout(300)
+def test_bench_keeps_the_headline_when_another_config_fails():
+    """The default run measures cfg3 / cfg4 / cfg5 after the headline config; whatever goes wrong in one of them (here: the stub's
+    step raises MemoryError for cfg3) is recorded in its place, the remaining configs are still measured and the cfg2 line is printed
+    with rc 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NSD_BENCH_STUB="1", NSD_DIST_BACKEND="gloo", NSD_BENCH_STUB_FAIL="cfg3")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--preheat-steps", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["config"]["name"] == "cfg2" and out["value"] > 0
+    oc = out["other_configs"]
+    assert "MemoryError" in oc["cfg3"]["error"] and oc["cfg4"]["value"] > 0 and oc["cfg5"]["value"] > 0

@@ -858,8 +858,9 @@ def test_scan_timeout_is_reported_everywhere(nsd, dev, fused):
     assert torch.isnan(lg).all()
     _, probs = ops.seq_infer(spec, flat, xt, ws)
     assert torch.isnan(probs).all()
+    m._last_seq_ws = ws
     with pytest.raises(nsd.NsdError, match="timed out"):
-        _raise_on_poison(probs.cpu().numpy(), xt.cpu().numpy(), "predict")
+        _raise_on_poison(m, probs.cpu().numpy(), "predict")
     # a fresh workspace is clean
     ws2 = ops.seq_workspace(spec, B, T, dev)
     lg2 = ops.seq_train_fwd(spec, flat, xt, yt, ws2)
@@ -868,6 +869,92 @@ def test_scan_timeout_is_reported_everywhere(nsd, dev, fused):
     ws3 = torch.full_like(ws2, 0x5A)
     lg3 = ops.seq_train_fwd(spec, flat, xt, yt, ws3)
     assert ops.seq_status(ws3) != 0 and torch.isnan(lg3).all()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fused", [True, False])
+def test_non_finite_values_propagate_like_the_reference(nsd, dev, fused):
+    """torch's nn.LSTM (lstm_eeg_model.py:34) propagates NaN / Inf: a window holding one NaN gives NaN logits for THAT trial and leaves
+    the others alone; a non-finite weight gives NaN logits for every trial.  The forward scans exchange h with a step tag in bit 14 of
+    every bf16 value -- free only while |h| < 2 -- so a non-finite h must neither spin a consumer into the ~1-s time-out nor be
+    masked into a finite 1.5: the producer publishes zeros with the right tag, writes NaN into the row-major sequence and sets
+    NSD_SEQ_ST_NONFINITE (status 4, not sticky).  Checked for the fused two-layer launch and the layer-by-layer (bidirectional)
+    kernels: NaN in one trial of x, Inf in one recurrent weight, inference and training, and the wall time of each evaluation."""
+    import time
+    from nsd_amd import ops
+    from nsd_amd.trainer import Trainer
+    from nsd_amd.lstm_eeg_model import _raise_on_poison
+    H, L, K, B, T = 128, 2, 3, 40, 7
+    D = 1 if fused else 2
+    torch.manual_seed(5)
+    m = nsd.EEG_LSTM(8, H, L, K, dropout=0.5, precision="bf16", bidirectional=D == 2).to(dev).eval()
+    spec, flat = m.spec, m.flat_parameters()
+    x = synth_x(B, T, seed=4)
+    xt = torch.from_numpy(x).to(dev)
+    yt = torch.from_numpy(synth_labels(B, K, seed=4)).to(dev)
+    ws = ops.seq_workspace(spec, B, T, dev)
+    clean, _ = ops.seq_infer(spec, flat, xt, ws)
+    assert ops.seq_status(ws) == 0 and torch.isfinite(clean).all()
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+
+    # ---- one NaN sample in trial 5 (from step 3 on the trial's hidden state is NaN); one Inf sample in trial 17
+    for bad_trial, t_bad, val in ((5, 3, float("nan")), (17, 0, float("inf")), (39, T - 1, float("nan"))):
+        xb = xt.clone()
+        xb[bad_trial, t_bad, 2] = val
+        (lg, pr), dt = timed(lambda: ops.seq_infer(spec, flat, xb, ws))
+        st = ops.seq_status(ws)
+        others = [b for b in range(B) if b != bad_trial]
+        assert dt < 0.5, f"non-finite input must not cost a spin to the time-out ({dt:.2f} s)"
+        assert (st & 3) == 0, st
+        assert torch.equal(lg[others], clean[others]), "the other trials of the batch are untouched, bitwise"
+        if val != val:
+            assert st == 4 and torch.isnan(lg[bad_trial]).all() and torch.isnan(pr[bad_trial]).all(), (st, lg[bad_trial])
+        else:
+            # Inf * w = +-Inf saturates the gates (finite h, as in the reference) unless a product meets 0 or an opposite Inf -> NaN;
+            # either way: no finite garbage out of a masked NaN -- a finite answer must come with a clean status
+            assert torch.isnan(lg[bad_trial]).all() == (st == 4), (st, lg[bad_trial])
+        # the facade: NaN probabilities are a result here (the reference returns them too), not a time-out
+        m._last_seq_ws = ws
+        _raise_on_poison(m, pr.cpu().numpy(), "predict")
+    # a healthy evaluation on the same workspace is clean again: the non-finite bit is per evaluation
+    lg, _ = ops.seq_infer(spec, flat, xt, ws)
+    assert ops.seq_status(ws) == 0 and torch.equal(lg, clean)
+
+    # ---- training on a batch with one NaN trial: NaN loss / gradients as in the reference, the guarded update is skipped and reported
+    m.train()
+    tr = Trainer(m, lr=1e-2, seed=3)
+    tr.step(xt, yt)
+    tr.check()
+    before = flat.clone()
+    xb = xt.clone()
+    xb[5, 3, 2] = float("nan")
+    _, dt = timed(lambda: tr.step(xb, yt))
+    assert dt < 1.0, dt
+    assert tr.scan_status() == 4
+    assert torch.equal(flat, before), "a NaN gradient must not be applied"
+    assert not torch.isfinite(tr.grads).all()
+    with pytest.raises(nsd.NsdError, match="non-finite"):
+        tr.check()
+    tr.step(xt, yt)                                             # not sticky: the next healthy step trains on
+    tr.check()
+    assert not torch.equal(flat, before) and torch.isfinite(flat).all()
+    m.eval()
+
+    # ---- an Inf / a NaN in one recurrent weight: every trial's logits are NaN, at once
+    for name, val in (("lstm.weight_hh_l0", float("inf")), ("lstm.weight_ih_l1", float("nan"))):
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd[name][3, 1] = val
+        m2 = nsd.EEG_LSTM(8, H, L, K, dropout=0.5, precision="bf16", bidirectional=D == 2).to(dev).eval()
+        m2.load_state_dict(sd, strict=True)
+        (lg, pr), dt = timed(lambda: ops.seq_infer(spec, m2.flat_parameters(), xt, ws))
+        st = ops.seq_status(ws)
+        assert dt < 0.5 and st == 4 and torch.isnan(lg).all() and torch.isnan(pr).all(), (name, dt, st)
 
 
 def test_large_batches_at_small_hidden_sizes_take_the_layer_by_layer_scans(nsd, dev):

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-if [ "$CFG" = "cfg2" ] || [ "$CFG" = "cfg4" ]; then LONG="--steps 200 --warmup 50"; SHORT="--steps 4 --warmup 2 --preheat-steps 4"; else LONG="--steps 10 --warmup 3"; SHORT="--steps 2 --warmup 1 --preheat-steps 1"; fi
+if [ "$CFG" = "cfg2" ] || [ "$CFG" = "cfg4" ]; then LONG="--steps 200 --warmup 50"; SHORT="--steps 4 --warmup 2 --preheat-steps 4"; else LONG="--steps 40 --warmup 5"; SHORT="--steps 2 --warmup 1 --preheat-steps 1"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --config $CFG $LONG --no-cpu-baseline --no-kernel-timing > $OUT.trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --config $CFG $SHORT --no-cpu-baseline --no-kernel-timing > $OUT.fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --config $CFG $SHORT --no-cpu-baseline --no-kernel-timing > $OUT.write.log 2>&1

@@ -41,7 +41,24 @@ def counters(sub, name):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+def short(kernel_name):
+    return kernel_name.replace("(anonymous namespace)::", "").replace("void ", "").split("<")[0].split("(")[0]
+
+
+def rocprof_averages():
+    """Average launch duration per kernel (us) from the kernel-trace pass of the PRODUCT library, instantiations of one template pooled
+    by launch count -- what bench.py quotes beside its live HIP-event figure."""
+    stats = sorted(glob.glob(os.path.join(base, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    if stats:
+        for r in csv.DictReader(open(stats[-1])):
+            tot[short(r["Name"])] += float(r["TotalDurationNs"])
+            n[short(r["Name"])] += int(r["Calls"])
+    return {k: tot[k] / n[k] / 1e3 for k in tot if n[k]}
+
+
 fetch, write = counters("fetch", "FETCH_SIZE"), counters("write", "WRITE_SIZE")
+avg_us = rocprof_averages()
 out = {"workload": f"bench.py --config {config} (B={cfg['B']}, T={cfg['T']}) on one MI355X", "config": config, "B": cfg["B"], "T": cfg["T"],
        "source_sha256": bench.kernel_source_hash(cfg["precision"]),
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_run.sh); FETCH_SIZE doubled per "
@@ -52,6 +69,8 @@ for k in sorted(set(fetch) | set(write)):
         continue
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     e = {"FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1), "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
+    if k in avg_us:
+        e["rocprof_avg_us"] = round(avg_us[k], 2)
     if k in ALG:
         e["algorithmic_bytes_per_launch"] = ALG[k]
         e["traffic_over_algorithmic"] = round(e["hbm_bytes_per_launch_corrected"] / ALG[k], 2)
