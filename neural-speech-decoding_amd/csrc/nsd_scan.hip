@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const ScanFwdArgs a) {
     bool wbad = false;                                          // (W_hh . h_{-1} is skipped at s = 0: a non-finite row is NaN at once in the reference)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wbad = wbad || frag_nonfinite(w[ks]);
+    wbad = __any(wbad);                                         // (a lane holds a weight ROW; the row acts on every trial = every lane of the wave)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         poison[nt] = wbad ? 0x7FC07FC0u : 0u;

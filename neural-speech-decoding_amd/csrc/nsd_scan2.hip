@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
         bool wbad = false;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wbad = wbad || frag_nonfinite(w0[ks]);
+        wbad = __any(wbad);                                     // (a lane holds a weight ROW; the row acts on every trial = every lane of the wave)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) poison[nt] = wbad ? 0x7FC07FC0u : 0u;
     }
