@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void scan2_fwd_kernel(const Scan2FwdArgs a) {
     // keep / drop bit of the unit's dropout multiplier (the multiplied copy layer 1 reads is rebuilt by the consumer, bit-identically).
     // A consumer simply loads its granules until every tag is the expected one: one L2 round trip behind the slowest producer's
     // store, where "stores -> drain -> flag -> poll -> loads" was three (round 2: ~3 800 of a step's ~9 900 cycles were protocol).
-    // A lane's 16 bytes are written by one store instruction and read by one load: they arrive together.  The slots start with the
+    // A lane's 16 bytes are written by one store instruction and read by one load: they arrive together -- measured, not assumed:
+    // tools/micro/granule_litmus.hip, profiles/r04_granule_litmus.md (1.6e9 observations of granules being rewritten under the loads,
+    // in both exchange modes and across XCDs: no torn granule, no torn 8-byte halves).  The slots start with the
     // tag their first writer will NOT use (the workspace may hold a previous launch's granules), drained before the start barrier.
     // NON-FINITE h (a NaN / Inf window, diverged or NaN weights: torch's nn.LSTM of lstm_eeg_model.py:34 propagates them) has bit 14
     // set by itself -- 0x7FC0, 0x7F80 -- and would read as a wrong tag (a consumer spinning to the time-out) or, masked, as 1.5.  A
