@@ -96,7 +96,7 @@ def recorded_traffic(config: str, precision: str, kernel: str, B: int, T: int):
         if j.get("config") != config or j.get("B") != B or j.get("T") != T:
             continue
         if j.get("source_sha256") != want:
-            best = best or (None, f"{os.path.basename(p)} was measured on other kernel sources: not quoted")
+            best = best or (None, f"{os.path.basename(p)} was measured on other kernel sources: not quoted", None)
             continue
         e = j.get("kernels", {}).get(kernel)
         if e:

@@ -24,5 +24,8 @@ extern "C" {
 // 5 head, 6 head parameter gradients, 7 operand preparation.
 int nsd_seq_profile(int32_t enable);
 int nsd_seq_profile_read(int32_t kind, float *total_ms, int32_t *count);
+// Pin the H = 48 forward instantiation of the fp32 fast path: 1 / 2 / 4 trials per workgroup (4 = nsd_lstm2_fwd48x4.hip where it
+// applies), 0 = the product's own choice.  Process-wide; tests compare the instantiations on the same inputs.
+int nsd_diag_force_fwd48(int32_t nb);
 }
 #endif

@@ -15,6 +15,7 @@
 //     handles t), so there is exactly ONE workgroup barrier per time step.
 #include <stdlib.h>
 #include "nsd_args.h"
+#include "nsd_diag.h"
 
 
 template <int H, int NB>
@@ -492,6 +493,22 @@ __global__ __launch_bounds__(8 * H) void lstm2_bwd_kernel(Lstm2BwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
+constexpr int X4_MIN_B = 384;        // training batch from which the four-trial forward kernel is used (H = 48)
+
+// Which H = 48 forward instantiation a launch takes is a pure function of the launch in the product library.  The diagnostic twin
+// (libnsd_hip_diag.so: this file compiled with -DNSD_DIAG=1) can pin it -- 1 / 2 / 4 trials per workgroup, 0 = automatic -- so that
+// tests compare the instantiations on the same inputs; the product has neither the entry point nor an environment hook.
+#if NSD_DIAG
+static int g_force_fwd48 = 0;
+extern "C" int nsd_diag_force_fwd48(int32_t nb) {
+    if (nb != 0 && nb != 1 && nb != 2 && nb != 4) { nsd_set_error("nsd_diag_force_fwd48: 0, 1, 2 or 4"); return NSD_E_INVALID; }
+    g_force_fwd48 = nb;
+    return NSD_OK;
+}
+static int nsd_diag_forced_fwd48() { return g_force_fwd48; }
+#else
+static int nsd_diag_forced_fwd48() { return 0; }
+#endif
 static int pick_nb(int B) {
     const int cus = nsd_num_cus();
     if (B <= cus) return 1;
@@ -537,12 +554,18 @@ int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st) {
     if (grid <= 0) return NSD_OK;
     switch (H) {
     case 32: launch_fwd_h<32>(a, nb, grid, st); break;
-    case 48: {   // role-split kernel (nsd_lstm2_fwd48.hip), one workgroup per CU, batches loop.  One trial per workgroup while that leaves
-                 // CUs idle or barely covers them (latency is all that counts), two trials per workgroup in lock step once every CU
-                 // has at least two trials to work on (training only: the inference tail is built for one)
+    case 48: {   // role-split kernels, one workgroup per CU, batches loop:
+                 //  * one trial per workgroup (nsd_lstm2_fwd48.hip) while that leaves CUs idle or barely covers them -- latency is all
+                 //    that counts -- and for inference (the pooling / head tail is built for one trial);
+                 //  * FOUR trials per workgroup with the gate products on the matrix pipe (nsd_lstm2_fwd48x4.hip) for training batches
+                 //    from X4_MIN_B trials on: a 4-trial step costs about what 1.3 one-trial steps cost, so 64+ CUs of four beat 256 of one
+                 //    as soon as the batch is a little over one trial per CU;
+                 //  * two trials per workgroup in lock step (nsd_lstm2_fwd48.hip) where the four-trial kernel does not apply (residual
+                 //    extension) and every CU has at least two trials.
         const int cus = nsd_num_cus();
-        const char *env_nb = getenv("NSD_FWD48_NB");            // test hook (read per launch): 1 / 2 forces the instantiation
-        const int force_nb = env_nb ? atoi(env_nb) : 0;
+        const int force_nb = nsd_diag_forced_fwd48();           // 0 in the product library (diagnostic build: nsd_diag_force_fwd48)
+        const bool x4 = nsd_lstm2_fwd48x4_ok(a) && (force_nb ? force_nb == 4 : a.B >= X4_MIN_B);
+        if (x4) { const int ngrp4 = (a.B + 3) / 4; return nsd_lstm2_fwd48x4_launch(a, ngrp4 < cus ? ngrp4 : cus, st); }
         const bool two = force_nb ? force_nb == 2 : a.B >= 2 * cus;
         if (two && !a.logits_out) { const int ngrp2 = (a.B + 1) / 2; return nsd_lstm2_fwd48_launch(a, 2, ngrp2 < cus ? ngrp2 : cus, st); }
         return nsd_lstm2_fwd48_launch(a, 1, a.B < cus ? a.B : cus, st);

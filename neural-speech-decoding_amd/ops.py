@@ -125,6 +125,15 @@ def set_seq_diag_flags(l2_exchange: bool = True, spread_groups: bool = False, fu
                         | (0 if fused_layers else _lib.NSD_DIAG_FLAG_NO_FUSED_LAYERS) | (_lib.NSD_DIAG_FLAG_LOSE_MEMBER if lose_member else 0))
 
 
+def force_fwd48(nb: int) -> None:
+    """Diagnostic build only (inside `with _lib.diagnostic_library():`): pin the H = 48 forward instantiation of the fp32 fast path
+    to 1 / 2 / 4 trials per workgroup (4 = the matrix-pipe kernel where it applies), 0 = the product's own choice.  Process-wide
+    state of the DIAGNOSTIC library: reset it to 0 before leaving the block."""
+    if not _lib.diag_active():
+        raise NsdError("force_fwd48: the instantiation can be pinned in the diagnostic build only: use `with _lib.diagnostic_library():`")
+    _lib.check(_lib.lib().nsd_diag_force_fwd48(int(nb)), "nsd_diag_force_fwd48")
+
+
 def set_gemm_bf16(on: bool) -> None:
     """Large-H batched path only (NSD_FLAG_BF16): GEMM operands rounded to bf16 (fp32 accumulate / storage).  Off by default."""
     global _extra_flags

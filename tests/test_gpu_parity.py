@@ -922,13 +922,14 @@ def test_train_cli_kfold_reports_mean_and_sd_without_epoch_selection(nsd, dev, t
 # two trials per workgroup in the H = 48 forward kernel (training batches with at least two trials per CU)
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,T,residual", [(2, 5, False), (7, 33, False), (9, 250, True), (513, 40, False), (1024, 250, False)])
-def test_two_trials_per_workgroup_forward_equals_the_one_trial_kernel_bitwise(nsd, dev, ref_state, B, T, residual, monkeypatch):
+def test_two_trials_per_workgroup_forward_equals_the_one_trial_kernel_bitwise(nsd, dev, ref_state, B, T, residual):
     """lstm2_fwd48_kernel<2> advances two trials in lock step through the same roles (both layers, the input projection, the save
     ring, attention pooling along the recurrence, the fused head / CE / head backward and the tail, in-kernel random streams):
     every number it leaves -- logits, the whole training workspace (activations, alpha, dscore, dpooled, loss, head slabs) and the
     gradients computed from it -- equals the one-trial instantiation's bit for bit, for odd batches too (a padding trial in the
-    last group), with explicit masks, with the streams drawn in the kernel, and through the two-launch (unfused head) route."""
-    from nsd_amd import ops
+    last group), with explicit masks, with the streams drawn in the kernel, and through the two-launch (unfused head) route.
+    (The instantiation is pinned through the diagnostic twin of the library: the product has no such hook.)"""
+    from nsd_amd import _lib, ops
     spec = ops.ModelSpec()
     flat = _t(orc.flatten_state(ref_state, D), dev)
     x, y = _t(synth_x(B, T, seed=B + T), dev), _t(synth_labels(B, seed=B + T).astype(np.int32), dev)
@@ -937,32 +938,87 @@ def test_two_trials_per_workgroup_forward_equals_the_one_trial_kernel_bitwise(ns
     variants = [dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh, fused_head=True), dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh, fused_head=False)]
     if ops.rng_path(spec, B, T) and not residual:
         variants.append(dict(rng=rng))
-    for kw in variants:
-        res = {}
-        for nb in ("1", "2"):
-            monkeypatch.setenv("NSD_FWD48_NB", nb)
-            ws = ops.new_workspace(spec, B, T, dev)
-            ws.fill_(float("nan"))
-            logits = torch.full((B, spec.K), float("nan"), device=dev)
-            grads = torch.empty_like(flat)
-            ops.train_step_grads(spec, flat, x, ws, y, logits, grads, residual=residual, **kw)
-            torch.cuda.synchronize()
-            res[nb] = (logits.clone(), grads.clone(), ws.clone())
-        monkeypatch.delenv("NSD_FWD48_NB")
-        (l1, g1, w1), (l2, g2, w2) = res["1"], res["2"]
-        assert torch.isfinite(l1).all() and torch.isfinite(g1).all()
-        assert torch.equal(l1, l2), (kw.keys(), (l1 - l2).abs().max().item())
-        assert torch.equal(g1, g2), (kw.keys(), (g1 - g2).abs().max().item())
-        same = (w1 == w2) | (torch.isnan(w1) & torch.isnan(w2))            # (regions neither kernel writes stay NaN in both)
-        assert bool(same.all()), int((~same).sum().item())
-    # and against the oracle on the explicit-mask route, through the two-trial kernel
-    if B <= 600:
-        monkeypatch.setenv("NSD_FWD48_NB", "2")
-        flat_np = orc.flatten_state(ref_state, D)
-        xn, yn = synth_x(B, T, seed=B + T), synth_labels(B, seed=B + T)
-        dln, sln, dhn = counter_masks(B, T, 48, 32, seed=3 * B + T)
-        loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, xn, yn, D, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn, residual=residual)
-        loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, xn, yn, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn, residual=residual)
-        monkeypatch.delenv("NSD_FWD48_NB")
-        assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
-        _grad_close(grads, g_ref, D, rtol=3e-4)
+    with _lib.diagnostic_library():
+        try:
+            for kw in variants:
+                res = {}
+                for nb in (1, 2):
+                    ops.force_fwd48(nb)
+                    ws = ops.new_workspace(spec, B, T, dev)
+                    ws.fill_(float("nan"))
+                    logits = torch.full((B, spec.K), float("nan"), device=dev)
+                    grads = torch.empty_like(flat)
+                    ops.train_step_grads(spec, flat, x, ws, y, logits, grads, residual=residual, **kw)
+                    torch.cuda.synchronize()
+                    res[nb] = (logits.clone(), grads.clone(), ws.clone())
+                (l1, g1, w1), (l2, g2, w2) = res[1], res[2]
+                assert torch.isfinite(l1).all() and torch.isfinite(g1).all()
+                assert torch.equal(l1, l2), (kw.keys(), (l1 - l2).abs().max().item())
+                assert torch.equal(g1, g2), (kw.keys(), (g1 - g2).abs().max().item())
+                same = (w1 == w2) | (torch.isnan(w1) & torch.isnan(w2))            # (regions neither kernel writes stay NaN in both)
+                assert bool(same.all()), int((~same).sum().item())
+            # and against the oracle on the explicit-mask route, through the two-trial kernel
+            if B <= 600:
+                ops.force_fwd48(2)
+                flat_np = orc.flatten_state(ref_state, D)
+                xn, yn = synth_x(B, T, seed=B + T), synth_labels(B, seed=B + T)
+                dln, sln, dhn = counter_masks(B, T, 48, 32, seed=3 * B + T)
+                loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, xn, yn, D, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn, residual=residual)
+                loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, xn, yn, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn, residual=residual)
+                assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
+                _grad_close(grads, g_ref, D, rtol=3e-4)
+        finally:
+            ops.force_fwd48(0)
+
+
+@pytest.mark.parametrize("B,T", [(4, 5), (7, 33), (33, 16), (64, 250), (130, 1), (9, 625)])
+def test_four_trials_per_workgroup_forward_on_the_matrix_pipe(nsd, dev, ref_state, B, T):
+    """lstm2_fwd48x4_kernel (nsd_lstm2_fwd48x4.hip): four trials per workgroup, the gate products as v_mfma_f32_4x4x1 with the
+    trials as the N dimension, cells in the lanes that own the accumulators, activations saved by those lanes, attention pooling of
+    two trials per pooling wave, the fused head's tail.  Its sums run in a different order than the one-trial kernel's, so it is held to
+    the ORACLE (logits 1e-4, gradients 3e-4 of each tensor's largest element) and to the one-trial kernel's workspace within 2e-5 --
+    for batches that are not a multiple of four (padding trials), T = 1, T not a multiple of the 16-step staging chunk / the 8-step
+    pooling chunk, the recorded windows' 625 steps; explicit masks (fused and unfused head) and the streams drawn in the kernel (whose
+    multipliers and RReLU slopes must be the one-trial kernel's bit for bit: same gradients to 1e-5)."""
+    from nsd_amd import _lib, ops
+    spec = ops.ModelSpec()
+    flat_np = orc.flatten_state(ref_state, D)
+    flat = _t(flat_np, dev)
+    xn, yn = synth_x(B, T, seed=B + T), synth_labels(B, seed=B + T)
+    x, y = _t(xn, dev), _t(yn.astype(np.int32), dev)
+    dln, sln, dhn = counter_masks(B, T, 48, 32, seed=3 * B + T)
+    dl, sl, dh = _t(dln, dev), _t(sln, dev), _t(dhn, dev)
+    rng = dict(seed=0x1234ABCD, base_stream=44, p_lstm=0.6, p_head=0.6)
+    variants = [dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh, fused_head=True), dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh, fused_head=False)]
+    if ops.rng_path(spec, B, T):
+        variants.append(dict(rng=rng))
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, xn, yn, D, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn)
+    with _lib.diagnostic_library():
+        try:
+            for vi, kw in enumerate(variants):
+                res = {}
+                for nb in (1, 4):
+                    ops.force_fwd48(nb)
+                    ws = ops.new_workspace(spec, B, T, dev)
+                    ws.fill_(float("nan"))
+                    logits = torch.full((B, spec.K), float("nan"), device=dev)
+                    grads = torch.empty_like(flat)
+                    ops.train_step_grads(spec, flat, x, ws, y, logits, grads, **kw)
+                    torch.cuda.synchronize()
+                    res[nb] = (logits.clone(), grads.clone(), ws.clone())
+                (l1, g1, w1), (l4, g4, w4) = res[1], res[4]
+                assert torch.isfinite(l4).all() and torch.isfinite(g4).all(), kw.keys()
+                assert (l1 - l4).abs().max().item() < 2e-5, (kw.keys(), (l1 - l4).abs().max().item())
+                assert (g1 - g4).abs().max().item() <= 1e-5 * max(g1.abs().max().item(), 1e-6) + 1e-7, (kw.keys(), (g1 - g4).abs().max().item())
+                # the same regions of the workspace are written (NaN elsewhere in both), with the same values to rounding
+                assert bool((torch.isnan(w1) == torch.isnan(w4)).all()), int((torch.isnan(w1) != torch.isnan(w4)).sum().item())
+                wd = torch.where(torch.isnan(w1), torch.zeros_like(w1), (w1 - w4).abs())
+                assert wd.max().item() < 2e-5, wd.max().item()
+                if vi < 2:                                        # explicit masks: the oracle saw the same ones
+                    assert np.abs(l4.cpu().numpy() - fw["logits"]).max() < LOGIT_TOL
+            ops.force_fwd48(4)
+            loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, xn, yn, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn)
+            assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
+            _grad_close(grads, g_ref, D, rtol=3e-4)
+        finally:
+            ops.force_fwd48(0)
