@@ -108,11 +108,7 @@ static nsd_ws_layout make_ws(const nsd_dims *d, bool have_device) {
 // NSD_ABLATE timing switches.  The shipped library has neither the symbol nor the getenv.
 #if NSD_PROFILE || NSD_ABLATE_HOOKS
 static long long *g_dbg = nullptr;
-static int ablate_mask() {
-    static int mask = -1;
-    if (mask < 0) { const char *e = getenv("NSD_ABLATE"); mask = e ? atoi(e) : 0; }
-    return mask;
-}
+static int ablate_mask() { const char *e = getenv("NSD_ABLATE"); return e ? atoi(e) : 0; }     // (read per launch: tools/kbench.py sweeps it)
 extern "C" int nsd_debug_profile_buffer(void *p) { g_dbg = (long long *)p; return NSD_OK; }
 #else
 static long long *const g_dbg = nullptr;

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(8 * H) void lstm2_bwd_kernel(Lstm2BwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-constexpr int X4_MIN_B = 384;        // training batch from which the four-trial forward kernel is used (H = 48)
+constexpr int X4_MIN_B = 768;        // training batch from which the four-trial forward kernel is used (H = 48): tools/x4_sweep.py
 
 // Which H = 48 forward instantiation a launch takes is a pure function of the launch in the product library.  The diagnostic twin
 // (libnsd_hip_diag.so: this file compiled with -DNSD_DIAG=1) can pin it -- 1 / 2 / 4 trials per workgroup, 0 = automatic -- so that
@@ -558,8 +558,7 @@ int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st) {
                  //  * one trial per workgroup (nsd_lstm2_fwd48.hip) while that leaves CUs idle or barely covers them -- latency is all
                  //    that counts -- and for inference (the pooling / head tail is built for one trial);
                  //  * FOUR trials per workgroup with the gate products on the matrix pipe (nsd_lstm2_fwd48x4.hip) for training batches
-                 //    from X4_MIN_B trials on: a 4-trial step costs about what 1.3 one-trial steps cost, so 64+ CUs of four beat 256 of one
-                 //    as soon as the batch is a little over one trial per CU;
+                 //    from X4_MIN_B trials on (three or more trials per CU: a four-trial step costs about what 2.3 one-trial steps cost);
                  //  * two trials per workgroup in lock step (nsd_lstm2_fwd48.hip) where the four-trial kernel does not apply (residual
                  //    extension) and every CU has at least two trials.
         const int cus = nsd_num_cus();

@@ -24,7 +24,8 @@
 //   g 1, 2, q 2  "pool"   fused train head: attention pooling of two trials each as an online softmax along the recurrence,
 //                         then LayerNorm / fc / CE / dense backward; otherwise spare
 //   (116 / 116 / 116 / 108 MFMAs per step and SIMD.)  The saved activations leave from the lanes that own them: the four gates of a
-//   cell are 16 contiguous bytes of gact[b][t][unit][4] -- buffer stores with a scalar time offset, no saver wave, no LDS ring.
+//   cell are 16 contiguous bytes of gact[b][t][unit][4] -- buffer stores with a scalar time offset, issued one at a time between the
+//   MFMAs of the NEXT step (no saver wave, no LDS ring: see "Pending").
 // After the last step: the tail of nsd_lstm2_fwd48.hip's fused train head (alpha, dL/dscore, d attn.weight), one trial at a time.
 #include "nsd_args.h"
 #include "nsd_prof.h"
@@ -66,6 +67,10 @@ struct XSmem {
 // arguments they keep live push ~330 scalar registers into spills -- and a callee sees this object as LDS, not as a generic pointer)
 __shared__ __align__(16) XSmem g_sm;
 
+// The helper roles and the tail are real function calls and get a reference to the kernel's argument block (hipcc keeps a copy of
+// the by-value parameter in scratch for that).  Each of them copies the block into a LOCAL first: the step barrier is an asm
+// statement with a memory clobber, and a helper that re-read one field per step from scratch arrived ~1 000 cycles late at EVERY
+// step barrier (measured: the stage wave -- the whole workgroup waited for it).
 constexpr float KC = -2.f * LOG2E_F;
 constexpr float INV_KC = 1.f / KC;
 __host__ __device__ constexpr float gate_scale(const int g) { return g == 2 ? -2.f * LOG2E_F : -LOG2E_F; }
@@ -99,6 +104,13 @@ __device__ __forceinline__ void mfma_cols(const float (&w)[H], const f32x4 (&bv)
 
 struct CellOut { float i, f, g, o, c, h; };
 // acc: exp2 arguments of the four gates (weights and biases are pre-multiplied by the gate's exp2 scale); cK = KC * c (updated)
+__device__ __forceinline__ CellOut cell4_abl(const f32x4 acc, float &cK) {      // timing experiments only: no transcendentals
+    CellOut o;
+    o.i = acc[0]; o.f = acc[1]; o.g = acc[2]; o.o = acc[3];
+    cK = fmaf(o.f, cK, o.i);
+    o.c = cK; o.h = o.o * 1e-3f;
+    return o;
+}
 __device__ __forceinline__ CellOut cell4(const f32x4 acc, float &cK) {
     const float ri = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0]));
     const float rf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1]));
@@ -114,15 +126,18 @@ __device__ __forceinline__ CellOut cell4(const f32x4 acc, float &cK) {
     return o;
 }
 
+#ifndef NSD_X4_ST_AUX
+#define NSD_X4_ST_AUX 2          // nt: streamed out, not kept in the L2 (measured: -33 us of 349 per launch at B = 1024)
+#endif
 __device__ __forceinline__ void st_b128(const rsrc_t r, const unsigned voff, const unsigned soff, const float a, const float b, const float c, const float d) {
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)}, r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)}, r, (int)voff, (int)soff, NSD_X4_ST_AUX);
 }
 __device__ __forceinline__ void st_b32(const rsrc_t r, const unsigned voff, const unsigned soff, const float a) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), r, (int)voff, (int)soff, NSD_X4_ST_AUX);
 }
 constexpr unsigned VOFF_DROP = 0x80000000u;                        // beyond every descriptor's range: the store of a padding trial is dropped
 
-__device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a, const int tid, const int b0);
+__device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a_in, const int tid, const int b0);
 
 // One barrier per macro step.  Raw s_barrier behind lgkmcnt(0): the step's LDS writes are complete, the asynchronous buffer stores of
 // the saved activations are NOT waited for (__syncthreads() would drain vmcnt every step).
@@ -141,11 +156,21 @@ __device__ __forceinline__ void xstep_barrier(Prof &p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// What a cell lane leaves for the backward pass goes out from the lane itself (the four gates of a cell are 16 contiguous bytes of
+// gact[b][t][unit][4]) -- but not where it is formed.  Issued behind the cell, the step's 21 store instructions of the six cell waves hit
+// the CU's one vector-memory path in a burst and every wave stood ~130 cycles per instruction IN FRONT of the step barrier (0.25 us
+// of a 1.04-us step; records through LDS + saver waves cost the same in LDS traffic: both measured, profiles/r04_x4_forward.md).
+// So a step's values wait in registers and leave one instruction at a time between the MFMAs of the NEXT step, where the wave's issue
+// slots are idle anyway; non-temporal: the backward pass reads them after the whole forward, nothing of them should stay in the L2.
+// ------------------------------------------------------------------------------------------------
+struct Pending { float i, f, g, o, h, c, x; unsigned so4, so16; bool on; };   // x: in1 (layer 0) / unused
+
+// ------------------------------------------------------------------------------------------------
 // layer 0
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, XSmem &sm, const int g, const int lane, const int n_steps, const int grp) {
     const int blk = lane >> 2, j = lane & 3, r = lane >> 4;
-    const int unit = 16 * g + blk, T = a.T, B = a.B, C = a.C;
+    const int unit = 16 * g + blk, T = a.T, C = a.C;
     const int row = (lane & 3) * H + unit;                          // A operand: gate (lane & 3) of this block's unit
     const float gs = gate_scale(lane & 3);
     float wx[8], wh[H];
@@ -156,14 +181,16 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, XSmem &sm, const 
     f32x4 bias;
 #pragma unroll
     for (int i = 0; i < 4; ++i) bias[i] = gate_scale(i) * (a.b_ih0[i * H + unit] + a.b_hh0[i * H + unit]);
-    const long bth4 = (long)B * T * H * 4;
+    const long bth4 = (long)a.B * T * H * 4;
     const rsrc_t r_g = make_rsrc(a.gact0, bth4 * 4), r_h = make_rsrc(a.hseq0, bth4), r_c = make_rsrc(a.cseq0, bth4), r_i = make_rsrc(a.inseq, bth4);
     Prof prof = prof_init(a.dbg);
     {
-        const int b = grp * NTR + j;
         float cK = 0.f;
-        const unsigned vo4 = b < B ? (unsigned)(((size_t)b * T * H + unit) * 4) : VOFF_DROP;
-        const unsigned vo16 = b < B ? vo4 * 4u : VOFF_DROP;
+        const int bt = grp * NTR + j;
+        const unsigned vo4 = bt < a.B ? (unsigned)(((size_t)bt * T * H + unit) * 4) : VOFF_DROP;
+        const unsigned vo16 = bt < a.B ? vo4 * 4u : VOFF_DROP;
+        Pending pd;
+        pd.on = false; pd.i = pd.f = pd.g = pd.o = pd.h = pd.c = pd.x = 0.f; pd.so4 = pd.so16 = 0u;
         // zero initial states: h0_{-1} lives in slot 3 of v0, h1_{-1} in slot 15 of the h1 ring (the whole ring: the pooling waves
         // multiply rows beyond T by zero weights, which must not meet stale NaNs)
         for (int e = g * 64 + lane; e < NTR * VS; e += 192) (&sm.v0[3][0][0])[e] = 0.f;
@@ -173,31 +200,61 @@ __device__ __forceinline__ void l0_role(const Lstm2FwdArgs &a, XSmem &sm, const 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int m = m0 + k;
-                if (m < T) {
+                prof_mark<-1, false>(prof);
+                const bool st_on = pd.on && !ablated(a.ablate, 2048);
+                if (m < T && !ablated(a.ablate, 1048576)) {
                     const int tl = m & (XCH - 1), cb = (m >> 4) & 1;
                     const f32x4 xv = *reinterpret_cast<const f32x4 *>(&sm.xs[cb][j][tl][4 * (r & 1)]);
                     const float mk = sm.ms[cb][j][tl][unit];
                     f32x4 hv[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) hv[c] = *reinterpret_cast<const f32x4 *>(&sm.v0[(k + 3) & 3][j][16 * c + 4 * r]);
+                    for (int c = 0; c < 3; ++c) hv[c] = ablated(a.ablate, 524288) ? f32x4{mk, mk, mk, mk} : *reinterpret_cast<const f32x4 *>(&sm.v0[(k + 3) & 3][j][16 * c + 4 * r]);
+                    prof_mark<0, true>(prof);        // seg0: LDS operands arrived
                     f32x4 acc0 = bias, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         if (kk & 1) acc1 = mfma_row(kk >> 2, wx[kk], xv[kk & 3], acc1); else acc0 = mfma_row(kk >> 2, wx[kk], xv[kk & 3], acc0);
                     }
-                    mfma_cols<0, H>(wh, hv, acc0, acc1);
-                    const CellOut o = cell4(acc0 + acc1, cK);
+                    if (!ablated(a.ablate, 4096)) {
+                        mfma_cols<0, 10>(wh, hv, acc0, acc1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st_on) st_b128(r_g, vo16, pd.so16, pd.i, pd.f, pd.g, pd.o);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_cols<10, 22>(wh, hv, acc0, acc1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st_on) st_b32(r_h, vo4, pd.so4, pd.h);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_cols<22, 34>(wh, hv, acc0, acc1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st_on) st_b32(r_c, vo4, pd.so4, pd.c);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_cols<34, 46>(wh, hv, acc0, acc1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st_on) st_b32(r_i, vo4, pd.so4, pd.x);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_cols<46, H>(wh, hv, acc0, acc1);
+                    }
+                    prof_mark<1, false>(prof);       // seg1: 56 MFMAs issued
+                    const CellOut o = ablated(a.ablate, 16384) ? cell4_abl(acc0 + acc1, cK) : cell4(acc0 + acc1, cK);
                     const float in1 = o.h * mk;
                     sm.v0[k][j][unit] = o.h;
                     sm.vm[k][j][unit] = in1;
-                    const unsigned so4 = (unsigned)m * (H * 4), so16 = (unsigned)m * (H * 16);
-                    st_b128(r_g, vo16, so16, o.i, o.f, o.g, o.o);
-                    st_b32(r_h, vo4, so4, o.h);
-                    st_b32(r_c, vo4, so4, o.c);
-                    st_b32(r_i, vo4, so4, in1);
+                    prof_mark<2, true>(prof);        // seg2: MFMAs retired, cell, h in LDS
+                    pd.i = o.i; pd.f = o.f; pd.g = o.g; pd.o = o.o; pd.h = o.h; pd.c = o.c; pd.x = in1;
+                    pd.so4 = (unsigned)m * (H * 4); pd.so16 = (unsigned)m * (H * 16); pd.on = true;
+                } else {
+                    if (st_on) {                     // (the last step's values)
+                        st_b128(r_g, vo16, pd.so16, pd.i, pd.f, pd.g, pd.o);
+                        st_b32(r_h, vo4, pd.so4, pd.h); st_b32(r_c, vo4, pd.so4, pd.c); st_b32(r_i, vo4, pd.so4, pd.x);
+                    }
+                    pd.on = false;
                 }
                 xstep_barrier(prof);
             }
+        }
+        if (pd.on && !ablated(a.ablate, 2048)) {    // (T a multiple of the step padding: the last step's values are still waiting)
+            st_b128(r_g, vo16, pd.so16, pd.i, pd.f, pd.g, pd.o);
+            st_b32(r_h, vo4, pd.so4, pd.h); st_b32(r_c, vo4, pd.so4, pd.c); st_b32(r_i, vo4, pd.so4, pd.x);
         }
     }
     prof_store(a.dbg, prof);
@@ -224,13 +281,17 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, XSmem &sm, const i
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int m = m0 + k;
-                if (m >= 1 && m <= T) {
+                prof_mark<-1, false>(prof);
+                if (m >= 1 && m <= T && !ablated(a.ablate, 1048576)) {
                     f32x4 iv[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) iv[c] = *reinterpret_cast<const f32x4 *>(&sm.vm[(k + 3) & 3][j][16 * c + 4 * r]);
+                    for (int c = 0; c < 3; ++c) iv[c] = ablated(a.ablate, 524288) ? bias : *reinterpret_cast<const f32x4 *>(&sm.vm[(k + 3) & 3][j][16 * c + 4 * r]);
+                    prof_mark<0, true>(prof);
                     f32x4 acc0 = bias, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    mfma_cols<0, KP>(wi, iv, acc0, acc1);
+                    if (!ablated(a.ablate, 4096)) mfma_cols<0, KP>(wi, iv, acc0, acc1);
+                    prof_mark<1, false>(prof);
                     *reinterpret_cast<f32x4 *>(&sm.pacc[k & 1][g][lane][0]) = acc0 + acc1;
+                    prof_mark<2, true>(prof);
                 }
                 xstep_barrier(prof);
             }
@@ -244,29 +305,33 @@ __device__ __forceinline__ void p_role(const Lstm2FwdArgs &a, XSmem &sm, const i
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, XSmem &sm, const int g, const int lane, const int n_steps, const int grp) {
     const int blk = lane >> 2, j = lane & 3, r = lane >> 4;
-    const int unit = 16 * g + blk, T = a.T, B = a.B;
+    const int unit = 16 * g + blk, T = a.T;
     const int row = (lane & 3) * H + unit;
     const float gs = gate_scale(lane & 3);
     float wt[H], wh[H];                                             // wt: columns KP.. of W_ih1 (the others are the P waves')
 #pragma unroll
     for (int k = 0; k < H; ++k) { wt[k] = k >= KP ? gs * a.w_ih1[(size_t)row * H + k] : 0.f; wh[k] = gs * a.w_hh1[(size_t)row * H + k]; }
-    const long bth4 = (long)B * T * H * 4;
+    const float *h1b = &sm.h1[0][j][4 * r];
+    const long bth4 = (long)a.B * T * H * 4;
     const rsrc_t r_g = make_rsrc(a.gact1, bth4 * 4), r_h = make_rsrc(a.hseq1, bth4), r_c = make_rsrc(a.cseq1, bth4);
     const rsrc_t r_t = make_rsrc(a.top ? a.top : a.hseq1, bth4);
     const bool save_top = a.top != nullptr;
-    const float *h1b = &sm.h1[0][j][4 * r];
     Prof prof = prof_init(a.dbg);
     {
-        const int b = grp * NTR + j;
         float cK = 0.f;
-        const unsigned vo4 = b < B ? (unsigned)(((size_t)b * T * H + unit) * 4) : VOFF_DROP;
-        const unsigned vo16 = b < B ? vo4 * 4u : VOFF_DROP;
+        const int bt = grp * NTR + j;
+        const unsigned vo4 = bt < a.B ? (unsigned)(((size_t)bt * T * H + unit) * 4) : VOFF_DROP;
+        const unsigned vo16 = bt < a.B ? vo4 * 4u : VOFF_DROP;
+        Pending pd;
+        pd.on = false; pd.i = pd.f = pd.g = pd.o = pd.h = pd.c = pd.x = 0.f; pd.so4 = pd.so16 = 0u;
         xstep_barrier(prof);
         for (int m0 = 0; m0 < n_steps; m0 += 4) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int m = m0 + k, t = m - 2;
-                if (t >= 0 && t < T) {
+                prof_mark<-1, false>(prof);
+                const bool st_on = pd.on && !ablated(a.ablate, 2048);
+                if (t >= 0 && t < T && !ablated(a.ablate, 1048576)) {
                     f32x4 acc0 = *reinterpret_cast<const f32x4 *>(&sm.pacc[(k + 1) & 1][g][lane][0]);     // P tile of step m - 1
                     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
                     f32x4 tv[3], hv[3];
@@ -274,19 +339,46 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, XSmem &sm, const 
                     tv[0] = tv[2]; tv[1] = tv[2];
                     const float *hp = h1b + ((t + HR - 1) & (HR - 1)) * (NTR * VS);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) hv[c] = *reinterpret_cast<const f32x4 *>(hp + 16 * c);
+                    for (int c = 0; c < 3; ++c) hv[c] = ablated(a.ablate, 524288) ? tv[2] : *reinterpret_cast<const f32x4 *>(hp + 16 * c);
+                    prof_mark<0, true>(prof);
                     mfma_cols<KP, H>(wt, tv, acc0, acc1);
-                    mfma_cols<0, H>(wh, hv, acc0, acc1);
-                    const CellOut o = cell4(acc0 + acc1, cK);
+                    if (!ablated(a.ablate, 4096)) {
+                        mfma_cols<0, 8>(wh, hv, acc0, acc1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st_on) st_b128(r_g, vo16, pd.so16, pd.i, pd.f, pd.g, pd.o);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_cols<8, 22>(wh, hv, acc0, acc1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st_on) st_b32(r_h, vo4, pd.so4, pd.h);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_cols<22, 36>(wh, hv, acc0, acc1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st_on) st_b32(r_c, vo4, pd.so4, pd.c);
+                        if (st_on && save_top) st_b32(r_t, vo4, pd.so4, pd.h);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_cols<36, H>(wh, hv, acc0, acc1);
+                    }
+                    prof_mark<1, false>(prof);
+                    const CellOut o = ablated(a.ablate, 16384) ? cell4_abl(acc0 + acc1, cK) : cell4(acc0 + acc1, cK);
                     (&sm.h1[0][0][0])[((t & (HR - 1)) * NTR + j) * VS + unit] = o.h;
-                    const unsigned so4 = (unsigned)t * (H * 4), so16 = (unsigned)t * (H * 16);
-                    st_b128(r_g, vo16, so16, o.i, o.f, o.g, o.o);
-                    st_b32(r_h, vo4, so4, o.h);
-                    st_b32(r_c, vo4, so4, o.c);
-                    if (save_top) st_b32(r_t, vo4, so4, o.h);
+                    prof_mark<2, true>(prof);
+                    pd.i = o.i; pd.f = o.f; pd.g = o.g; pd.o = o.o; pd.h = o.h; pd.c = o.c;
+                    pd.so4 = (unsigned)t * (H * 4); pd.so16 = (unsigned)t * (H * 16); pd.on = true;
+                } else {
+                    if (st_on) {
+                        st_b128(r_g, vo16, pd.so16, pd.i, pd.f, pd.g, pd.o);
+                        st_b32(r_h, vo4, pd.so4, pd.h); st_b32(r_c, vo4, pd.so4, pd.c);
+                        if (save_top) st_b32(r_t, vo4, pd.so4, pd.h);
+                    }
+                    pd.on = false;
                 }
                 xstep_barrier(prof);
             }
+        }
+        if (pd.on && !ablated(a.ablate, 2048)) {    // (T + 2 a multiple of the step padding: the last step's values are still waiting)
+            st_b128(r_g, vo16, pd.so16, pd.i, pd.f, pd.g, pd.o);
+            st_b32(r_h, vo4, pd.so4, pd.h); st_b32(r_c, vo4, pd.so4, pd.c);
+            if (save_top) st_b32(r_t, vo4, pd.so4, pd.h);
         }
     }
     prof_store(a.dbg, prof);
@@ -295,15 +387,19 @@ __device__ __forceinline__ void l1_role(const Lstm2FwdArgs &a, XSmem &sm, const 
 // ------------------------------------------------------------------------------------------------
 // stage wave: x and the dropout multipliers, one 16-step chunk ahead
 // ------------------------------------------------------------------------------------------------
+// (pointers that reach a called function through the argument block are generic to hipcc: a flat load counts in lgkmcnt as well, and
+// the step barrier's lgkmcnt(0) would sit out its HBM latency -- say what they are)
+typedef const __attribute__((address_space(1))) float *gfloat_p;
+typedef const __attribute__((address_space(1))) f32x4 *gf32x4_p;
 __device__ __forceinline__ float x_at(const Lstm2FwdArgs &a, const int b0, const int e, const int t0) {     // e in [0, NTR*XCH*8)
     const int n = e / (XCH * 8), tl = (e >> 3) & (XCH - 1), ch = e & 7;
     const int b = b0 + n, t = t0 + tl;
-    return (b < a.B && t < a.T && ch < a.C) ? a.x[((size_t)b * a.T + t) * a.C + ch] : 0.f;
+    return (b < a.B && t < a.T && ch < a.C) ? ((gfloat_p)a.x)[((size_t)b * a.T + t) * a.C + ch] : 0.f;
 }
 __device__ __forceinline__ float4 mask_at(const Lstm2FwdArgs &a, const int b0, const int e, const int t0) {  // e: float4 index in [0, NTR*XCH*12)
     const int n = e / (XCH * 12), rem = e - n * (XCH * 12), tl = rem / 12, q = rem - tl * 12;
     const int b = b0 + n, t = t0 + tl;
-    if (a.mask && b < a.B && t < a.T) return *reinterpret_cast<const float4 *>(a.mask + ((size_t)b * a.T + t) * H + 4 * q);
+    if (a.mask && b < a.B && t < a.T) { const f32x4 v = *(gf32x4_p)(a.mask + ((size_t)b * a.T + t) * H + 4 * q); return make_float4(v[0], v[1], v[2], v[3]); }
     return make_float4(1.f, 1.f, 1.f, 1.f);
 }
 // the multipliers of time step t for the four trials: 192 values, 3 per lane (same stream as nsd_train_masks: index (b*T + t)*48 + unit)
@@ -317,8 +413,9 @@ __device__ __forceinline__ void rng_row(const Lstm2FwdArgs &a, XSmem &sm, const 
         sm.ms[buf][n][tl][u] = mk;
     }
 }
-__device__ __attribute__((noinline)) void stage_role(const Lstm2FwdArgs &a, const int lane, const int n_steps, const int grp) {
+__device__ __attribute__((noinline)) void stage_role(const Lstm2FwdArgs &a_in, const int lane, const int n_steps, const int grp) {
     XSmem &sm = g_sm;
+    const Lstm2FwdArgs a = a_in;
     constexpr int XPL = NTR * XCH * 8 / 64;                          // 8 x floats per lane and chunk
     constexpr int MPL = NTR * XCH * 12 / 64;                         // 12 multiplier float4 per lane and chunk
     Prof prof = prof_init(a.dbg);
@@ -346,7 +443,7 @@ __device__ __attribute__((noinline)) void stage_role(const Lstm2FwdArgs &a, cons
             }
 #pragma unroll 1
             for (int k = 0; k < XCH; ++k) {
-                if (a.rng.on) rng_row(a, sm, b0, m0 + XCH + k, cb ^ 1, k, lane);
+                if (a.rng.on && !ablated(a.ablate, 8192)) rng_row(a, sm, b0, m0 + XCH + k, cb ^ 1, k, lane);
                 if (k == XCH - 1) {
 #pragma unroll
                     for (int q = 0; q < XPL; ++q) (&sm.xs[cb ^ 1][0][0][0])[lane + 64 * q] = xr[q];
@@ -488,8 +585,9 @@ __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, XSmem &sm, con
 }
 
 // what every wave does after the last step of a trial group when the head is fused
-__device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a, const int tid, const int b0) {
+__device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a_in, const int tid, const int b0) {
     XSmem &sm = g_sm;
+    const Lstm2FwdArgs a = a_in;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's h rows are in memory before the workgroup reads them back
     __syncthreads();                                                // ... and the pooling waves have left the four trials' dense-head results in LDS
 #pragma unroll 1
@@ -578,8 +676,9 @@ __device__ __forceinline__ void dense_head(const Lstm2FwdArgs &a, XSmem &sm, con
 // pooling wave `pw` (0 / 1) takes trials 2 pw and 2 pw + 1 of the group.  Chunk c of a trial (t = 8c .. 8c + 7) is complete in the
 // ring when macro step 8c + 9 has ended and is overwritten from macro step 8c + 18 on: its eight stage-steps (4 stages x 2 trials)
 // run in the macro steps 8c + 10 .. 8c + 17.
-__device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a, const int pw, const int lane, const int n_steps, const int grp) {
+__device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a_in, const int pw, const int lane, const int n_steps, const int grp) {
     XSmem &sm = g_sm;
+    const Lstm2FwdArgs a = a_in;
     const int T = a.T, K = a.K, F = a.F;
     float awp[6];
 #pragma unroll
@@ -658,7 +757,9 @@ __global__ __launch_bounds__(NTHR) void lstm2_fwd48x4_kernel(Lstm2FwdArgs a) {
 
 bool nsd_lstm2_fwd48x4_ok(const Lstm2FwdArgs &a) {
     // training launches of the plain two-layer stack; offsets of the saved activations are 32-bit byte offsets
-    return a.hseq0 != nullptr && !a.logits_out && !a.residual && a.C <= 8 && (long)a.B * a.T * H * 16 < 0x7fffffffL &&
+    // (the saved arrays are addressed with 32-bit byte offsets)
+    if ((long)a.B * a.T * H * 16 >= 0x7fffffffL) return false;
+    return a.hseq0 != nullptr && a.hseq1 && a.cseq0 && a.cseq1 && a.gact0 && a.gact1 && a.inseq && !a.logits_out && !a.residual && a.C <= 8 &&
            (!a.head_train || (a.T <= TT_TMAX && a.F <= 64 && a.K <= TT_KMAX && a.F >= 1 && a.K >= 1));
 }
 

@@ -23,7 +23,7 @@ __global__ void probe_kernel(const float *a, const float *b, float *d) {
 template <int CHAINS>
 __global__ __launch_bounds__(512) void rate_kernel(const float *w, float *out, long long *cycles, int iters, int valu_partner) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave >= 4) {                       // waves 4..7 share SIMDs 0..3 with waves 0..3
+    if (wave >= 4 && valu_partner != 3) {  // waves 4..7 share SIMDs 0..3 with waves 0..3 (valu_partner == 3: they stream MFMAs too)
         if (!valu_partner) return;
         float x = 0.001f * lane, y = 0.f;
         const long long t0 = clock64();
@@ -120,6 +120,18 @@ int main() {
     hipDeviceSynchronize();
     hipMemcpy(hc, cyc, 64, hipMemcpyDeviceToHost);
     printf("VALU wave alone: %.2f ticks per exp2+rcp+add+fma group\n", (double)hc[4] / (64.0 * iters));
+    for (int chains = 1; chains <= 4; chains *= 2) {            // two MFMA waves per SIMD: does the pipe take one 4x4x1 per 8 cycles or more?
+        hipMemset(cyc, 0, 64);
+        for (int rep = 0; rep < 2; ++rep) {
+            if (chains == 1) hipLaunchKernelGGL((rate_kernel<1>), dim3(256), dim3(512), 0, 0, w, out, cyc, iters, 3);
+            if (chains == 2) hipLaunchKernelGGL((rate_kernel<2>), dim3(256), dim3(512), 0, 0, w, out, cyc, iters, 3);
+            if (chains == 4) hipLaunchKernelGGL((rate_kernel<4>), dim3(256), dim3(512), 0, 0, w, out, cyc, iters, 3);
+        }
+        hipDeviceSynchronize();
+        hipMemcpy(hc, cyc, 64, hipMemcpyDeviceToHost);
+        printf("TWO MFMA waves per SIMD, chains=%d: %.2f ticks per MFMA of wave 0, %.2f of wave 4 -> one MFMA per %.2f ticks on the SIMD\n", chains,
+               (double)hc[0] / (32.0 * iters), (double)hc[4] / (32.0 * iters), (double)hc[0] / (64.0 * iters));
+    }
     for (int partner = 0; partner < 2; ++partner) {
         for (int chains = 1; chains <= 4; chains *= 2) {
             hipMemset(cyc, 0, 64);
