@@ -96,6 +96,7 @@ DIAG_SYMBOLS = {
     "nsd_seq_profile": (C.c_int, [C.c_int32]),
     "nsd_seq_profile_read": (C.c_int, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "nsd_diag_force_fwd48": (C.c_int, [C.c_int32]),
+    "nsd_diag_force_bwd48": (C.c_int, [C.c_int32]),
 }
 DIAG_LIB_PATH = os.path.join(_HERE, "libnsd_hip_diag.so")
 

@@ -493,13 +493,19 @@ __global__ __launch_bounds__(8 * H) void lstm2_bwd_kernel(Lstm2BwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-constexpr int X4_MIN_B = 768;        // training batch from which the four-trial forward kernel is used (H = 48): tools/x4_sweep.py
+constexpr int X4_MIN_B = 576;        // training batch from which the four-trial kernels are used (H = 48): tools/x4_sweep.py
 
 // Which H = 48 forward instantiation a launch takes is a pure function of the launch in the product library.  The diagnostic twin
 // (libnsd_hip_diag.so: this file compiled with -DNSD_DIAG=1) can pin it -- 1 / 2 / 4 trials per workgroup, 0 = automatic -- so that
 // tests compare the instantiations on the same inputs; the product has neither the entry point nor an environment hook.
 #if NSD_DIAG
-static int g_force_fwd48 = 0;
+static int g_force_fwd48 = 0, g_force_bwd48 = 0;
+extern "C" int nsd_diag_force_bwd48(int32_t nb) {
+    if (nb != 0 && nb != 2 && nb != 4) { nsd_set_error("nsd_diag_force_bwd48: 0, 2 (the one- / two-trial kernel) or 4"); return NSD_E_INVALID; }
+    g_force_bwd48 = nb;
+    return NSD_OK;
+}
+static int nsd_diag_forced_bwd48() { return g_force_bwd48; }
 extern "C" int nsd_diag_force_fwd48(int32_t nb) {
     if (nb != 0 && nb != 1 && nb != 2 && nb != 4) { nsd_set_error("nsd_diag_force_fwd48: 0, 1, 2 or 4"); return NSD_E_INVALID; }
     g_force_fwd48 = nb;
@@ -508,6 +514,7 @@ extern "C" int nsd_diag_force_fwd48(int32_t nb) {
 static int nsd_diag_forced_fwd48() { return g_force_fwd48; }
 #else
 static int nsd_diag_forced_fwd48() { return 0; }
+static int nsd_diag_forced_bwd48() { return 0; }
 #endif
 static int pick_nb(int B) {
     const int cus = nsd_num_cus();
@@ -582,7 +589,12 @@ int nsd_lstm2_bwd_launch(const Lstm2BwdArgs &a, int H, hipStream_t st) {
     if (grid <= 0) return NSD_OK;
     switch (H) {
     case 32: launch_bwd_h<32>(a, nb, grid, st); break;
-    case 48: return nsd_lstm2_bwd48_launch(a, nb, grid, st);   // role-split kernel (nsd_lstm2_bwd48.hip)
+    case 48: {   // role-split kernels: four trials per workgroup on the matrix pipe (nsd_lstm2_bwd48x4.hip) from X4_MIN_B trials on, else
+                 // one / two trials per workgroup (nsd_lstm2_bwd48.hip).  Same grid either way: the workspace holds one slab per workgroup.
+        const int force_nb = nsd_diag_forced_bwd48();
+        if (nsd_lstm2_bwd48x4_ok(a) && (force_nb ? force_nb == 4 : a.B >= X4_MIN_B)) return nsd_lstm2_bwd48x4_launch(a, grid, st);
+        return nsd_lstm2_bwd48_launch(a, nb, grid, st);
+    }
     case 64: launch_bwd_h<64>(a, nb, grid, st); break;
     default: nsd_set_error("lstm2 bwd: unsupported H=%d", H); return NSD_E_INVALID;
     }

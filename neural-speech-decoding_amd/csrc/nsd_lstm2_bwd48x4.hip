@@ -1,0 +1,486 @@
+// nsd_lstm2_bwd48x4.hip -- BPTT of the two-layer H=48 LSTM for batches of several trials per CU (BASELINE configs[3]: 1024 trials
+// per GPU): FOUR trials per workgroup, every product on the matrix pipe (gfx950).
+//
+// Replaces autograd through self.lstm(x) (Neuro-Alpha-App/Utilities/lstm_eeg_model.py:34) like nsd_lstm2_bwd48.hip (one or two
+// trials per workgroup: transposed mat-vecs as v_pk_fma_f32 with DPP reductions, ~1 300 cycles per trial-step and issue-bound).
+// With four trials every product of a step is a small GEMM with N = 4 and runs as v_mfma_f32_4x4x1_16B_f32 (16 blocks per
+// instruction, D_b[4x4] += A_b[4x1] * B_b[1x4]; operand layout, broadcast modifiers and rate: tools/micro/mfma4x4.hip -- two
+// waves of a SIMD together issue one every ~4.4 cycles, twice the nominal fp32 rate):
+//
+//   * the transposed products dh[u][trial] = sum_k W[k][u] da[k][trial] (W_hh1, W_ih1, W_hh0: 48 outputs x 192 k each).  A wave owns
+//     16 output units and splits k over the four 16-lane ROWS of the instruction: block (row ks, ub) = units 4ub..4ub+3 x the
+//     k-slice 48ks..48ks+47 x 4 trials, A lane (ks, ub, i) = W[k][unit 4ub + i] resident in VGPRs, B lane (ks, ub, j) = da[k][trial j]
+//     from ONE ds_read_b128 per four MFMAs; 48 MFMAs per wave and step, then a reduce-scatter of the four slices over the rows with
+//     v_permlane32_swap / v_permlane16_swap (3 swaps + 3 adds; semantics probed in tools/micro/permlane_probe.hip): lane (r, ub, j)
+//     ends up with dh of unit 4ub + r for trial j -- one cell per lane, every lane useful, the cell's backward in the lane;
+//   * the weight gradients dW[192 x 48] += da[.][trial] (x) operand[trial][.] as outer products: block (rb, cb) = 4 rows x 4 columns,
+//     A = da from LDS with CBSZ = 2 / ABID = trial (one register holds the four trials of a 16-row tile), B = the saved h / in1 / x
+//     rows from HBM with BLGP = 4 + trial (one register holds the four trials of a 16-column tile): 2 registers feed 4 MFMAs.
+//
+// 16 waves, role = f(SIMD g = wave & 3, slot q = wave >> 2); ONE barrier per macro step m:
+//   q 0, g 0..2  "C1"  layer-1 recurrence, t = T-1-m, units 16g..: W_hh1^T da1[t+1] -> dh -> cell backward -> da1[t] -> LDS
+//   q 1, g 0..2  "C0"  layer-0 recurrence, t = T+1-m: W_hh0^T da0[t+1] + multiplier * d_in1[t] -> da0[t] -> LDS
+//   q 2, g 0..2  "X1"  d_in1[t] = W_ih1^T da1[t], t = T-m (what layer 0 receives from layer 1); + dW_ih0 (four row tiles each)
+//   q 3, g 0..2 and g 3, q 0..2  "dW"  six waves: dW_hh1, dW_ih1, dW_hh0 (two waves each, 6 row tiles x 3 column tiles):
+//                      72 MFMAs per wave and step, B rows prefetched from HBM four steps ahead
+//   q 3, g 3     "aux" {alpha, dscore} of the layer-1 steps and the layer-0 dropout multipliers (explicit tensor or the counter
+//                      stream), one 16-step chunk ahead -> LDS
+//   (232 / 232 / 232 / 216 MFMAs per step and SIMD.)  The saved activations of a cell (16 bytes of gates, c[t-1]) are prefetched by
+//   the lane that owns the cell, two steps ahead, with buffer loads whose time offset is scalar -- no staging through LDS.
+// HBM traffic = saved activations read once + one slab of partial gradients per workgroup at the end.
+#include "nsd_args.h"
+#include "nsd_prof.h"
+
+namespace {
+
+constexpr int H = 48;
+constexpr int NTR = 4;
+constexpr int NTHR = 1024;
+constexpr int VSD = 208;          // floats per trial of a da vector (k' = 4 unit + gate): 16-byte pieces of the four trials fall into different banks
+constexpr int VS1 = 64;
+constexpr int XCH = 16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+struct BSmem {
+    float da[2][2][NTR][VSD];     // [slot m & 1][layer][trial][4 unit + gate]
+    float din1[2][NTR][VS1];      // [slot m & 1][trial][unit]: W_ih1^T da1 of t = T - m
+    float mk[2][NTR][XCH][H];     // layer-0 dropout multipliers of t = T + 1 - m, 16 macro steps per chunk
+    float sc[2][NTR][XCH][4];     // {alpha, dscore, -, -} of t = T - 1 - m
+};
+__shared__ __align__(16) BSmem g_bsm;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, const long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
+constexpr unsigned VOFF_DROP = 0x80000000u;                        // beyond every descriptor's range: a load returns zeros
+
+// one barrier per macro step: raw s_barrier behind lgkmcnt(0) -- the prefetches in flight (vmcnt) are not waited for
+__device__ __forceinline__ void xstep_barrier(Prof &p) {
+    if (kProfile && p.on) {
+        const long long t = clock64();
+        p.work += t - p.last;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const long long t2 = clock64();
+        p.wait += t2 - t;
+        p.last = t2;
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma_plain(const float a, const float b, const f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+// outer-product form: A of block `TR` of each group of four blocks, B of the 16-lane row `TR`
+template <int TR> __device__ __forceinline__ f32x4 mfma_outer(const float a, const float b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 2, TR, 4 + TR);
+}
+
+// sum of the four 16-lane rows' partial sums, scattered: row r keeps register r (v_permlane32_swap: {x.lo, y.lo} / {x.hi, y.hi};
+// v_permlane16_swap: {x.r0, y.r0, x.r2, y.r2} / {x.r1, y.r1, x.r3, y.r3})
+__device__ __forceinline__ float rows_reduce_scatter(const f32x4 a) {
+    const u32x2 p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[0]), __float_as_uint(a[2]), false, false);
+    const u32x2 p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[1]), __float_as_uint(a[3]), false, false);
+    const float s02 = __uint_as_float(p02[0]) + __uint_as_float(p02[1]);
+    const float s13 = __uint_as_float(p13[0]) + __uint_as_float(p13[1]);
+    const u32x2 q = __builtin_amdgcn_permlane16_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// W^T rows of a transposed product for lane (ks = lane >> 4, ub = (lane >> 2) & 3, i = lane & 3): w[s] = W[row(k' = 48 ks + s)][16 g + 4 ub + i],
+// k' = 4 unit + gate (the order of the da vectors in LDS) -> row of nn.LSTM's [4H][H] weight = gate * 48 + unit
+__device__ __forceinline__ void load_wT(const float *w, const int g, const int lane, float (&wv)[H]) {
+    const int ks = lane >> 4, col = 16 * g + 4 * ((lane >> 2) & 3) + (lane & 3);
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+        const int kp = 48 * ks + s;
+        wv[s] = w[(size_t)((kp & 3) * H + (kp >> 2)) * H + col];
+    }
+}
+
+// dh of this lane's cell (unit 16 g + 4 ub + r, trial j) = sum over k' of W[k'][unit] * v[k'][trial]; v = one trial-major da vector set
+__device__ __forceinline__ float transposed_product(const float (&wv)[H], const float *vj /* &v[j][48 * ks] */) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qb = 0; qb < 12; qb += 4) {                              // three batches of four reads: 16 B-operand registers live at a time
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(vj + 4 * (qb + q));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = mfma_plain(wv[4 * (qb + q) + 0], bq[q][0], acc0);
+            acc1 = mfma_plain(wv[4 * (qb + q) + 1], bq[q][1], acc1);
+            acc0 = mfma_plain(wv[4 * (qb + q) + 2], bq[q][2], acc0);
+            acc1 = mfma_plain(wv[4 * (qb + q) + 3], bq[q][3], acc1);
+        }
+    }
+    return rows_reduce_scatter(acc0 + acc1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// recurrences: layer = 1 (t = T-1-m) or 0 (t = T+1-m)
+// ------------------------------------------------------------------------------------------------
+// (every role is a real function call with its own register allocation -- inlined into one body, hipcc spilled the dW accumulators
+// inside the step loop -- and works on a LOCAL copy of the argument block: the step barrier is an asm statement with a memory clobber)
+template <int LAYER>
+__device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, const int g, const int lane, const int n_steps) {
+    BSmem &sm = g_bsm;
+    const Lstm2BwdArgs a = a_in;
+    const int r = lane >> 4, ub = (lane >> 2) & 3, j = lane & 3;
+    const int u = 16 * g + 4 * ub + r;                              // this lane's cell after the reduce-scatter
+    const int T = a.T, B = a.B;
+    float wv[H];
+    load_wT(LAYER == 0 ? a.w_hh0 : a.w_hh1, g, lane, wv);
+    const float awj = a.attn_w[u];
+    const long bth4 = (long)B * T * H * 4;
+    const rsrc_t r_g = make_rsrc(LAYER == 0 ? a.gact0 : a.gact1, bth4 * 4), r_c = make_rsrc(LAYER == 0 ? a.cseq0 : a.cseq1, bth4);
+    const bool masked = LAYER == 0 && (a.mask != nullptr || a.rng.on);
+    float db[4] = {0.f, 0.f, 0.f, 0.f};
+    Prof prof = prof_init(a.dbg);
+    const int ngrp = (B + NTR - 1) / NTR;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b = grp * NTR + j;
+        const bool vb = b < B;
+        const unsigned vo4 = vb ? (unsigned)(((size_t)b * T * H + u) * 4) : VOFF_DROP;
+        const unsigned vo16 = vb ? vo4 * 4u : VOFF_DROP;
+        const float dpj = (LAYER == 1 && vb) ? a.dpooled[(size_t)b * H + u] : 0.f;
+        float dc = 0.f;
+        // time index of macro step m, clamped for the prefetches (values of inactive steps are never used)
+        auto t_of = [&](const int m) { return LAYER == 1 ? T - 1 - m : T + 1 - m; };
+        auto clampt = [&](const int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
+        f32x4 gq[2];
+        float cq[2];                                               // c[t-1] of the step
+        auto prefetch = [&](const int m, f32x4 &gv, float &cv) {
+            const int t = clampt(t_of(m)), tp = clampt(t_of(m) - 1);
+            gv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_g, (int)vo16, t * (H * 16), 0));
+            cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_c, (int)vo4, tp * (H * 4), 0));
+        };
+        float ct = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_c, (int)vo4, (T - 1) * (H * 4), 0));     // c[T-1] of the first step
+        prefetch(0, gq[0], cq[0]);
+        prefetch(1, gq[1], cq[1]);
+        if (LAYER == 0 && g == 0) {                                 // zero the da slots and d_in1 of the group (one wave: 3 328 + 512 floats)
+            for (int e = lane; e < 2 * 2 * NTR * VSD; e += 64) (&sm.da[0][0][0][0])[e] = 0.f;
+            for (int e = lane; e < 2 * NTR * VS1; e += 64) (&sm.din1[0][0][0])[e] = 0.f;
+        }
+        xstep_barrier(prof);
+        for (int m0 = 0; m0 < n_steps; m0 += 2) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int m = m0 + k;
+                const int t = t_of(m);
+                const bool active = t >= 0 && t < T, prev_active = t + 1 >= 0 && t + 1 < T;
+                // ---- what does not depend on the recurrence: the derivative factors of this cell, the gradient arriving from above
+                const f32x4 gc = gq[k];
+                const float cprev = t > 0 ? cq[k] : 0.f;
+                prefetch(m + 2, gq[k], cq[k]);                      // (the registers are free again: two steps ahead)
+                const float ig = gc[0], fg = gc[1], gg = gc[2], og = gc[3];
+                const float tc = fast_tanh(ct);
+                const float wq = og * (1.f - tc * tc);              // d c_t / d h_t
+                const float Fi = gg * ig * (1.f - ig), Ff = cprev * fg * (1.f - fg), Fg = ig * (1.f - gg * gg), Fo = tc * og * (1.f - og);
+                float dout;
+                if (LAYER == 1) {
+                    const float2 ad = *reinterpret_cast<const float2 *>(&sm.sc[(m >> 4) & 1][j][m & (XCH - 1)][0]);
+                    dout = fmaf(ad.x, dpj, ad.y * awj);
+                } else {
+                    const float mkv = masked ? sm.mk[(m >> 4) & 1][j][m & (XCH - 1)][u] : 1.f;
+                    dout = sm.din1[(k + 1) & 1][j][u] * mkv;        // written by the X1 waves at macro step m - 1
+                }
+                // ---- the recurrence
+                float rec = 0.f;
+                if (prev_active) rec = transposed_product(wv, &sm.da[(k + 1) & 1][LAYER][j][48 * r]);
+                f32x4 dav = {0.f, 0.f, 0.f, 0.f};
+                if (active && vb) {
+                    const float dht = dout + rec;
+                    const float dct = fmaf(dht, wq, dc);
+                    dav = f32x4{dct * Fi, dct * Ff, dct * Fg, dht * Fo};
+                    dc = dct * fg;
+                    db[0] += dav[0]; db[1] += dav[1]; db[2] += dav[2]; db[3] += dav[3];
+                }
+                if (active) ct = cprev;                             // c[t-1] is the cell state of the next step handled
+                *reinterpret_cast<f32x4 *>(&sm.da[k][LAYER][j][4 * u]) = dav;      // (zeros for inactive steps / padding trials: dW and X1 add nothing)
+                xstep_barrier(prof);
+            }
+        }
+    }
+    prof_store(a.dbg, prof);
+    // bias gradients: sum over the four trials of the quad, lane j == 0 writes (b_ih and b_hh get the same sum)
+    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float s = quad_sum(db[q]);
+        if (j == 0) {
+            slab[(LAYER == 0 ? a.o_b_ih0 : a.o_b_ih1) + q * H + u] = s;
+            slab[(LAYER == 0 ? a.o_b_hh0 : a.o_b_hh1) + q * H + u] = s;
+        }
+    }
+}
+
+template <int TR>
+__device__ __forceinline__ void dwx_trial(const float (&a3)[4], const float bx, f32x4 (&acc3)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc3[q] = mfma_outer<TR>(a3[q], bx, acc3[q]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// X1: d_in1[t] = W_ih1^T da1[t], t = T - m (da1 written at macro step m - 1) -> LDS for the layer-0 recurrence of macro step m + 1
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((noinline)) void x1_role(const Lstm2BwdArgs &a_in, const int g, const int lane, const int n_steps) {
+    BSmem &sm = g_bsm;
+    const Lstm2BwdArgs a = a_in;
+    const int r = lane >> 4, ub = (lane >> 2) & 3, j = lane & 3;
+    const int u = 16 * g + 4 * ub + r;
+    const int T = a.T, B = a.B, C = a.C;
+    float wv[H];
+    load_wT(a.w_ih1, g, lane, wv);
+    // dW_ih0 = da0 (x) x[t] (outer-product form, see the dW waves): row tiles 4g .. 4g + 3 of k', the one 16-column tile of the channels
+    const int a3_off = ((lane >> 2) & 3) * VSD + 16 * (4 * g) + 4 * (lane >> 4) + (lane & 3);      // + 16 q: lane (rb, tr, i)
+    const int xc = 4 * ((lane >> 2) & 3) + (lane & 3);              // B operand lane (tr = lane >> 4, cb, jj): channel 4 cb + jj
+    const rsrc_t r_x = make_rsrc(a.x, (long)B * T * C * 4);
+    f32x4 acc3[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc3[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Prof prof = prof_init(a.dbg);
+    const int ngrp = (B + NTR - 1) / NTR;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int bb = grp * NTR + (lane >> 4);
+        const unsigned vox = (bb < B && xc < C) ? (unsigned)(((size_t)bb * T * C + xc) * 4) : VOFF_DROP;
+        auto prefetch = [&](const int m) -> float {                 // x row of the da0 written at macro step m - 1: t = T + 2 - m
+            const int tx = T + 2 - m;
+            const bool okx = tx >= 0 && tx < T;
+            const float xv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_x, (int)vox, (okx ? tx : 0) * (C * 4), 0));
+            return okx ? xv : 0.f;
+        };
+        float bxq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bxq[k] = prefetch(k);
+        xstep_barrier(prof);
+        for (int m0 = 0; m0 < n_steps; m0 += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + k, t1p = T - m;
+                if (t1p >= 0 && t1p < T) sm.din1[k & 1][j][u] = transposed_product(wv, &sm.da[(k + 1) & 1][1][j][48 * r]);
+                const float *da0 = &sm.da[(k + 1) & 1][0][0][0];
+                float a3[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a3[q] = da0[a3_off + 16 * q];
+                const float bx = bxq[k];
+                bxq[k] = prefetch(m + 4);
+                if (m >= 1) {
+                    dwx_trial<0>(a3, bx, acc3);
+                    dwx_trial<1>(a3, bx, acc3);
+                    dwx_trial<2>(a3, bx, acc3);
+                    dwx_trial<3>(a3, bx, acc3);
+                }
+                xstep_barrier(prof);
+            }
+        }
+    }
+    prof_store(a.dbg, prof);
+    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    const int rb = lane >> 4;
+    if (xc < C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kp = 16 * (4 * g + q) + 4 * rb + i;
+                slab[a.o_w_ih0 + (size_t)((kp & 3) * H + (kp >> 2)) * C + xc] = acc3[q][i];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW waves.  Wave d: matrix Q = d >> 1 (0: dW_hh1 = da1 (x) h1[t-1], 1: dW_ih1 = da1 (x) in1[t], 2: dW_hh0 = da0 (x) h0[t-1]), row tiles
+// 6 (d & 1) .. + 5 (16 rows of k' each), all three 16-column tiles.  (dW_ih0 = da0 (x) x[t], one column tile, rides in the X1 waves.)
+// ------------------------------------------------------------------------------------------------
+template <int TR>
+__device__ __forceinline__ void dw_trial(const float (&av)[6], const float (&bv)[3], f32x4 (&acc)[6][3]) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) acc[q][ct] = mfma_outer<TR>(av[q], bv[ct], acc[q][ct]);
+}
+
+
+__device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, const int d, const int lane, const int n_steps) {
+    BSmem &sm = g_bsm;
+    const Lstm2BwdArgs a = a_in;
+    const int Q = d >> 1, half = d & 1;
+    const int T = a.T, B = a.B;
+    // A operand: lane (rb = lane >> 4, tr = (lane >> 2) & 3, i = lane & 3) = da[tr][16 rt + 4 rb + i]; B operand: lane (tr = lane >> 4, cb, jj)
+    const int a_rb = lane >> 4, a_tr = (lane >> 2) & 3, a_i = lane & 3;
+    const int b_tr = lane >> 4, b_cb = (lane >> 2) & 3, b_jj = lane & 3;
+    const int layerQ = Q == 2 ? 0 : 1;
+    const float *src = Q == 0 ? a.hseq1 : Q == 1 ? a.in1seq : a.hseq0;
+    const long bth4 = (long)B * T * H * 4;
+    const rsrc_t r_s = make_rsrc(src, bth4);
+    f32x4 acc[6][3];
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) acc[q][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_off = a_tr * VSD + 16 * (6 * half) + 4 * a_rb + a_i;          // + 16 q
+    Prof prof = prof_init(a.dbg);
+    const int ngrp = (B + NTR - 1) / NTR;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int bb = grp * NTR + b_tr;
+        const bool vb = bb < B;
+        const unsigned vo = vb ? (unsigned)(((size_t)bb * T * H + 4 * b_cb + b_jj) * 4) : VOFF_DROP;     // + 64 ct bytes
+        // B rows of macro step m (pairing with the da written at macro step m - 1); out of range: zeros
+        auto prefetch = [&](const int m, float (&bv)[3]) {
+            const int t = Q == 2 ? T + 2 - m : T - m;               // the step whose da is used
+            const int tt = Q == 1 ? t : t - 1;                      // row of the saved sequence
+            const bool ok = t >= 0 && t < T && tt >= 0;
+            const int tc = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_s, (int)(vo + 64u * ct), tc * (H * 4), 0));
+                bv[ct] = ok ? v : 0.f;
+            }
+        };
+        float bq[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) prefetch(k, bq[k]);
+        xstep_barrier(prof);
+        for (int m0 = 0; m0 < n_steps; m0 += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + k;
+                const float *dal = &sm.da[(k + 1) & 1][layerQ][0][0];
+                float av[6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) av[q] = dal[a_off + 16 * q];
+                float bv[3] = {bq[k][0], bq[k][1], bq[k][2]};
+                prefetch(m + 4, bq[k]);
+                if (m >= 1 && !ablated(a.ablate, 1)) {
+                    dw_trial<0>(av, bv, acc);
+                    dw_trial<1>(av, bv, acc);
+                    dw_trial<2>(av, bv, acc);
+                    dw_trial<3>(av, bv, acc);
+                }
+                xstep_barrier(prof);
+            }
+        }
+    }
+    prof_store(a.dbg, prof);
+    // accumulator tile -> slab: lane (rb = lane >> 4, cb, jj) register i = dW[k' = 16 rt + 4 rb + i][16 ct + 4 cb + jj]
+    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    const long base = Q == 0 ? a.o_w_hh1 : Q == 1 ? a.o_w_ih1 : a.o_w_hh0;
+    const int rb = lane >> 4, cb = (lane >> 2) & 3, jj = lane & 3;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kp = 16 * (6 * half + q) + 4 * rb + i;
+                slab[base + (size_t)((kp & 3) * H + (kp >> 2)) * H + 16 * ct + 4 * cb + jj] = acc[q][ct][i];
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// aux wave: {alpha, dscore} of the layer-1 steps and the layer-0 dropout multipliers, one 16-step chunk ahead
+// ------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) f32x4 *gf32x4_p;
+__device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, const int lane, const int n_steps) {
+    BSmem &sm = g_bsm;
+    const Lstm2BwdArgs a = a_in;
+    const int T = a.T, B = a.B;
+    Prof prof = prof_init(a.dbg);
+    const int ngrp = (B + NTR - 1) / NTR;
+    // chunk c = macro steps 16c .. 16c + 15 into buffer c & 1:  sc: lane (n = lane >> 4, s = lane & 15) one 16-byte record;
+    // multipliers: 4 trials x 16 steps x 12 float4 = 768 float4, 12 per lane (explicit tensor), or 3 hashes per lane and step
+    auto sc_at = [&](const int b0, const int c) -> f32x4 {
+        const int n = lane >> 4, s = lane & 15, b = b0 + n, t = T - 1 - (16 * c + s);
+        if (b < B && t >= 0 && t < T) return *(gf32x4_p)(a.dsc_pack + ((size_t)b * T + t) * 4);
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto mask_at = [&](const int b0, const int c, const int e) -> f32x4 {      // e: float4 index in [0, NTR*XCH*12)
+        const int n = e / (XCH * 12), rem = e - n * (XCH * 12), s = rem / 12, q = rem - s * 12;
+        const int b = b0 + n, t = T + 1 - (16 * c + s);
+        if (a.mask && b < B && t >= 0 && t < T) return *(gf32x4_p)(a.mask + ((size_t)b * T + t) * H + 4 * q);
+        return f32x4{1.f, 1.f, 1.f, 1.f};
+    };
+    auto rng_row = [&](const int b0, const int m, const int buf) {            // the 192 multipliers of macro step m: 3 per lane
+        const int t = T + 1 - m;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int v = lane + 64 * i, n = v / H, uu = v - n * H;
+            const int b = b0 + n;
+            float mkv = 1.f;
+            if (b < B && t >= 0 && t < T) mkv = nsd_rand_u32(a.rng.seed, a.rng.base, ((uint64_t)b * T + t) * H + uu) < a.rng.thr_lstm ? 0.f : a.rng.keep_lstm;
+            sm.mk[buf][n][m & (XCH - 1)][uu] = mkv;
+        }
+    };
+    constexpr int MPL = NTR * XCH * 12 / 64;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b0 = grp * NTR;
+        *reinterpret_cast<f32x4 *>(&sm.sc[0][0][0][0] + 4 * lane) = sc_at(b0, 0);
+        if (a.rng.on) {
+#pragma unroll 1
+            for (int s = 0; s < XCH; ++s) rng_row(b0, s, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < MPL; ++q) *reinterpret_cast<f32x4 *>(&sm.mk[0][0][0][0] + 4 * (lane + 64 * q)) = mask_at(b0, 0, lane + 64 * q);
+        }
+        xstep_barrier(prof);
+        for (int m0 = 0; m0 < n_steps; m0 += XCH) {
+            const int c = m0 >> 4, cb = c & 1;
+            const f32x4 scr = sc_at(b0, c + 1);
+            f32x4 mr[MPL];
+            if (!a.rng.on) {
+#pragma unroll
+                for (int q = 0; q < MPL; ++q) mr[q] = mask_at(b0, c + 1, lane + 64 * q);
+            }
+#pragma unroll 1
+            for (int k = 0; k < XCH; ++k) {
+                if (a.rng.on) rng_row(b0, m0 + XCH + k, cb ^ 1);
+                if (k == XCH - 1) {
+                    *reinterpret_cast<f32x4 *>(&sm.sc[cb ^ 1][0][0][0] + 4 * lane) = scr;
+                    if (!a.rng.on) {
+#pragma unroll
+                        for (int q = 0; q < MPL; ++q) *reinterpret_cast<f32x4 *>(&sm.mk[cb ^ 1][0][0][0] + 4 * (lane + 64 * q)) = mr[q];
+                    }
+                }
+                xstep_barrier(prof);
+            }
+        }
+    }
+    prof_store(a.dbg, prof);
+}
+
+__global__ __launch_bounds__(NTHR) void lstm2_bwd48x4_kernel(Lstm2BwdArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // macro steps 0 .. T+2 (the dW waves use the da of macro step m - 1), padded to whole 16-step chunks
+    const int n_steps = ((a.T + 3 + XCH - 1) / XCH) * XCH;
+    const int g = wave & 3, q = wave >> 2;                          // SIMD, slot
+#ifdef NSD_BX4_ONLY_ROLE                                            // resource probe (never built into the library): one role alone
+    if (NSD_BX4_ONLY_ROLE == 1) chain_role<1>(a, g, lane, n_steps);
+    else if (NSD_BX4_ONLY_ROLE == 2) chain_role<0>(a, g, lane, n_steps);
+    else if (NSD_BX4_ONLY_ROLE == 3) x1_role(a, g, lane, n_steps);
+    else if (NSD_BX4_ONLY_ROLE == 4) dw_role(a, g, lane, n_steps);
+    else aux_role(a, lane, n_steps);
+    return;
+#endif
+    if (g < 3 && q == 0)      { __builtin_amdgcn_s_setprio(3); chain_role<1>(a, g, lane, n_steps); }
+    else if (g < 3 && q == 1) { __builtin_amdgcn_s_setprio(3); chain_role<0>(a, g, lane, n_steps); }
+    else if (g < 3 && q == 2) { __builtin_amdgcn_s_setprio(2); x1_role(a, g, lane, n_steps); }
+    else if (g < 3)           dw_role(a, g, lane, n_steps);                 // dW waves 0..2
+    else if (q < 3)           dw_role(a, 3 + q, lane, n_steps);             // dW waves 3..5
+    else                      aux_role(a, lane, n_steps);
+    // a workgroup without a trial group (grid = the workspace's slab count) has written a zero slab: every role's sums are zero
+}
+
+}  // namespace
+
+bool nsd_lstm2_bwd48x4_ok(const Lstm2BwdArgs &a) {
+    return !a.residual && a.C <= 8 && (long)a.B * a.T * H * 16 < 0x7fffffffL && a.dsc_pack != nullptr;
+}
+
+int nsd_lstm2_bwd48x4_launch(const Lstm2BwdArgs &a, int grid, hipStream_t st) {
+    if (!nsd_lstm2_bwd48x4_ok(a)) { nsd_set_error("lstm2_bwd48x4: launch outside the kernel's domain"); return NSD_E_INVALID; }
+    hipLaunchKernelGGL(lstm2_bwd48x4_kernel, dim3(grid), dim3(NTHR), 0, st, a);
+    NSD_CHECK_LAUNCH("lstm2_bwd48x4");
+    return NSD_OK;
+}

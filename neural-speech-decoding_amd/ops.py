@@ -134,6 +134,14 @@ def force_fwd48(nb: int) -> None:
     _lib.check(_lib.lib().nsd_diag_force_fwd48(int(nb)), "nsd_diag_force_fwd48")
 
 
+def force_bwd48(nb: int) -> None:
+    """Diagnostic build only: pin the H = 48 backward kernel -- 2 = the one- / two-trial kernel, 4 = the four-trial matrix-pipe kernel
+    where it applies, 0 = the product's own choice.  Reset it to 0 before leaving the block."""
+    if not _lib.diag_active():
+        raise NsdError("force_bwd48: the kernel can be pinned in the diagnostic build only: use `with _lib.diagnostic_library():`")
+    _lib.check(_lib.lib().nsd_diag_force_bwd48(int(nb)), "nsd_diag_force_bwd48")
+
+
 def set_gemm_bf16(on: bool) -> None:
     """Large-H batched path only (NSD_FLAG_BF16): GEMM operands rounded to bf16 (fp32 accumulate / storage).  Off by default."""
     global _extra_flags

@@ -1022,3 +1022,54 @@ def test_four_trials_per_workgroup_forward_on_the_matrix_pipe(nsd, dev, ref_stat
             _grad_close(grads, g_ref, D, rtol=3e-4)
         finally:
             ops.force_fwd48(0)
+
+
+@pytest.mark.parametrize("B,T", [(4, 5), (7, 33), (33, 16), (64, 250), (130, 1), (9, 625), (5, 13), (6, 29), (2, 2)])
+def test_four_trials_per_workgroup_backward_on_the_matrix_pipe(nsd, dev, ref_state, B, T):
+    """lstm2_bwd48x4_kernel (nsd_lstm2_bwd48x4.hip): BPTT with four trials per workgroup -- the transposed products as v_mfma_f32_4x4x1
+    with the k dimension split over the rows of the instruction and a v_permlane reduce-scatter, the cell's backward in the lane that
+    owns the cell, the weight gradients as outer-product MFMAs (CBSZ / ABID / BLGP broadcasts), saved activations prefetched by the
+    owning lanes.  Held to the ORACLE (gradients 3e-4 of each tensor's largest element) and to the one- / two-trial kernel on the SAME
+    forward workspace (2e-5 of the largest gradient element: the sums run in another order): padding trials, T = 1 and 2, T + 3 a
+    multiple of the 16-step padding, the recorded windows' 625 steps; explicit masks and the streams drawn in the kernel."""
+    from nsd_amd import _lib, ops
+    spec = ops.ModelSpec()
+    flat_np = orc.flatten_state(ref_state, D)
+    flat = _t(flat_np, dev)
+    xn, yn = synth_x(B, T, seed=B + T), synth_labels(B, seed=B + T)
+    x, y = _t(xn, dev), _t(yn.astype(np.int32), dev)
+    dln, sln, dhn = counter_masks(B, T, 48, 32, seed=3 * B + T)
+    dl, sl, dh = _t(dln, dev), _t(sln, dev), _t(dhn, dev)
+    rng = dict(seed=0x1234ABCD, base_stream=44, p_lstm=0.6, p_head=0.6)
+    variants = [dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh, fused_head=True), dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh, fused_head=False)]
+    if ops.rng_path(spec, B, T):
+        variants.append(dict(rng=rng))
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, xn, yn, D, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn)
+    with _lib.diagnostic_library():
+        try:
+            ops.force_fwd48(1)                                   # the same forward for both: only the backward kernel changes
+            for vi, kw in enumerate(variants):
+                res = {}
+                for nb in (2, 4):
+                    ops.force_bwd48(nb)
+                    ws = ops.new_workspace(spec, B, T, dev)
+                    ws.fill_(float("nan"))
+                    logits = torch.full((B, spec.K), float("nan"), device=dev)
+                    grads = torch.empty_like(flat)
+                    ops.train_step_grads(spec, flat, x, ws, y, logits, grads, **kw)
+                    torch.cuda.synchronize()
+                    res[nb] = grads.clone()
+                g2, g4 = res[2], res[4]
+                assert torch.isfinite(g4).all(), kw.keys()
+                assert (g2 - g4).abs().max().item() <= 2e-5 * g2.abs().max().item() + 1e-9, (kw.keys(), (g2 - g4).abs().max().item(), g2.abs().max().item())
+                if vi < 2:
+                    _grad_close(g4.cpu().numpy() * 1.0, g_ref, D, rtol=3e-4)
+            # both new kernels together (what the product runs from 576 trials on), against the oracle
+            ops.force_fwd48(4)
+            ops.force_bwd48(4)
+            loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, xn, yn, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn)
+            assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
+            _grad_close(grads, g_ref, D, rtol=3e-4)
+        finally:
+            ops.force_fwd48(0)
+            ops.force_bwd48(0)
