@@ -102,6 +102,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return rows_combine_max(v);
 }
 
+// A called function sees the kernel's argument block through a pointer: what it loads from there sits in VGPRs, and hipcc cannot know that
+// every lane holds the same value -- buffer descriptors built from such pointers are used inside WATERFALL loops (one pass per distinct
+// value, a vmcnt(0) in front), loop bounds become vector compares.  uniform_copy() hands every dword through v_readfirstlane: scalar again.
+template <class A>
+__device__ __forceinline__ A uniform_copy(const A &in) {
+    static_assert(sizeof(A) % 4 == 0, "argument block: whole dwords");
+    A out;
+    const unsigned *s = reinterpret_cast<const unsigned *>(&in);
+    unsigned *d = reinterpret_cast<unsigned *>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(A) / 4; ++i) d[i] = __builtin_amdgcn_readfirstlane(s[i]);
+    return out;
+}
+
 // in-kernel train-mode streams (see nsd_rng in nsd.h): thresholds and keep factors precomputed on the host
 struct RngArgs {
     uint64_t seed;

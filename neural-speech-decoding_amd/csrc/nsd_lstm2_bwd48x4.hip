@@ -23,10 +23,10 @@
 //   q 2, g 0..2  "X1"  d_in1[t] = W_ih1^T da1[t], t = T-m (what layer 0 receives from layer 1); + dW_ih0 (four row tiles each)
 //   q 3, g 0..2 and g 3, q 0..2  "dW"  six waves: dW_hh1, dW_ih1, dW_hh0 (two waves each, 6 row tiles x 3 column tiles):
 //                      72 MFMAs per wave and step, B rows prefetched from HBM four steps ahead
-//   q 3, g 3     "aux" {alpha, dscore} of the layer-1 steps and the layer-0 dropout multipliers (explicit tensor or the counter
-//                      stream), one 16-step chunk ahead -> LDS
+//   q 3, g 3     "aux" {alpha, dscore} of the layer-1 steps, the x rows and the layer-0 dropout multipliers (explicit tensor or the
+//                      counter stream), one 16-step chunk ahead -> LDS
 //   (232 / 232 / 232 / 216 MFMAs per step and SIMD.)  The saved activations of a cell (16 bytes of gates, c[t-1]) are prefetched by
-//   the lane that owns the cell, two steps ahead, with buffer loads whose time offset is scalar -- no staging through LDS.
+//   the lane that owns the cell, four steps ahead, with buffer loads whose time offset is scalar -- no staging through LDS.
 // HBM traffic = saved activations read once + one slab of partial gradients per workgroup at the end.
 #include "nsd_args.h"
 #include "nsd_prof.h"
@@ -42,12 +42,24 @@ constexpr int XCH = 16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#ifndef NSD_BX4_DWD
+#define NSD_BX4_DWD 4
+#endif
+constexpr int DWD = NSD_BX4_DWD;
+#ifndef NSD_BX4_B96
+#define NSD_BX4_B96 1
+#endif
+#ifndef NSD_BX4_CHD
+#define NSD_BX4_CHD 4
+#endif
+constexpr int CHD = NSD_BX4_CHD;   // steps a cell lane requests its saved activations ahead (= unroll of the recurrences' step loop; even, 16 % CHD == 0)   // steps the dW waves' B rows are requested ahead (= unroll of their step loop; 16 % DWD == 0)
 
 struct BSmem {
     float da[2][2][NTR][VSD];     // [slot m & 1][layer][trial][4 unit + gate]
     float din1[2][NTR][VS1];      // [slot m & 1][trial][unit]: W_ih1^T da1 of t = T - m
     float mk[2][NTR][XCH][H];     // layer-0 dropout multipliers of t = T + 1 - m, 16 macro steps per chunk
     float sc[2][NTR][XCH][4];     // {alpha, dscore, -, -} of t = T - 1 - m
+    float xs[2][NTR][XCH][16];    // x[t = T + 2 - m][channel] (channels >= C: zeros), the B operand of dW_ih0
 };
 __shared__ __align__(16) BSmem g_bsm;
 
@@ -99,22 +111,29 @@ __device__ __forceinline__ void load_wT(const float *w, const int g, const int l
 }
 
 // dh of this lane's cell (unit 16 g + 4 ub + r, trial j) = sum over k' of W[k'][unit] * v[k'][trial]; v = one trial-major da vector set
-__device__ __forceinline__ float transposed_product(const float (&wv)[H], const float *vj /* &v[j][48 * ks] */) {
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ float transposed_product(const float (&wv)[H], const float *vj /* &v[j][48 * ks] */, const int abl = 0) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+    if (ablated(abl, 2)) return wv[0];                              // timing experiments: no product at all
+    if (ablated(abl, 4)) {                                          // ... the MFMAs without the LDS reads
+        const f32x4 c4 = {wv[1], wv[2], wv[3], wv[4]};
+#pragma unroll
+        for (int s = 0; s < H; s += 2) { acc0 = mfma_plain(wv[s], c4[s & 3], acc0); acc1 = mfma_plain(wv[s + 1], c4[(s + 1) & 3], acc1); }
+        return rows_reduce_scatter(acc0 + acc1);
+    }
 #pragma unroll
     for (int qb = 0; qb < 12; qb += 4) {                              // three batches of four reads: 16 B-operand registers live at a time
         f32x4 bq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(vj + 4 * (qb + q));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc0 = mfma_plain(wv[4 * (qb + q) + 0], bq[q][0], acc0);
+        for (int q = 0; q < 4; ++q) {                                   // four accumulator chains: with four waves per SIMD in the pipe a dependent
+            acc0 = mfma_plain(wv[4 * (qb + q) + 0], bq[q][0], acc0);    // MFMA waits well over its own 8 cycles for its predecessor
             acc1 = mfma_plain(wv[4 * (qb + q) + 1], bq[q][1], acc1);
-            acc0 = mfma_plain(wv[4 * (qb + q) + 2], bq[q][2], acc0);
-            acc1 = mfma_plain(wv[4 * (qb + q) + 3], bq[q][3], acc1);
+            acc2 = mfma_plain(wv[4 * (qb + q) + 2], bq[q][2], acc2);
+            acc3 = mfma_plain(wv[4 * (qb + q) + 3], bq[q][3], acc3);
         }
     }
-    return rows_reduce_scatter(acc0 + acc1);
+    return rows_reduce_scatter((acc0 + acc1) + (acc2 + acc3));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -123,9 +142,10 @@ __device__ __forceinline__ float transposed_product(const float (&wv)[H], const 
 // (every role is a real function call with its own register allocation -- inlined into one body, hipcc spilled the dW accumulators
 // inside the step loop -- and works on a LOCAL copy of the argument block: the step barrier is an asm statement with a memory clobber)
 template <int LAYER>
-__device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, const int g, const int lane, const int n_steps) {
+__device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, const int g_in, const int lane, const int n_steps_in) {
     BSmem &sm = g_bsm;
-    const Lstm2BwdArgs a = a_in;
+    const int g = __builtin_amdgcn_readfirstlane(g_in), n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);    // (arguments arrive in VGPRs: uniform_copy's comment)
+    const Lstm2BwdArgs a = uniform_copy(a_in);
     const int r = lane >> 4, ub = (lane >> 2) & 3, j = lane & 3;
     const int u = 16 * g + 4 * ub + r;                              // this lane's cell after the reduce-scatter
     const int T = a.T, B = a.B;
@@ -148,35 +168,42 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
         // time index of macro step m, clamped for the prefetches (values of inactive steps are never used)
         auto t_of = [&](const int m) { return LAYER == 1 ? T - 1 - m : T + 1 - m; };
         auto clampt = [&](const int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
-        f32x4 gq[2];
-        float cq[2];                                               // c[t-1] of the step
+        f32x4 gq[CHD];
+        float cq[CHD];                                             // c[t-1] of the step
         auto prefetch = [&](const int m, f32x4 &gv, float &cv) {
             const int t = clampt(t_of(m)), tp = clampt(t_of(m) - 1);
             gv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_g, (int)vo16, t * (H * 16), 0));
             cv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_c, (int)vo4, tp * (H * 4), 0));
         };
         float ct = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_c, (int)vo4, (T - 1) * (H * 4), 0));     // c[T-1] of the first step
-        prefetch(0, gq[0], cq[0]);
-        prefetch(1, gq[1], cq[1]);
+#pragma unroll
+        for (int k = 0; k < CHD; ++k) prefetch(k, gq[k], cq[k]);
+        // (weights in registers before the loop: otherwise hipcc carries "loads pending" into the loop and every wait inside it becomes vmcnt(0))
+#pragma unroll
+        for (int s4 = 0; s4 < H; s4 += 8)
+            asm volatile("" : "+v"(wv[s4]), "+v"(wv[s4 + 1]), "+v"(wv[s4 + 2]), "+v"(wv[s4 + 3]), "+v"(wv[s4 + 4]), "+v"(wv[s4 + 5]), "+v"(wv[s4 + 6]), "+v"(wv[s4 + 7]));
         if (LAYER == 0 && g == 0) {                                 // zero the da slots and d_in1 of the group (one wave: 3 328 + 512 floats)
             for (int e = lane; e < 2 * 2 * NTR * VSD; e += 64) (&sm.da[0][0][0][0])[e] = 0.f;
             for (int e = lane; e < 2 * NTR * VS1; e += 64) (&sm.din1[0][0][0])[e] = 0.f;
         }
         xstep_barrier(prof);
-        for (int m0 = 0; m0 < n_steps; m0 += 2) {
+        for (int m0 = 0; m0 < n_steps; m0 += CHD) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < CHD; ++k) {
                 const int m = m0 + k;
                 const int t = t_of(m);
                 const bool active = t >= 0 && t < T, prev_active = t + 1 >= 0 && t + 1 < T;
                 // ---- what does not depend on the recurrence: the derivative factors of this cell, the gradient arriving from above
-                const f32x4 gc = gq[k];
                 const float cprev = t > 0 ? cq[k] : 0.f;
-                prefetch(m + 2, gq[k], cq[k]);                      // (the registers are free again: two steps ahead)
-                const float ig = gc[0], fg = gc[1], gg = gc[2], og = gc[3];
+                const float ig = gq[k][0], fg = gq[k][1], gg = gq[k][2], og = gq[k][3];
                 const float tc = fast_tanh(ct);
-                const float wq = og * (1.f - tc * tc);              // d c_t / d h_t
-                const float Fi = gg * ig * (1.f - ig), Ff = cprev * fg * (1.f - fg), Fg = ig * (1.f - gg * gg), Fo = tc * og * (1.f - og);
+                float wq = og * (1.f - tc * tc);                    // d c_t / d h_t
+                float Fi = gg * ig * (1.f - ig), Ff = cprev * fg * (1.f - fg), Fg = ig * (1.f - gg * gg), Fo = tc * og * (1.f - og);
+                float fgk = fg, cpk = cprev;
+                // (the step's saved values are consumed: pinned here, so that the loads below may land in the SAME registers -- with the
+                // old values still live hipcc rotates the prefetch registers with copies in the loop latch and waits for the loads there)
+                asm volatile("" : "+v"(wq), "+v"(Fi), "+v"(Ff), "+v"(Fg), "+v"(Fo), "+v"(fgk), "+v"(cpk));
+                if (!ablated(a.ablate, 16)) prefetch(m + CHD, gq[k], cq[k]);     // CHD steps ahead
                 float dout;
                 if (LAYER == 1) {
                     const float2 ad = *reinterpret_cast<const float2 *>(&sm.sc[(m >> 4) & 1][j][m & (XCH - 1)][0]);
@@ -187,17 +214,17 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
                 }
                 // ---- the recurrence
                 float rec = 0.f;
-                if (prev_active) rec = transposed_product(wv, &sm.da[(k + 1) & 1][LAYER][j][48 * r]);
+                if (prev_active) rec = transposed_product(wv, &sm.da[(k + 1) & 1][LAYER][j][48 * r], a.ablate);
                 f32x4 dav = {0.f, 0.f, 0.f, 0.f};
                 if (active && vb) {
                     const float dht = dout + rec;
                     const float dct = fmaf(dht, wq, dc);
                     dav = f32x4{dct * Fi, dct * Ff, dct * Fg, dht * Fo};
-                    dc = dct * fg;
+                    dc = dct * fgk;
                     db[0] += dav[0]; db[1] += dav[1]; db[2] += dav[2]; db[3] += dav[3];
                 }
-                if (active) ct = cprev;                             // c[t-1] is the cell state of the next step handled
-                *reinterpret_cast<f32x4 *>(&sm.da[k][LAYER][j][4 * u]) = dav;      // (zeros for inactive steps / padding trials: dW and X1 add nothing)
+                if (active) ct = cpk;                               // c[t-1] is the cell state of the next step handled
+                *reinterpret_cast<f32x4 *>(&sm.da[k & 1][LAYER][j][4 * u]) = dav;      // (zeros for inactive steps / padding trials: dW and X1 add nothing)
                 xstep_barrier(prof);
             }
         }
@@ -224,9 +251,10 @@ __device__ __forceinline__ void dwx_trial(const float (&a3)[4], const float bx, 
 // ------------------------------------------------------------------------------------------------
 // X1: d_in1[t] = W_ih1^T da1[t], t = T - m (da1 written at macro step m - 1) -> LDS for the layer-0 recurrence of macro step m + 1
 // ------------------------------------------------------------------------------------------------
-__device__ __attribute__((noinline)) void x1_role(const Lstm2BwdArgs &a_in, const int g, const int lane, const int n_steps) {
+__device__ __attribute__((noinline)) void x1_role(const Lstm2BwdArgs &a_in, const int g_in, const int lane, const int n_steps_in) {
     BSmem &sm = g_bsm;
-    const Lstm2BwdArgs a = a_in;
+    const int g = __builtin_amdgcn_readfirstlane(g_in), n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);
+    const Lstm2BwdArgs a = uniform_copy(a_in);
     const int r = lane >> 4, ub = (lane >> 2) & 3, j = lane & 3;
     const int u = 16 * g + 4 * ub + r;
     const int T = a.T, B = a.B, C = a.C;
@@ -235,37 +263,27 @@ __device__ __attribute__((noinline)) void x1_role(const Lstm2BwdArgs &a_in, cons
     // dW_ih0 = da0 (x) x[t] (outer-product form, see the dW waves): row tiles 4g .. 4g + 3 of k', the one 16-column tile of the channels
     const int a3_off = ((lane >> 2) & 3) * VSD + 16 * (4 * g) + 4 * (lane >> 4) + (lane & 3);      // + 16 q: lane (rb, tr, i)
     const int xc = 4 * ((lane >> 2) & 3) + (lane & 3);              // B operand lane (tr = lane >> 4, cb, jj): channel 4 cb + jj
-    const rsrc_t r_x = make_rsrc(a.x, (long)B * T * C * 4);
     f32x4 acc3[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc3[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     Prof prof = prof_init(a.dbg);
     const int ngrp = (B + NTR - 1) / NTR;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
-        const int bb = grp * NTR + (lane >> 4);
-        const unsigned vox = (bb < B && xc < C) ? (unsigned)(((size_t)bb * T * C + xc) * 4) : VOFF_DROP;
-        auto prefetch = [&](const int m) -> float {                 // x row of the da0 written at macro step m - 1: t = T + 2 - m
-            const int tx = T + 2 - m;
-            const bool okx = tx >= 0 && tx < T;
-            const float xv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_x, (int)vox, (okx ? tx : 0) * (C * 4), 0));
-            return okx ? xv : 0.f;
-        };
-        float bxq[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bxq[k] = prefetch(k);
+        for (int s4 = 0; s4 < H; s4 += 8)
+            asm volatile("" : "+v"(wv[s4]), "+v"(wv[s4 + 1]), "+v"(wv[s4 + 2]), "+v"(wv[s4 + 3]), "+v"(wv[s4 + 4]), "+v"(wv[s4 + 5]), "+v"(wv[s4 + 6]), "+v"(wv[s4 + 7]));
         xstep_barrier(prof);
         for (int m0 = 0; m0 < n_steps; m0 += 4) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int m = m0 + k, t1p = T - m;
-                if (t1p >= 0 && t1p < T) sm.din1[k & 1][j][u] = transposed_product(wv, &sm.da[(k + 1) & 1][1][j][48 * r]);
+                if (t1p >= 0 && t1p < T) sm.din1[k & 1][j][u] = transposed_product(wv, &sm.da[(k + 1) & 1][1][j][48 * r], a.ablate);
                 const float *da0 = &sm.da[(k + 1) & 1][0][0][0];
                 float a3[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a3[q] = da0[a3_off + 16 * q];
-                const float bx = bxq[k];
-                bxq[k] = prefetch(m + 4);
-                if (m >= 1) {
+                const float bx = sm.xs[(m >> 4) & 1][lane >> 4][m & (XCH - 1)][xc];       // x[T + 2 - m] of trial lane >> 4 (staged by the aux wave)
+                if (m >= 1 && !ablated(a.ablate, 1)) {
                     dwx_trial<0>(a3, bx, acc3);
                     dwx_trial<1>(a3, bx, acc3);
                     dwx_trial<2>(a3, bx, acc3);
@@ -302,9 +320,10 @@ __device__ __forceinline__ void dw_trial(const float (&av)[6], const float (&bv)
 }
 
 
-__device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, const int d, const int lane, const int n_steps) {
+__device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, const int d_in, const int lane, const int n_steps_in) {
     BSmem &sm = g_bsm;
-    const Lstm2BwdArgs a = a_in;
+    const int d = __builtin_amdgcn_readfirstlane(d_in), n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);
+    const Lstm2BwdArgs a = uniform_copy(a_in);
     const int Q = d >> 1, half = d & 1;
     const int T = a.T, B = a.B;
     // A operand: lane (rb = lane >> 4, tr = (lane >> 2) & 3, i = lane & 3) = da[tr][16 rt + 4 rb + i]; B operand: lane (tr = lane >> 4, cb, jj)
@@ -325,45 +344,51 @@ __device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, cons
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int bb = grp * NTR + b_tr;
         const bool vb = bb < B;
-        const unsigned vo = vb ? (unsigned)(((size_t)bb * T * H + 4 * b_cb + b_jj) * 4) : VOFF_DROP;     // + 64 ct bytes
+        const unsigned vo = vb ? (unsigned)(((size_t)bb * T * H + 3 * (4 * b_cb + b_jj)) * 4) : VOFF_DROP;
         // B rows of macro step m (pairing with the da written at macro step m - 1); out of range: zeros
         auto prefetch = [&](const int m, float (&bv)[3]) {
             const int t = Q == 2 ? T + 2 - m : T - m;               // the step whose da is used
             const int tt = Q == 1 ? t : t - 1;                      // row of the saved sequence
             const bool ok = t >= 0 && t < T && tt >= 0;
             const int tc = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
+            const unsigned voe = ok ? vo : VOFF_DROP;               // (the ADDRESS is switched, not the value: a select on the loaded value is a wait for the load)
+            // ONE 12-byte load per lane: columns 3c .. 3c + 2, c = 4 cb + jj -- "column tile" v of the accumulators = the columns = v (mod 3).
+            // (Every vector-memory instruction of the step costs ~2.5 us per launch whatever it moves: three dword loads were three of them.)
+            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+#if NSD_BX4_B96
+            const u32x3 v3 = __builtin_amdgcn_raw_buffer_load_b96(r_s, (int)voe, tc * (H * 4), 0);
+            bv[0] = __uint_as_float(v3[0]); bv[1] = __uint_as_float(v3[1]); bv[2] = __uint_as_float(v3[2]);
+#else
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
-                const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_s, (int)(vo + 64u * ct), tc * (H * 4), 0));
-                bv[ct] = ok ? v : 0.f;
-            }
+            for (int ct = 0; ct < 3; ++ct) bv[ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_s, (int)(voe + 4u * ct), tc * (H * 4), 0));
+#endif
         };
-        float bq[4][3];
+        float bq[DWD][3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) prefetch(k, bq[k]);
+        for (int k = 0; k < DWD; ++k) prefetch(k, bq[k]);
         xstep_barrier(prof);
-        for (int m0 = 0; m0 < n_steps; m0 += 4) {
+        for (int m0 = 0; m0 < n_steps; m0 += DWD) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < DWD; ++k) {
                 const int m = m0 + k;
-                const float *dal = &sm.da[(k + 1) & 1][layerQ][0][0];
+                const float *dal = &sm.da[(m + 1) & 1][layerQ][0][0];
                 float av[6];
 #pragma unroll
                 for (int q = 0; q < 6; ++q) av[q] = dal[a_off + 16 * q];
-                float bv[3] = {bq[k][0], bq[k][1], bq[k][2]};
-                prefetch(m + 4, bq[k]);
                 if (m >= 1 && !ablated(a.ablate, 1)) {
-                    dw_trial<0>(av, bv, acc);
-                    dw_trial<1>(av, bv, acc);
-                    dw_trial<2>(av, bv, acc);
-                    dw_trial<3>(av, bv, acc);
+                    dw_trial<0>(av, bq[k], acc);
+                    dw_trial<1>(av, bq[k], acc);
+                    dw_trial<2>(av, bq[k], acc);
+                    dw_trial<3>(av, bq[k], acc);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!ablated(a.ablate, 8)) prefetch(m + DWD, bq[k]);     // (behind the MFMAs that read these registers: the loads land in place)
                 xstep_barrier(prof);
             }
         }
     }
     prof_store(a.dbg, prof);
-    // accumulator tile -> slab: lane (rb = lane >> 4, cb, jj) register i = dW[k' = 16 rt + 4 rb + i][16 ct + 4 cb + jj]
+    // accumulator tile -> slab: lane (rb = lane >> 4, cb, jj) register i = dW[k' = 16 rt + 4 rb + i][3 (4 cb + jj) + ct]
     float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
     const long base = Q == 0 ? a.o_w_hh1 : Q == 1 ? a.o_w_ih1 : a.o_w_hh0;
     const int rb = lane >> 4, cb = (lane >> 2) & 3, jj = lane & 3;
@@ -374,7 +399,7 @@ __device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, cons
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int kp = 16 * (6 * half + q) + 4 * rb + i;
-                slab[base + (size_t)((kp & 3) * H + (kp >> 2)) * H + 16 * ct + 4 * cb + jj] = acc[q][ct][i];
+                slab[base + (size_t)((kp & 3) * H + (kp >> 2)) * H + 3 * (4 * cb + jj) + ct] = acc[q][ct][i];
             }
 }
 
@@ -382,9 +407,10 @@ __device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, cons
 // aux wave: {alpha, dscore} of the layer-1 steps and the layer-0 dropout multipliers, one 16-step chunk ahead
 // ------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(1))) f32x4 *gf32x4_p;
-__device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, const int lane, const int n_steps) {
+__device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, const int lane, const int n_steps_in) {
     BSmem &sm = g_bsm;
-    const Lstm2BwdArgs a = a_in;
+    const int n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);
+    const Lstm2BwdArgs a = uniform_copy(a_in);
     const int T = a.T, B = a.B;
     Prof prof = prof_init(a.dbg);
     const int ngrp = (B + NTR - 1) / NTR;
@@ -412,10 +438,23 @@ __device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, con
             sm.mk[buf][n][m & (XCH - 1)][uu] = mkv;
         }
     };
+    // x rows of chunk c: 4 trials x 16 steps x 16 floats (channels >= C: zeros) = 256 float4, 4 per lane
+    typedef const __attribute__((address_space(1))) float *gfloat_p;
+    auto x_at = [&](const int b0, const int c, const int e) -> f32x4 {        // e: float4 index in [0, NTR*XCH*4)
+        const int n = e >> 6, s = (e >> 2) & 15, q = e & 3, b = b0 + n, t = T + 2 - (16 * c + s);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < B && t >= 0 && t < T) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (4 * q + i < a.C) v[i] = ((gfloat_p)a.x)[((size_t)b * T + t) * a.C + 4 * q + i];
+        }
+        return v;
+    };
     constexpr int MPL = NTR * XCH * 12 / 64;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NTR;
         *reinterpret_cast<f32x4 *>(&sm.sc[0][0][0][0] + 4 * lane) = sc_at(b0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(&sm.xs[0][0][0][0] + 4 * (lane + 64 * q)) = x_at(b0, 0, lane + 64 * q);
         if (a.rng.on) {
 #pragma unroll 1
             for (int s = 0; s < XCH; ++s) rng_row(b0, s, 0);
@@ -427,6 +466,9 @@ __device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, con
         for (int m0 = 0; m0 < n_steps; m0 += XCH) {
             const int c = m0 >> 4, cb = c & 1;
             const f32x4 scr = sc_at(b0, c + 1);
+            f32x4 xr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[q] = x_at(b0, c + 1, lane + 64 * q);
             f32x4 mr[MPL];
             if (!a.rng.on) {
 #pragma unroll
@@ -437,6 +479,8 @@ __device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, con
                 if (a.rng.on) rng_row(b0, m0 + XCH + k, cb ^ 1);
                 if (k == XCH - 1) {
                     *reinterpret_cast<f32x4 *>(&sm.sc[cb ^ 1][0][0][0] + 4 * lane) = scr;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(&sm.xs[cb ^ 1][0][0][0] + 4 * (lane + 64 * q)) = xr[q];
                     if (!a.rng.on) {
 #pragma unroll
                         for (int q = 0; q < MPL; ++q) *reinterpret_cast<f32x4 *>(&sm.mk[cb ^ 1][0][0][0] + 4 * (lane + 64 * q)) = mr[q];
@@ -463,11 +507,15 @@ __global__ __launch_bounds__(NTHR) void lstm2_bwd48x4_kernel(Lstm2BwdArgs a) {
     else aux_role(a, lane, n_steps);
     return;
 #endif
-    if (g < 3 && q == 0)      { __builtin_amdgcn_s_setprio(3); chain_role<1>(a, g, lane, n_steps); }
-    else if (g < 3 && q == 1) { __builtin_amdgcn_s_setprio(3); chain_role<0>(a, g, lane, n_steps); }
-    else if (g < 3 && q == 2) { __builtin_amdgcn_s_setprio(2); x1_role(a, g, lane, n_steps); }
-    else if (g < 3)           dw_role(a, g, lane, n_steps);                 // dW waves 0..2
-    else if (q < 3)           dw_role(a, 3 + q, lane, n_steps);             // dW waves 3..5
+#ifndef NSD_BX4_PRIO
+#define NSD_BX4_PRIO 0
+#endif
+    constexpr int PC = NSD_BX4_PRIO == 0 ? 3 : NSD_BX4_PRIO == 1 ? 0 : 1, PX = NSD_BX4_PRIO == 0 ? 2 : NSD_BX4_PRIO == 1 ? 0 : 1, PD = NSD_BX4_PRIO == 2 ? 3 : 0;
+    if (g < 3 && q == 0)      { __builtin_amdgcn_s_setprio(PC); chain_role<1>(a, g, lane, n_steps); }
+    else if (g < 3 && q == 1) { __builtin_amdgcn_s_setprio(PC); chain_role<0>(a, g, lane, n_steps); }
+    else if (g < 3 && q == 2) { __builtin_amdgcn_s_setprio(PX); x1_role(a, g, lane, n_steps); }
+    else if (g < 3)           { __builtin_amdgcn_s_setprio(PD); dw_role(a, g, lane, n_steps); }                 // dW waves 0..2
+    else if (q < 3)           { __builtin_amdgcn_s_setprio(PD); dw_role(a, 3 + q, lane, n_steps); }             // dW waves 3..5
     else                      aux_role(a, lane, n_steps);
     // a workgroup without a trial group (grid = the workspace's slab count) has written a zero slab: every role's sums are zero
 }

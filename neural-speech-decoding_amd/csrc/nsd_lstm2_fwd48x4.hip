@@ -413,9 +413,10 @@ __device__ __forceinline__ void rng_row(const Lstm2FwdArgs &a, XSmem &sm, const 
         sm.ms[buf][n][tl][u] = mk;
     }
 }
-__device__ __attribute__((noinline)) void stage_role(const Lstm2FwdArgs &a_in, const int lane, const int n_steps, const int grp) {
+__device__ __attribute__((noinline)) void stage_role(const Lstm2FwdArgs &a_in, const int lane, const int n_steps_in, const int grp_in) {
     XSmem &sm = g_sm;
-    const Lstm2FwdArgs a = a_in;
+    const int n_steps = __builtin_amdgcn_readfirstlane(n_steps_in), grp = __builtin_amdgcn_readfirstlane(grp_in);   // (arguments arrive in VGPRs)
+    const Lstm2FwdArgs a = uniform_copy(a_in);
     constexpr int XPL = NTR * XCH * 8 / 64;                          // 8 x floats per lane and chunk
     constexpr int MPL = NTR * XCH * 12 / 64;                         // 12 multiplier float4 per lane and chunk
     Prof prof = prof_init(a.dbg);
@@ -585,9 +586,10 @@ __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, XSmem &sm, con
 }
 
 // what every wave does after the last step of a trial group when the head is fused
-__device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a_in, const int tid, const int b0) {
+__device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a_in, const int tid, const int b0_in) {
     XSmem &sm = g_sm;
-    const Lstm2FwdArgs a = a_in;
+    const int b0 = __builtin_amdgcn_readfirstlane(b0_in);
+    const Lstm2FwdArgs a = uniform_copy(a_in);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's h rows are in memory before the workgroup reads them back
     __syncthreads();                                                // ... and the pooling waves have left the four trials' dense-head results in LDS
 #pragma unroll 1
@@ -676,9 +678,10 @@ __device__ __forceinline__ void dense_head(const Lstm2FwdArgs &a, XSmem &sm, con
 // pooling wave `pw` (0 / 1) takes trials 2 pw and 2 pw + 1 of the group.  Chunk c of a trial (t = 8c .. 8c + 7) is complete in the
 // ring when macro step 8c + 9 has ended and is overwritten from macro step 8c + 18 on: its eight stage-steps (4 stages x 2 trials)
 // run in the macro steps 8c + 10 .. 8c + 17.
-__device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a_in, const int pw, const int lane, const int n_steps, const int grp) {
+__device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a_in, const int pw_in, const int lane, const int n_steps_in, const int grp_in) {
     XSmem &sm = g_sm;
-    const Lstm2FwdArgs a = a_in;
+    const int pw = __builtin_amdgcn_readfirstlane(pw_in), n_steps = __builtin_amdgcn_readfirstlane(n_steps_in), grp = __builtin_amdgcn_readfirstlane(grp_in);
+    const Lstm2FwdArgs a = uniform_copy(a_in);
     const int T = a.T, K = a.K, F = a.F;
     float awp[6];
 #pragma unroll

@@ -71,6 +71,72 @@ __global__ __launch_bounds__(512) void rate_kernel(const float *w, float *out, l
     out[threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
+// the outer-product form of the weight gradients: 18 accumulators, A with CBSZ = 2 / ABID = t, B with BLGP = 4 + t
+template <int T> __device__ __forceinline__ f32x4 outer(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 2, T, 4 + T); }
+template <bool BCAST>
+__global__ __launch_bounds__(1024) void outer_kernel(const float *w, float *out, long long *cycles, int iters, int waves_per_simd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((wave >> 2) >= waves_per_simd) return;
+    float a[6], b[3];
+    for (int k = 0; k < 6; ++k) a[k] = w[k * 64 + lane];
+    for (int k = 0; k < 3; ++k) b[k] = w[1024 + k * 64 + lane];
+    f32x4 acc[6][3];
+    for (int q = 0; q < 6; ++q) for (int c = 0; c < 3; ++c) acc[q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (BCAST) {
+                    acc[q][c] = outer<0>(a[q], b[c], acc[q][c]); acc[q][c] = outer<1>(a[q], b[c], acc[q][c]);
+                    acc[q][c] = outer<2>(a[q], b[c], acc[q][c]); acc[q][c] = outer<3>(a[q], b[c], acc[q][c]);
+                } else {
+                    for (int t = 0; t < 4; ++t) acc[q][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[q], b[c], acc[q][c], 0, 0, 0);
+                }
+            }
+    }
+    const long long t1 = clock64();
+    f32x4 s = acc[0][0];
+    for (int q = 0; q < 6; ++q) for (int c = 0; c < 3; ++c) s += acc[q][c];
+    if (lane == 0) cycles[wave] = t1 - t0;
+    out[threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+template <bool BCAST>
+__global__ __launch_bounds__(1024) void outer_kernel_interleaved(const float *w, float *out, long long *cycles, int iters, int waves_per_simd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((wave >> 2) >= waves_per_simd) return;
+    float a[6], b[3];
+    for (int k = 0; k < 6; ++k) a[k] = w[k * 64 + lane];
+    for (int k = 0; k < 3; ++k) b[k] = w[1024 + k * 64 + lane];
+    f32x4 acc[6][3];
+    for (int q = 0; q < 6; ++q) for (int c = 0; c < 3; ++c) acc[q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {                  // trial-major: consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[q][c] = outer<0>(a[q], b[c], acc[q][c]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[q][c] = outer<1>(a[q], b[c], acc[q][c]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[q][c] = outer<2>(a[q], b[c], acc[q][c]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[q][c] = outer<3>(a[q], b[c], acc[q][c]);
+    }
+    const long long t1 = clock64();
+    f32x4 s = acc[0][0];
+    for (int q = 0; q < 6; ++q) for (int c = 0; c < 3; ++c) s += acc[q][c];
+    if (lane == 0) cycles[wave] = t1 - t0;
+    out[threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
 static int check(const char *what, const float *got, const float *want) {
     int bad = 0;
     for (int i = 0; i < 256; ++i) if (got[i] != want[i]) ++bad;
@@ -108,7 +174,7 @@ int main() {
 
     // (3) issue rate
     float *w, *out; long long *cyc;
-    hipMalloc(&w, 4096 * 4); hipMalloc(&out, 1024 * 4); hipMalloc(&cyc, 64);
+    hipMalloc(&w, 4096 * 4); hipMalloc(&out, 1024 * 4); hipMalloc(&cyc, 128);
     float hw[4096];
     for (int i = 0; i < 4096; ++i) hw[i] = 1e-3f * (float)((i * 37) % 101);
     hipMemcpy(w, hw, sizeof(hw), hipMemcpyHostToDevice);
@@ -131,6 +197,16 @@ int main() {
         hipMemcpy(hc, cyc, 64, hipMemcpyDeviceToHost);
         printf("TWO MFMA waves per SIMD, chains=%d: %.2f ticks per MFMA of wave 0, %.2f of wave 4 -> one MFMA per %.2f ticks on the SIMD\n", chains,
                (double)hc[0] / (32.0 * iters), (double)hc[4] / (32.0 * iters), (double)hc[0] / (64.0 * iters));
+    }
+    for (int wps = 1; wps <= 4; ++wps) {
+        hipMemset(cyc, 0, 128);
+        hipLaunchKernelGGL((outer_kernel_interleaved<true>), dim3(256), dim3(1024), 0, 0, w, out, cyc, 500, wps);
+        hipLaunchKernelGGL((outer_kernel_interleaved<true>), dim3(256), dim3(1024), 0, 0, w, out, cyc, 500, wps);
+        hipDeviceSynchronize();
+        long long hc2[16];
+        hipMemcpy(hc2, cyc, 128, hipMemcpyDeviceToHost);
+        printf("outer-product form (CBSZ=2, ABID=t, BLGP=4+t), 18 accumulators, %d wave(s) per SIMD: %.2f ticks per MFMA per wave -> one per %.2f ticks on the SIMD\n", wps,
+               (double)hc2[0] / (72.0 * 500), (double)hc2[0] / (72.0 * 500 * wps));
     }
     for (int partner = 0; partner < 2; ++partner) {
         for (int chains = 1; chains <= 4; chains *= 2) {
