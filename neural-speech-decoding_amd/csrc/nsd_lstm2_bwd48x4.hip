@@ -4,8 +4,8 @@
 // Replaces autograd through self.lstm(x) (Neuro-Alpha-App/Utilities/lstm_eeg_model.py:34) like nsd_lstm2_bwd48.hip (one or two
 // trials per workgroup: transposed mat-vecs as v_pk_fma_f32 with DPP reductions, ~1 300 cycles per trial-step and issue-bound).
 // With four trials every product of a step is a small GEMM with N = 4 and runs as v_mfma_f32_4x4x1_16B_f32 (16 blocks per
-// instruction, D_b[4x4] += A_b[4x1] * B_b[1x4]; operand layout, broadcast modifiers and rate: tools/micro/mfma4x4.hip -- two
-// waves of a SIMD together issue one every ~4.4 cycles, twice the nominal fp32 rate):
+// instruction, D_b[4x4] += A_b[4x1] * B_b[1x4]; operand layout, broadcast modifiers and rate: tools/micro/mfma4x4.hip -- the SIMD's
+// matrix pipe takes one per 8 cycles = the nominal fp32 rate, and the 912 of a step make this kernel matrix-pipe-bound):
 //
 //   * the transposed products dh[u][trial] = sum_k W[k][u] da[k][trial] (W_hh1, W_ih1, W_hh0: 48 outputs x 192 k each).  A wave owns
 //     16 output units and splits k over the four 16-lane ROWS of the instruction: block (row ks, ub) = units 4ub..4ub+3 x the
@@ -126,8 +126,8 @@ __device__ __forceinline__ float transposed_product(const float (&wv)[H], const 
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(vj + 4 * (qb + q));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                                   // four accumulator chains: with four waves per SIMD in the pipe a dependent
-            acc0 = mfma_plain(wv[4 * (qb + q) + 0], bq[q][0], acc0);    // MFMA waits well over its own 8 cycles for its predecessor
+        for (int q = 0; q < 4; ++q) {                                   // four accumulator chains (a dependent 4x4x1 issues every ~12.8 cycles,
+            acc0 = mfma_plain(wv[4 * (qb + q) + 0], bq[q][0], acc0);    // independent ones every ~8.8)
             acc1 = mfma_plain(wv[4 * (qb + q) + 1], bq[q][1], acc1);
             acc2 = mfma_plain(wv[4 * (qb + q) + 2], bq[q][2], acc2);
             acc3 = mfma_plain(wv[4 * (qb + q) + 3], bq[q][3], acc3);

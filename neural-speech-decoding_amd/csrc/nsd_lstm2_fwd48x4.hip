@@ -12,9 +12,10 @@
 //     D register i of lane (b, j) = gate i of unit b, trial j  -- the four gates of a cell in ONE lane: the cell update is in-lane,
 //                                                                no cross-lane traffic, every lane useful
 //   (layout and broadcast modifiers probed on the hardware: tools/micro/mfma4x4.hip; exact fp32, an fmaf chain over k.)
-//   One instruction = 16 units x 4 gates x 4 trials x 1 k = 512 FLOP in 8 cycles = the SIMD's full fp32 rate, for ONE issue slot --
-//   456 per 4-trial step against ~2 900 VALU instructions in the one-trial kernel -- and a VALU wave on the same SIMD runs beside
-//   the MFMA stream at its own speed (same probe), so the cells hide behind the other layer's products.
+//   One instruction = 16 units x 4 gates x 4 trials x 1 k = 512 FLOP in 8 cycles of the SIMD's matrix pipe = the nominal fp32 rate
+//   (64 FLOP/clk/SIMD; the pipe takes one per 8 cycles however many waves feed it: SQ_VALU_MFMA_BUSY_CYCLES = 8 per instruction), for
+//   ONE issue slot -- 456 per 4-trial step against ~2 900 VALU instructions in the one-trial kernel -- and a VALU wave on the same SIMD
+//   runs beside the MFMA stream at its own speed (same probe), so the cells hide behind the other layer's products.
 //
 // 12 waves, role = f(SIMD g = wave & 3, slot q = wave >> 2); one barrier per macro step m; layer 1 two steps behind layer 0:
 //   g 0..2, q 1  "L0"  layer 0, units 16g..16g+15, t = m    : W_ih0 x_t + W_hh0 h0_{t-1} (56 MFMAs), cells, h0 / masked h0 -> LDS
@@ -509,31 +510,39 @@ __device__ __forceinline__ void pool_stage(const int stage, PoolRun &p, XSmem &s
     }
 }
 
-__device__ __forceinline__ float tail_block_sum(float v, float *red, const int tid) {
+// Sum over the 192 threads (3 waves) of a TEAM; every team of the workgroup calls it at the same time (the barriers are the workgroup's)
+constexpr int TEAM = NTHR / NTR;                                   // 192 threads = 3 waves per trial
+constexpr int TPARTS = TEAM / H;                                   // 4
+__device__ __forceinline__ float team_sum(float v, float *red /* [NTHR / 64] */, const int tid) {
     v = wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < NTHR / 64; ++w) s += red[w];
+    const int w0 = 3 * (tid / TEAM);
+    const float s = (red[w0] + red[w0 + 1]) + red[w0 + 2];
     __syncthreads();
     return s;
 }
 
-// every wave, trial n of the group (after the pooling waves left dpooled / the softmax statistics of the trial in LDS and the
-// layer-1 waves' h rows are in memory): alpha_t, dL/dscore_t = alpha_t (dpooled . top_t - sum_s alpha_s dpooled . top_s), d attn.*
-__device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, XSmem &sm, const int tid, const int b, const int n) {
+// The tail of the fused train head, ALL FOUR TRIALS AT ONCE: team n = waves 3n .. 3n + 2 takes trial n (after the pooling waves left
+// dpooled / the softmax statistics of every trial in LDS and the layer-1 waves' h rows are in memory): alpha_t, dL/dscore_t =
+// alpha_t (dpooled . top_t - sum_s alpha_s dpooled . top_s), d attn.weight, d attn.bias.  (One trial after the other with all twelve
+// waves on it, the tail took 37 us of a 300-us launch: its phases are latency -- barriers, the rows read back from memory -- not work.)
+__device__ __forceinline__ void train_tail4(const Lstm2FwdArgs &a, XSmem &sm, const int tid, const int b0) {
     const int T = a.T;
+    const int n = tid / TEAM, tt = tid - n * TEAM;                  // team = trial, thread of the team
+    const int b = b0 + n;
+    const bool vb = b < a.B;
     float *sc = sm.sc[n];
-    const float *top = a.hseq1 + (size_t)b * T * H;
+    const float *top = a.hseq1 + (size_t)(vb ? b : 0) * T * H;
     const float mx = sm.md[n][0], rden = sm.md[n][1];
-    float al[2], dd[2];
+    constexpr int NQ = (TT_TMAX + TEAM - 1) / TEAM;                 // 6 time steps per thread at most
+    float al[NQ], dd[NQ];
     float lsd = 0.f;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int t = tid + q * NTHR;
+    for (int q = 0; q < NQ; ++q) {
+        const int t = tt + q * TEAM;
         al[q] = 0.f; dd[q] = 0.f;
-        if (t < T) {
+        if (t < T && vb) {
             al[q] = __expf(sc[t] - mx) * rden;
             const float4 *rowp = reinterpret_cast<const float4 *>(top + (size_t)t * H);
             float d0 = 0.f, d1 = 0.f;
@@ -547,12 +556,12 @@ __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, XSmem &sm, con
             lsd = fmaf(al[q], dd[q], lsd);
         }
     }
-    const float sdot = tail_block_sum(lsd, sm.red, tid);
+    const float sdot = team_sum(lsd, sm.red, tid);
     float lb = 0.f;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int t = tid + q * NTHR;
-        if (t < T) {
+    for (int q = 0; q < NQ; ++q) {
+        const int t = tt + q * TEAM;
+        if (t < T && vb) {
             const float ds = al[q] * (dd[q] - sdot);
             a.alpha[(size_t)b * T + t] = al[q];
             a.dscore[(size_t)b * T + t] = ds;
@@ -561,26 +570,36 @@ __device__ __forceinline__ void train_tail(const Lstm2FwdArgs &a, XSmem &sm, con
             lb += ds;
         }
     }
-    const float dab = tail_block_sum(lb, sm.red, tid);
-    float *slab = a.hslabs + (size_t)b * a.Ph;
-    if (tid == 0) slab[a.o_attn_b] = dab;
-    if (tid < TT_PARTS * H) {
-        const int part = tid / H, j = tid - part * H;
+    const float dab = team_sum(lb, sm.red, tid);                    // (its barriers also publish sc[] = dscore)
+    float *slab = a.hslabs + (size_t)(vb ? b : 0) * a.Ph;
+    if (tt == 0 && vb) slab[a.o_attn_b] = dab;
+    // d attn.weight[j] = sum_t dscore_t top_t[j]: thread (part, j) of the team sums the steps t == part (mod 4)
+    {
+        const int part = tt / H, j = tt - part * H;
         float s0 = 0.f, s1 = 0.f;
-        int t = part;
-        for (; t + TT_PARTS < T; t += 2 * TT_PARTS) {
-            s0 = fmaf(sc[t], top[(size_t)t * H + j], s0);
-            s1 = fmaf(sc[t + TT_PARTS], top[(size_t)(t + TT_PARTS) * H + j], s1);
+        if (vb) {
+            // eight rows in flight per thread (the rows are L2 hits by now; one row per iteration was one L2 latency per row: 63 of them)
+            for (int t = part; t < T; t += 8 * TPARTS) {
+                float v[8], w[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int tq = t + q * TPARTS;
+                    const bool ok = tq < T;
+                    v[q] = top[(size_t)(ok ? tq : 0) * H + j];
+                    w[q] = ok ? sc[ok ? tq : 0] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) { s0 = fmaf(w[q], v[q], s0); s1 = fmaf(w[q + 1], v[q + 1], s1); }
+            }
         }
-        if (t < T) s0 = fmaf(sc[t], top[(size_t)t * H + j], s0);
-        sm.part[part][j] = s0 + s1;
+        sm.part[n * TPARTS + part][j] = s0 + s1;
     }
     __syncthreads();
-    if (tid < H) {
+    if (tt < H && vb) {
         float s = 0.f;
 #pragma unroll
-        for (int p = 0; p < TT_PARTS; ++p) s += sm.part[p][tid];
-        slab[a.o_attn_w + tid] = s;
+        for (int p = 0; p < TPARTS; ++p) s += sm.part[n * TPARTS + p][tt];
+        slab[a.o_attn_w + tt] = s;
     }
     __syncthreads();
 }
@@ -592,9 +611,7 @@ __device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a_in, con
     const Lstm2FwdArgs a = uniform_copy(a_in);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's h rows are in memory before the workgroup reads them back
     __syncthreads();                                                // ... and the pooling waves have left the four trials' dense-head results in LDS
-#pragma unroll 1
-    for (int n = 0; n < NTR; ++n)
-        if (b0 + n < a.B) train_tail(a, sm, tid, b0 + n, n);
+    train_tail4(a, sm, tid, b0);
 }
 
 // the dense head of trial n by one wave alone: lstm_eeg_model.py:38-39 forward, mean CE, and their backward down to dL/dpooled
@@ -707,7 +724,7 @@ __device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a_in, co
         xstep_barrier(prof);
         for (int m = 0; m < n_steps; ++m) {
             const int q = m - 10;
-            if (q >= 0 && q <= last_q) stage_step(q);
+            if (q >= 0 && q <= last_q && !ablated(a.ablate, 2097152)) stage_step(q);
             xstep_barrier(prof);
         }
         for (int q = n_steps - 10 > 0 ? n_steps - 10 : 0; q <= last_q; ++q) stage_step(q);     // (the ring is complete and stable now)

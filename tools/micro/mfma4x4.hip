@@ -4,7 +4,8 @@
 //   (1) layout probe: A lane (b, i) = row i of block b, B lane (b, j) = column j, D register i of lane (b, j) = D_b[i][j]
 //   (2) broadcast probes: BLGP 4..7 = one 16-lane row of B for all four rows; CBSZ = 4 / ABID = n = block n's A for all 16 blocks
 //   (3) issue rate of one wave per SIMD: one dependent accumulator chain, 2 and 4 independent chains; with a second wave on the
-//       same SIMD streaming transcendental VALU work (does the cell arithmetic of another wave hide behind the MFMAs?)
+//       same SIMD streaming transcendental VALU work (does the cell arithmetic of another wave hide behind the MFMAs?); with 2..4 waves
+//       per SIMD streaming MFMAs (the pipe's own rate: one 4x4x1 per 8 cycles whatever the number of waves -- the nominal fp32 rate)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -195,8 +196,9 @@ int main() {
         }
         hipDeviceSynchronize();
         hipMemcpy(hc, cyc, 64, hipMemcpyDeviceToHost);
-        printf("TWO MFMA waves per SIMD, chains=%d: %.2f ticks per MFMA of wave 0, %.2f of wave 4 -> one MFMA per %.2f ticks on the SIMD\n", chains,
-               (double)hc[0] / (32.0 * iters), (double)hc[4] / (32.0 * iters), (double)hc[0] / (64.0 * iters));
+        // (the older wave wins the arbitration and runs at its own rate; the pipe's rate is what BOTH needed: the slower wave's time)
+        printf("TWO MFMA waves per SIMD, chains=%d: %.2f ticks per MFMA of wave 0, %.2f of wave 4 -> the SIMD's pipe took one MFMA per %.2f ticks\n", chains,
+               (double)hc[0] / (32.0 * iters), (double)hc[4] / (32.0 * iters), (double)(hc[0] > hc[4] ? hc[0] : hc[4]) / (64.0 * iters));
     }
     for (int wps = 1; wps <= 4; ++wps) {
         hipMemset(cyc, 0, 128);
@@ -205,8 +207,10 @@ int main() {
         hipDeviceSynchronize();
         long long hc2[16];
         hipMemcpy(hc2, cyc, 128, hipMemcpyDeviceToHost);
-        printf("outer-product form (CBSZ=2, ABID=t, BLGP=4+t), 18 accumulators, %d wave(s) per SIMD: %.2f ticks per MFMA per wave -> one per %.2f ticks on the SIMD\n", wps,
-               (double)hc2[0] / (72.0 * 500), (double)hc2[0] / (72.0 * 500 * wps));
+        long long slowest = 0;
+        for (int wv = 0; wv < 4 * wps; wv += 4) slowest = hc2[wv] > slowest ? hc2[wv] : slowest;      // waves 0, 4, 8, 12 share SIMD 0's pipe
+        printf("outer-product form (CBSZ=2, ABID=t, BLGP=4+t), 18 accumulators, %d wave(s) per SIMD: wave 0 %.2f ticks per MFMA, the slowest wave %.2f -> the pipe took one per %.2f ticks\n", wps,
+               (double)hc2[0] / (72.0 * 500), (double)slowest / (72.0 * 500), (double)slowest / (72.0 * 500 * wps));
     }
     for (int partner = 0; partner < 2; ++partner) {
         for (int chains = 1; chains <= 4; chains *= 2) {
