@@ -53,6 +53,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+X4_MIN_B = 576                                 # csrc/nsd_lstm2.hip: batch from which the H = 48 path runs its four-trial matrix-pipe kernels
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: fp32 vector == fp32 matrix rate; dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -70,7 +71,8 @@ CONFIGS = {
 }
 # sources whose hash ties a recorded PMC traffic file to the kernels it was measured on
 KERNEL_SOURCES = {
-    "fp32": ["nsd_lstm2_fwd48.hip", "nsd_lstm2_bwd48.hip", "nsd_common.h", "nsd_args.h", "nsd_prof.h"],
+    "fp32": ["nsd_lstm2_fwd48.hip", "nsd_lstm2_bwd48.hip", "nsd_lstm2_fwd48x4.hip", "nsd_lstm2_bwd48x4.hip", "nsd_lstm2.hip", "nsd_common.h", "nsd_args.h",
+             "nsd_prof.h"],
     "bf16": ["nsd_scan.hip", "nsd_scan2.hip", "nsd_scan_common.h", "nsd_gemm_bf16.hip", "nsd_head_tm.hip", "nsd_seq.hip", "nsd_seq.h", "nsd_bf16.h",
              "nsd_common.h"],
 }
@@ -332,13 +334,18 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extr
             if small:
                 fwd_key = next(k for k in ("nsd_lstm_head_train_rng", "nsd_lstm_head_train", "nsd_lstm_fwd") if kern_us.get(k))
                 bwd_key = next(k for k in ("nsd_lstm_bwd_rng", "nsd_lstm_bwd") if kern_us.get(k))
-                names = {fwd_key: "lstm2_fwd48_kernel", bwd_key: "lstm2_bwd48_kernel"}
-                bound = "fp32-valu"
-                why = ("fp32 path: arithmetic intensity ~110 FLOP/B >> ridge (~20) so the compute roof binds, not HBM; peak = 157.3 "
-                       "TFLOP/s fp32 (packed-FMA vector rate == f32 MFMA rate on gfx950); the kernels are v_pk_fma_f32 (VALU) "
-                       "recurrences bound by instruction issue + the LDS hand-off of h per step; "
-                       "north_star's 40 % of HBM is out of reach for H=48 by construction (at the fp32 peak the step would still "
-                       "take 71 us = 18 % of 8 TB/s for its algorithmic bytes): see `hbm` for the measured HBM view")
+                x4 = B >= X4_MIN_B                                # (csrc/nsd_lstm2.hip: four trials per workgroup on the matrix pipe)
+                names = {fwd_key: "lstm2_fwd48x4_kernel" if x4 else "lstm2_fwd48_kernel", bwd_key: "lstm2_bwd48x4_kernel" if x4 else "lstm2_bwd48_kernel"}
+                bound = "mfma" if x4 else "fp32-valu"
+                common = ("fp32 path: arithmetic intensity ~110 FLOP/B >> ridge (~20) so the compute roof binds, not HBM; peak = 157.3 "
+                          "TFLOP/s fp32 (packed-FMA vector rate == f32 MFMA rate on gfx950); north_star's 40 % of HBM is out of reach "
+                          "for H=48 by construction (at the fp32 peak the step would still take 71 us per 256 trials = 18 % of 8 TB/s "
+                          "for its algorithmic bytes): see `hbm` for the measured HBM view; ")
+                why = common + ("four trials per workgroup: every product of a step is v_mfma_f32_4x4x1_16B_f32 (one per 8 cycles and SIMD = "
+                                "the fp32 rate), 456 per forward and 912 per backward step: the kernels are matrix-pipe-bound, the rest "
+                                "is the recurrence's serial tail per step (LDS hand-off, cell, barrier)" if x4 else
+                                "one trial per workgroup: the kernels are v_pk_fma_f32 (VALU) recurrences bound by instruction issue + "
+                                "the LDS hand-off of h per step")
             else:
                 fwd_key, bwd_key = "scan_fwd", "scan_bwd"
                 names = dict(zip((fwd_key, bwd_key), scan_kernel_names(cfg)))

@@ -46,6 +46,12 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define NSD_BX4_DWD 4
 #endif
 constexpr int DWD = NSD_BX4_DWD;
+#ifndef NSD_BX4_DW_SLEEP
+#define NSD_BX4_DW_SLEEP 0
+#endif
+#ifndef NSD_BX4_X1_SLEEP
+#define NSD_BX4_X1_SLEEP 0
+#endif
 #ifndef NSD_BX4_B96
 #define NSD_BX4_B96 1
 #endif
@@ -277,6 +283,7 @@ __device__ __attribute__((noinline)) void x1_role(const Lstm2BwdArgs &a_in, cons
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int m = m0 + k, t1p = T - m;
+                if (NSD_BX4_X1_SLEEP) __builtin_amdgcn_s_sleep(NSD_BX4_X1_SLEEP);
                 if (t1p >= 0 && t1p < T) sm.din1[k & 1][j][u] = transposed_product(wv, &sm.da[(k + 1) & 1][1][j][48 * r], a.ablate);
                 const float *da0 = &sm.da[(k + 1) & 1][0][0][0];
                 float a3[4];
@@ -375,6 +382,7 @@ __device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, cons
                 float av[6];
 #pragma unroll
                 for (int q = 0; q < 6; ++q) av[q] = dal[a_off + 16 * q];
+                if (NSD_BX4_DW_SLEEP) __builtin_amdgcn_s_sleep(NSD_BX4_DW_SLEEP);      // (let the recurrences' products through the matrix pipe first)
                 if (m >= 1 && !ablated(a.ablate, 1)) {
                     dw_trial<0>(av, bq[k], acc);
                     dw_trial<1>(av, bq[k], acc);

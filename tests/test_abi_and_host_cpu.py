@@ -315,3 +315,13 @@ def test_bench_accounting_of_the_sequence_batched_configs():
     assert a5["bwd_flop"] == 2 * 1000 * 2 * 4 * 512 * 512 * 512
     # the kernel-source hash that keys the recorded PMC traffic covers every file of the path
     assert {"nsd_scan.hip", "nsd_scan2.hip", "nsd_scan_common.h", "nsd_gemm_bf16.hip", "nsd_seq.hip"} <= set(bench.KERNEL_SOURCES["bf16"])
+
+
+def test_bench_knows_where_the_four_trial_kernels_take_over():
+    """bench.py names the dominant kernel of the fp32 path by batch size: its threshold must be the launcher's (csrc/nsd_lstm2.hip)."""
+    import re
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "neural-speech-decoding_amd", "csrc", "nsd_lstm2.hip")).read()
+    m = re.search(r"constexpr int X4_MIN_B = (\d+);", src)
+    assert m and int(m.group(1)) == bench.X4_MIN_B

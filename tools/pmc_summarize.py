@@ -23,7 +23,8 @@ cfg = bench.CONFIGS[config]
 base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 alg = bench.algorithmic(cfg, cfg["B"], cfg["T"])
 if cfg["precision"] == "fp32":
-    ALG = {"lstm2_fwd48_kernel": alg["fwd_bytes"], "lstm2_bwd48_kernel": alg["bwd_bytes"]}
+    ALG = {"lstm2_fwd48_kernel": alg["fwd_bytes"], "lstm2_bwd48_kernel": alg["bwd_bytes"],
+           "lstm2_fwd48x4_kernel": alg["fwd_bytes"], "lstm2_bwd48x4_kernel": alg["bwd_bytes"]}
 else:
     ALG = dict(zip(bench.scan_kernel_names(cfg), (alg["fwd_bytes"], alg["bwd_bytes"])))
 
