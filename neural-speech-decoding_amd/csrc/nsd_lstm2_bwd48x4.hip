@@ -36,7 +36,10 @@ namespace {
 constexpr int H = 48;
 constexpr int NTR = 4;
 constexpr int NTHR = 1024;
-constexpr int VSD = 208;          // floats per trial of a da vector (k' = 4 unit + gate): 16-byte pieces of the four trials fall into different banks
+#ifndef NSD_BX4_VSD
+#define NSD_BX4_VSD 196
+#endif
+constexpr int VSD = NSD_BX4_VSD;  // floats per trial of a da vector (k' = 4 unit + gate).  196: the 16 (k-slice, trial) pieces of a B-operand read fall into 16 different 4-bank groups (208: four groups, 4-way conflicts)
 constexpr int VS1 = 64;
 constexpr int XCH = 16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -199,6 +202,7 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
                 const int m = m0 + k;
                 const int t = t_of(m);
                 const bool active = t >= 0 && t < T, prev_active = t + 1 >= 0 && t + 1 < T;
+                prof_mark<-1, false>(prof);
                 // ---- what does not depend on the recurrence: the derivative factors of this cell, the gradient arriving from above
                 const float cprev = t > 0 ? cq[k] : 0.f;
                 const float ig = gq[k][0], fg = gq[k][1], gg = gq[k][2], og = gq[k][3];
@@ -209,7 +213,9 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
                 // (the step's saved values are consumed: pinned here, so that the loads below may land in the SAME registers -- with the
                 // old values still live hipcc rotates the prefetch registers with copies in the loop latch and waits for the loads there)
                 asm volatile("" : "+v"(wq), "+v"(Fi), "+v"(Ff), "+v"(Fg), "+v"(Fo), "+v"(fgk), "+v"(cpk));
+                prof_mark<0, false>(prof);                          // seg0: derivative factors
                 if (!ablated(a.ablate, 16)) prefetch(m + CHD, gq[k], cq[k]);     // CHD steps ahead
+                prof_mark<1, false>(prof);                          // seg1: prefetch issued
                 float dout;
                 if (LAYER == 1) {
                     const float2 ad = *reinterpret_cast<const float2 *>(&sm.sc[(m >> 4) & 1][j][m & (XCH - 1)][0]);
@@ -220,7 +226,9 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
                 }
                 // ---- the recurrence
                 float rec = 0.f;
+                prof_mark<2, true>(prof);                           // seg2: dout operands (LDS) arrived
                 if (prev_active) rec = transposed_product(wv, &sm.da[(k + 1) & 1][LAYER][j][48 * r], a.ablate);
+                prof_mark<3, false>(prof);                          // seg3: product + reduce-scatter
                 f32x4 dav = {0.f, 0.f, 0.f, 0.f};
                 if (active && vb) {
                     const float dht = dout + rec;
@@ -231,6 +239,7 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
                 }
                 if (active) ct = cpk;                               // c[t-1] is the cell state of the next step handled
                 *reinterpret_cast<f32x4 *>(&sm.da[k & 1][LAYER][j][4 * u]) = dav;      // (zeros for inactive steps / padding trials: dW and X1 add nothing)
+                prof_mark<4, true>(prof);                           // seg4: cell backward, da in LDS
                 xstep_barrier(prof);
             }
         }

@@ -611,7 +611,7 @@ __device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a_in, con
     const Lstm2FwdArgs a = uniform_copy(a_in);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's h rows are in memory before the workgroup reads them back
     __syncthreads();                                                // ... and the pooling waves have left the four trials' dense-head results in LDS
-    train_tail4(a, sm, tid, b0);
+    if (!ablated(a.ablate, 8388608)) train_tail4(a, sm, tid, b0);
 }
 
 // the dense head of trial n by one wave alone: lstm_eeg_model.py:38-39 forward, mean CE, and their backward down to dL/dpooled
@@ -728,8 +728,10 @@ __device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a_in, co
             xstep_barrier(prof);
         }
         for (int q = n_steps - 10 > 0 ? n_steps - 10 : 0; q <= last_q; ++q) stage_step(q);     // (the ring is complete and stable now)
+        if (!ablated(a.ablate, 4194304)) {
         dense_head(a, sm, lane, b0 + 2 * pw, 2 * pw, pr[0], lnw, lnb, b0v, b3v);
         dense_head(a, sm, lane, b0 + 2 * pw + 1, 2 * pw + 1, pr[1], lnw, lnb, b0v, b3v);
+        }
     }
     prof_store(a.dbg, prof);
 }
