@@ -160,7 +160,7 @@ __device__ __forceinline__ void xstep_barrier(Prof &p) {
 // What a cell lane leaves for the backward pass goes out from the lane itself (the four gates of a cell are 16 contiguous bytes of
 // gact[b][t][unit][4]) -- but not where it is formed.  Issued behind the cell, the step's 21 store instructions of the six cell waves hit
 // the CU's one vector-memory path in a burst and every wave stood ~130 cycles per instruction IN FRONT of the step barrier (0.25 us
-// of a 1.04-us step; records through LDS + saver waves cost the same in LDS traffic: both measured, profiles/r04_x4_forward.md).
+// of a 1.04-us step; records through LDS + saver waves cost the same in LDS traffic: both measured, profiles/r04_x4_kernels.md).
 // So a step's values wait in registers and leave one instruction at a time between the MFMAs of the NEXT step, where the wave's issue
 // slots are idle anyway; non-temporal: the backward pass reads them after the whole forward, nothing of them should stay in the L2.
 // ------------------------------------------------------------------------------------------------
