@@ -15,7 +15,7 @@
  * cell follows torch.nn.LSTM's documented semantics: gate order i,f,g,o, two
  * bias vectors, zero initial state, inter-layer dropout on all but the last
  * layer.  Parity is pinned by the .npz files under tests/golden/, produced by
- * tools/make_goldens.py from the reference module + checkpoint.
+ * tests/golden/make_goldens.py from the reference module + checkpoint.
  *
  * All arithmetic is fp32 in forward (k-ordered fmaf-free multiply-add chains);
  * the backward keeps fp32 values but accumulates long sums (over B*T) in
