@@ -1073,3 +1073,50 @@ def test_four_trials_per_workgroup_backward_on_the_matrix_pipe(nsd, dev, ref_sta
         finally:
             ops.force_fwd48(0)
             ops.force_bwd48(0)
+
+
+@pytest.mark.parametrize("C,K,B,T", [(5, 4, 10, 37), (1, 2, 5, 20), (8, 8, 13, 50)])
+def test_four_trial_kernels_other_channel_and_class_counts(nsd, dev, C, K, B, T):
+    """The four-trial forward / backward kernels with fewer EEG channels than the 8 their x staging is laid out for (zero weights /
+    dropped columns beyond C) and with other class counts in the fused head, against the oracle."""
+    from nsd_amd import _lib, ops
+    d = orc.Dims(C=C, H=48, L=2, K=K)
+    spec = ops.ModelSpec(C=C, H=48, L=2, K=K)
+    flat_np = orc.flatten_state(synth_params(C, 48, 2, K, seed=40 + C), d)
+    x, y = synth_x(B, T, C=C, seed=C), synth_labels(B, K=K, seed=C)
+    dl, sl, dh = counter_masks(B, T, 48, 32, seed=C)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, d, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    with _lib.diagnostic_library():
+        try:
+            ops.force_fwd48(4)
+            ops.force_bwd48(4)
+            loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, x, y, spec=spec, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+            # ... and the single-launch forward + head with the same masks
+            flat, xt = _t(flat_np, dev), _t(x, dev)
+            ws = ops.new_workspace(spec, B, T, dev)
+            lg = torch.empty((B, K), device=dev)
+            g2 = torch.empty_like(flat)
+            ops.train_step_grads(spec, flat, xt, ws, _t(y.astype(np.int32), dev), lg, g2, drop_lstm=_t(dl, dev), rrelu_slope=_t(sl, dev), drop_head=_t(dh, dev))
+            torch.cuda.synchronize()
+        finally:
+            ops.force_fwd48(0)
+            ops.force_bwd48(0)
+    assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
+    _grad_close(grads, g_ref, d, rtol=3e-4)
+    assert np.abs(lg.cpu().numpy() - fw["logits"]).max() < LOGIT_TOL
+    _grad_close(g2.cpu().numpy(), g_ref, d, rtol=3e-4)
+
+
+def test_four_trial_kernels_loop_over_trial_groups(nsd, dev, ref_state):
+    """More trial groups than workgroups (B = 1 100 -> 275 groups of four on at most 256 workgroups): some workgroups walk two groups --
+    state buffers re-zeroed, weights re-read, bias / weight-gradient sums carried across the groups -- through the PRODUCT's own
+    dispatch (no pinning: 1 100 >= the 576 trials from which the four-trial kernels are used)."""
+    from nsd_amd import ops
+    B, T = 1100, 6
+    flat_np = orc.flatten_state(ref_state, D)
+    x, y = synth_x(B, T, seed=77), synth_labels(B, seed=77)
+    dl, sl, dh = counter_masks(B, T, 48, 32, seed=78)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, x, y, D, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, x, y, drop_lstm=dl, rrelu_slope=sl, drop_head=dh)
+    assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL and abs(loss - loss_ref) < 5e-5
+    _grad_close(grads, g_ref, D, rtol=3e-4)
