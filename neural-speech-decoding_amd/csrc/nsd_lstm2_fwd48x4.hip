@@ -19,12 +19,12 @@
 //
 // 12 waves, role = f(SIMD g = wave & 3, slot q = wave >> 2); one barrier per macro step m; layer 1 two steps behind layer 0:
 //   g 0..2, q 1  "L0"  layer 0, units 16g..16g+15, t = m    : W_ih0 x_t + W_hh0 h0_{t-1} (56 MFMAs), cells, h0 / masked h0 -> LDS
-//   g 3,    q 0..2 "P" layer-1 input projection of t = m-1  : rows of group q, k < 36 of W_ih1 in1_t (36 MFMAs) + bias -> LDS tiles
-//   g 0..2, q 0  "L1"  layer 1, units 16g.., t = m-2        : P tile + k >= 36 of W_ih1 in1_t (12) + W_hh1 h1_{t-1} (48), cells
+//   g 3,    q 0..2 "P" layer-1 input projection of t = m-1  : rows of group q, W_ih1 in1_t (48 MFMAs) + both biases -> LDS tiles
+//   g 0..2, q 0  "L1"  layer 1, units 16g.., t = m-2        : P tile + W_hh1 h1_{t-1} (48), cells
 //   g 0,    q 2  "stage"  x and the dropout multipliers of the next 16-step chunk (explicit tensor or the counter stream) -> LDS
 //   g 1, 2, q 2  "pool"   fused train head: attention pooling of two trials each as an online softmax along the recurrence,
 //                         then LayerNorm / fc / CE / dense backward; otherwise spare
-//   (116 / 116 / 116 / 108 MFMAs per step and SIMD.)  The saved activations leave from the lanes that own them: the four gates of a
+//   (104 / 104 / 104 / 144 MFMAs per step and SIMD: the recurrences' SIMDs also carry the cells and the helper waves.)  The saved activations leave from the lanes that own them: the four gates of a
 //   cell are 16 contiguous bytes of gact[b][t][unit][4] -- buffer stores with a scalar time offset, issued one at a time between the
 //   MFMAs of the NEXT step (no saver wave, no LDS ring: see "Pending").
 // After the last step: the tail of nsd_lstm2_fwd48.hip's fused train head (alpha, dL/dscore, d attn.weight), one trial at a time.
@@ -39,7 +39,12 @@ constexpr int NTHR = 768;
 constexpr int VS = 80;            // floats per trial in the operand vectors: bank = 16 j + unit -> conflict-free writes and b128 reads
 constexpr int XCH = 16;           // steps per staged chunk of x / multipliers
 constexpr int HR = 16;            // h1 ring (two 8-step pooling chunks)
-constexpr int KP = 36;            // k-columns of W_ih1 the P waves take (the rest rides in the L1 waves)
+#ifndef NSD_X4_KP
+#define NSD_X4_KP 48
+#endif
+constexpr int KP = NSD_X4_KP;     // k-columns of W_ih1 the P waves take (the rest would ride in the L1 waves); 32 <= KP <= 48, even.
+                                  // All 48: the SIMDs of the recurrences also carry the cells and the helper waves -- measured (same box, ablation
+                                  // build): KP = 32 / 36 / 40 / 44 / 48 -> 332 / 327 / 323 / 314 / 309 us per launch
 constexpr int SCH = 8;
 constexpr int TT_TMAX = 1024, TT_KMAX = 8, TT_W0S = 49;
 constexpr int TT_PARTS = NTHR / H;
