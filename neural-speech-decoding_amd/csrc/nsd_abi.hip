@@ -453,6 +453,11 @@ static int lstm_bwd_impl(const nsd_dims *d, const float *params, const float *x,
     a.in1seq = workspace + w.inseq;
     a.alpha = workspace + w.alpha; a.dscore = workspace + w.dscore; a.dpooled = workspace + w.dpooled;
     a.dsc_pack = workspace + w.adpack;
+    {
+        const HeadArgs h = build_head(d, params);
+        a.pooled = workspace + w.pooled; a.dscore_out = workspace + w.dscore; a.hslabs = workspace + w.hslabs;
+        a.Ph = h.Ph; a.o_attn_w = h.o_attn_w; a.o_attn_b = h.o_attn_b;
+    }
     a.dbg = g_dbg;
     a.slabs = workspace + w.slabs;
     a.slab_stride = align4(pl.lstm_total);

@@ -20,6 +20,10 @@ struct Lstm2FwdArgs {
     // LayerNorm, dense head, mean-CE and the head's backward run in the kernel's tail -- what nsd_head_train does in a
     // second launch.  Outputs and per-trial gradient slabs are those of HeadArgs.
     int head_train;
+    // lstm2_fwd48x4 only, set by the launcher when the backward pass of this batch runs lstm2_bwd48x4_kernel: the per-step part of the
+    // attention's backward (dL/dscore_t, d attn.weight, d attn.bias) is left to that kernel, which reads the top rows anyway; the
+    // forward writes alpha_t and marks the {alpha, dscore} records as open ({alpha_t, 0, 1, 0}: see Lstm2BwdArgs::dsc_pack)
+    int defer_att;
     const int32_t *labels;
     const float *rrelu_slope, *drop_head;
     float scale;
@@ -35,6 +39,13 @@ struct Lstm2BwdArgs {
     const float *in1seq;
     const float *alpha, *dscore, *dpooled;
     const float *dsc_pack;                   // [B,T,4] {alpha, dscore, 0, 0}: 16-byte records for LDS-DMA
+                                             // lstm2_bwd48x4: a record {alpha, -, 1, -} is OPEN (left by lstm2_fwd48x4 with defer_att): the kernel
+                                             // forms dscore_t = alpha_t dpooled . (top_t - pooled) itself, writes it to dscore_out and adds
+                                             // d attn.weight / d attn.bias of the trial to its head slab
+    const float *pooled;                     // [B,H] (open records only)
+    float *dscore_out;                       // [B,T]
+    float *hslabs;                           // per-trial head-gradient slabs (stride Ph), offsets of attn.weight / attn.bias in them
+    long Ph, o_attn_w, o_attn_b;
     float *slabs;
     long slab_stride;
     long o_w_ih0, o_w_hh0, o_b_ih0, o_b_hh0, o_w_ih1, o_w_hh1, o_b_ih1, o_b_hh1;

@@ -571,7 +571,15 @@ int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st) {
         const int cus = nsd_num_cus();
         const int force_nb = nsd_diag_forced_fwd48();           // 0 in the product library (diagnostic build: nsd_diag_force_fwd48)
         const bool x4 = nsd_lstm2_fwd48x4_ok(a) && (force_nb ? force_nb == 4 : a.B >= X4_MIN_B);
-        if (x4) { const int ngrp4 = (a.B + 3) / 4; return nsd_lstm2_fwd48x4_launch(a, ngrp4 < cus ? ngrp4 : cus, st); }
+        if (x4) {
+            // The backward pass of the same batch takes lstm2_bwd48x4_kernel under the same rule (nsd_lstm2_bwd_launch below; its domain
+            // contains the forward kernel's): the fused head then leaves the per-step part of the attention's backward to it
+            const int force_b = nsd_diag_forced_bwd48();
+            Lstm2FwdArgs a4 = a;
+            a4.defer_att = a.head_train && (force_b ? force_b == 4 : a.B >= X4_MIN_B);
+            const int ngrp4 = (a.B + 3) / 4;
+            return nsd_lstm2_fwd48x4_launch(a4, ngrp4 < cus ? ngrp4 : cus, st);
+        }
         const bool two = force_nb ? force_nb == 2 : a.B >= 2 * cus;
         if (two && !a.logits_out) { const int ngrp2 = (a.B + 1) / 2; return nsd_lstm2_fwd48_launch(a, 2, ngrp2 < cus ? ngrp2 : cus, st); }
         return nsd_lstm2_fwd48_launch(a, 1, a.B < cus ? a.B : cus, st);

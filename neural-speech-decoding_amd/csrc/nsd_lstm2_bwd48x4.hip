@@ -24,7 +24,7 @@
 //   q 3, g 0..2 and g 3, q 0..2  "dW"  six waves: dW_hh1, dW_ih1, dW_hh0 (two waves each, 6 row tiles x 3 column tiles):
 //                      72 MFMAs per wave and step, B rows prefetched from HBM four steps ahead
 //   q 3, g 3     "aux" {alpha, dscore} of the layer-1 steps, the x rows and the layer-0 dropout multipliers (explicit tensor or the
-//                      counter stream), one 16-step chunk ahead -> LDS
+//                      counter stream), one 16-step chunk ahead -> LDS; dL/dscore_t itself where the forward kernel left it open
 //   (232 / 232 / 232 / 216 MFMAs per step and SIMD.)  The saved activations of a cell (16 bytes of gates, c[t-1]) are prefetched by
 //   the lane that owns the cell, four steps ahead, with buffer loads whose time offset is scalar -- no staging through LDS.
 // HBM traffic = saved activations read once + one slab of partial gradients per workgroup at the end.
@@ -61,13 +61,17 @@ constexpr int DWD = NSD_BX4_DWD;
 #ifndef NSD_BX4_CHD
 #define NSD_BX4_CHD 4
 #endif
+#ifndef NSD_BX4_VAR
+#define NSD_BX4_VAR 0             // timing experiments (never in the library): 1 no d attn.weight in C1, 2 records never open, 4 open without the row requests
+#endif
 constexpr int CHD = NSD_BX4_CHD;   // steps a cell lane requests its saved activations ahead (= unroll of the recurrences' step loop; even, 16 % CHD == 0)   // steps the dW waves' B rows are requested ahead (= unroll of their step loop; 16 % DWD == 0)
 
 struct BSmem {
     float da[2][2][NTR][VSD];     // [slot m & 1][layer][trial][4 unit + gate]
     float din1[2][NTR][VS1];      // [slot m & 1][trial][unit]: W_ih1^T da1 of t = T - m
     float mk[2][NTR][XCH][H];     // layer-0 dropout multipliers of t = T + 1 - m, 16 macro steps per chunk
-    float sc[2][NTR][XCH][4];     // {alpha, dscore, -, -} of t = T - 1 - m
+    float sc[2][NTR][XCH][4];     // {alpha, dscore, open, -} of t = T - 1 - m (open = 1: the record came without dscore, see the aux wave)
+    float dpv[NTR][H];            // dL/dpooled of the group's trials (the aux wave's own copy, open records only)
     float xs[2][NTR][XCH][16];    // x[t = T + 2 - m][channel] (channels >= C: zeros), the B operand of dW_ih0
 };
 __shared__ __align__(16) BSmem g_bsm;
@@ -174,6 +178,7 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
         const unsigned vo16 = vb ? vo4 * 4u : VOFF_DROP;
         const float dpj = (LAYER == 1 && vb) ? a.dpooled[(size_t)b * H + u] : 0.f;
         float dc = 0.f;
+        float attw = 0.f, open_rec = 0.f;                           // layer 1, open records: d attn.weight[u] of trial j = sum_t dscore_t h1_t[u]
         // time index of macro step m, clamped for the prefetches (values of inactive steps are never used)
         auto t_of = [&](const int m) { return LAYER == 1 ? T - 1 - m : T + 1 - m; };
         auto clampt = [&](const int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
@@ -208,18 +213,24 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
                 const float ig = gq[k][0], fg = gq[k][1], gg = gq[k][2], og = gq[k][3];
                 const float tc = fast_tanh(ct);
                 float wq = og * (1.f - tc * tc);                    // d c_t / d h_t
-                float Fi = gg * ig * (1.f - ig), Ff = cprev * fg * (1.f - fg), Fg = ig * (1.f - gg * gg), Fo = tc * og * (1.f - og);
+                float ht = tc * og;                                 // h_t of this cell (o * tanh(c): what the forward pass saved, to rounding)
+                float Fi = gg * ig * (1.f - ig), Ff = cprev * fg * (1.f - fg), Fg = ig * (1.f - gg * gg), Fo = ht * (1.f - og);
                 float fgk = fg, cpk = cprev;
                 // (the step's saved values are consumed: pinned here, so that the loads below may land in the SAME registers -- with the
                 // old values still live hipcc rotates the prefetch registers with copies in the loop latch and waits for the loads there)
-                asm volatile("" : "+v"(wq), "+v"(Fi), "+v"(Ff), "+v"(Fg), "+v"(Fo), "+v"(fgk), "+v"(cpk));
+                if (LAYER == 1) asm volatile("" : "+v"(wq), "+v"(Fi), "+v"(Ff), "+v"(Fg), "+v"(Fo), "+v"(fgk), "+v"(cpk), "+v"(ht));
+                else            asm volatile("" : "+v"(wq), "+v"(Fi), "+v"(Ff), "+v"(Fg), "+v"(Fo), "+v"(fgk), "+v"(cpk));
                 prof_mark<0, false>(prof);                          // seg0: derivative factors
                 if (!ablated(a.ablate, 16)) prefetch(m + CHD, gq[k], cq[k]);     // CHD steps ahead
                 prof_mark<1, false>(prof);                          // seg1: prefetch issued
                 float dout;
                 if (LAYER == 1) {
-                    const float2 ad = *reinterpret_cast<const float2 *>(&sm.sc[(m >> 4) & 1][j][m & (XCH - 1)][0]);
-                    dout = fmaf(ad.x, dpj, ad.y * awj);
+                    const f32x4 ad = *reinterpret_cast<const f32x4 *>(&sm.sc[(m >> 4) & 1][j][m & (XCH - 1)][0]);
+                    dout = fmaf(ad[0], dpj, ad[1] * awj);
+                    if (!(NSD_BX4_VAR & 1)) {
+                    attw = fmaf(ad[1], ht, attw);                   // (dscore is zero on inactive steps and padding trials)
+                    open_rec = fmaxf(open_rec, ad[2]);
+                    }
                 } else {
                     const float mkv = masked ? sm.mk[(m >> 4) & 1][j][m & (XCH - 1)][u] : 1.f;
                     dout = sm.din1[(k + 1) & 1][j][u] * mkv;        // written by the X1 waves at macro step m - 1
@@ -243,6 +254,7 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
                 xstep_barrier(prof);
             }
         }
+        if (LAYER == 1 && vb && open_rec != 0.f) a.hslabs[(size_t)b * a.Ph + a.o_attn_w + u] = attw;
     }
     prof_store(a.dbg, prof);
     // bias gradients: sum over the four trials of the quad, lane j == 0 writes (b_ih and b_hh get the same sum)
@@ -421,11 +433,20 @@ __device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// aux wave: {alpha, dscore} of the layer-1 steps and the layer-0 dropout multipliers, one 16-step chunk ahead
+// aux wave: {alpha, dscore} of the layer-1 steps and the layer-0 dropout multipliers, one 16-step chunk ahead.
+// OPEN records ({alpha_t, -, 1, -}: the forward pass of this batch was lstm2_fwd48x4_kernel with the head fused, which does not walk
+// the top rows a second time): lane (trial n, step s) reads the 48 floats of top_t with the record and closes it,
+//   dL/dscore_t = alpha_t (dpooled . top_t - dpooled . pooled)       (= alpha_t (dd_t - sum_s alpha_s dd_s): pooled IS sum_s alpha_s top_s),
+// writes it to the workspace and sums d attn.bias; d attn.weight = sum_t dscore_t h1_t is formed by the layer-1 recurrence's lanes,
+// which hold h1_t = o_t tanh(c_t) of their cell.
 // ------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(1))) f32x4 *gf32x4_p;
-__device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, const int lane, const int n_steps_in) {
+__device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, const int lane_in, const int n_steps_in) {
     BSmem &sm = g_bsm;
+    // `lane` is made opaque once per chunk (an empty asm): what the request lambdas derive from it -- 28 + 12 per-lane addresses -- is then
+    // recomputed per chunk (a few hundred integer instructions per 16 steps) instead of being hoisted out of the chunk loop into registers
+    // this wave does not have: spilled, every request of a chunk waited for a scratch reload first (measured: +85 us per launch)
+    int lane = lane_in;
     const int n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);
     const Lstm2BwdArgs a = uniform_copy(a_in);
     const int T = a.T, B = a.B;
@@ -438,11 +459,15 @@ __device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, con
         if (b < B && t >= 0 && t < T) return *(gf32x4_p)(a.dsc_pack + ((size_t)b * T + t) * 4);
         return f32x4{0.f, 0.f, 0.f, 0.f};
     };
+    // (requests as buffer loads over a scalar base with ONE 32-bit offset each: no 64-bit address arithmetic, no branch around the
+    // request -- a row outside the trial is sent out of the descriptor's range and reads as zeros, which no active step uses)
+    const rsrc_t r_mask = make_rsrc(a.mask, a.mask ? (long)B * T * H * 4 : 0);
     auto mask_at = [&](const int b0, const int c, const int e) -> f32x4 {      // e: float4 index in [0, NTR*XCH*12)
         const int n = e / (XCH * 12), rem = e - n * (XCH * 12), s = rem / 12, q = rem - s * 12;
         const int b = b0 + n, t = T + 1 - (16 * c + s);
-        if (a.mask && b < B && t >= 0 && t < T) return *(gf32x4_p)(a.mask + ((size_t)b * T + t) * H + 4 * q);
-        return f32x4{1.f, 1.f, 1.f, 1.f};
+        if (!a.mask) return f32x4{1.f, 1.f, 1.f, 1.f};
+        const unsigned off = (b < B && t >= 0 && t < T) ? (unsigned)(((b * T + t) * H + 4 * q) * 4) : VOFF_DROP;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_mask, (int)off, 0, 0));
     };
     auto rng_row = [&](const int b0, const int m, const int buf) {            // the 192 multipliers of macro step m: 3 per lane
         const int t = T + 1 - m;
@@ -456,20 +481,75 @@ __device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, con
         }
     };
     // x rows of chunk c: 4 trials x 16 steps x 16 floats (channels >= C: zeros) = 256 float4, 4 per lane
-    typedef const __attribute__((address_space(1))) float *gfloat_p;
+    const rsrc_t r_x = make_rsrc(a.x, (long)B * T * a.C * 4);
     auto x_at = [&](const int b0, const int c, const int e) -> f32x4 {        // e: float4 index in [0, NTR*XCH*4)
         const int n = e >> 6, s = (e >> 2) & 15, q = e & 3, b = b0 + n, t = T + 2 - (16 * c + s);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (b < B && t >= 0 && t < T) {
+        const bool ok = b < B && t >= 0 && t < T;
+        f32x4 v;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (4 * q + i < a.C) v[i] = ((gfloat_p)a.x)[((size_t)b * T + t) * a.C + 4 * q + i];
+        for (int i = 0; i < 4; ++i) {                                 // (rows of C floats: dword requests; channels >= C read as zero)
+            const unsigned off = (ok && 4 * q + i < a.C) ? (unsigned)(((b * T + t) * a.C + 4 * q + i) * 4) : VOFF_DROP;
+            v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_x, (int)off, 0, 0));
         }
         return v;
     };
     constexpr int MPL = NTR * XCH * 12 / 64;
+    const int an = lane_in >> 4, as = lane_in & 15;
+    // piece q of top_t of this lane's record in chunk c: ONE 32-bit offset per lane and chunk over a scalar base (a 64-bit address per
+    // piece, hoisted out of the chunk loop by hipcc, cost the wave its registers); clamped: a record outside the trial is not used
+    const rsrc_t r_top = make_rsrc(a.hseq1, (long)B * T * H * 4);
+    auto row_off = [&](const int b0, const int c) -> unsigned {
+        int b = b0 + an, t = T - 1 - (16 * c + as);
+        b = b < B ? b : B - 1;
+        t = t < 0 ? 0 : t;
+        return (unsigned)((b * T + t) * (H * 4));
+    };
+    auto row_at = [&](const unsigned off, const int q) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_top, (int)(off + 16u * (unsigned)q), 0, 0));
+    };
+    auto dot_piece = [&](const f32x4 r, const int q, float &d0, float &d1) {
+        const f32x4 p = *reinterpret_cast<const f32x4 *>(&sm.dpv[an][4 * q]);
+        d0 = fmaf(r[0], p[0], d0); d1 = fmaf(r[1], p[1], d1); d0 = fmaf(r[2], p[2], d0); d1 = fmaf(r[3], p[3], d1);
+    };
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NTR;
-        *reinterpret_cast<f32x4 *>(&sm.sc[0][0][0][0] + 4 * lane) = sc_at(b0, 0);
+        // Start of a group: the first records, the rows they may need, dL/dpooled and pooled are requested AT ONCE (one round trip to
+        // memory in front of the group's first barrier, not three in a row; the addresses are valid whatever the records turn out to be)
+        typedef const __attribute__((address_space(1))) float *gfl_p;
+        f32x4 scr0 = sc_at(b0, 0);
+        f32x4 rr0[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) rr0[q] = row_at(row_off(b0, 0), q);
+        const int bn = b0 + an < B ? b0 + an : B - 1;
+        float dpl[3], pol[3], dpe[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dpl[i] = ((gfl_p)a.dpooled)[(size_t)bn * H + 3 * as + i];
+            pol[i] = ((gfl_p)a.pooled)[(size_t)bn * H + 3 * as + i];
+            const int e = lane + 64 * i, n = e / H;
+            dpe[i] = ((gfl_p)a.dpooled)[(size_t)(b0 + n < B ? b0 + n : B - 1) * H + (e - n * H)];
+        }
+        const bool open = (NSD_BX4_VAR & 2) ? false : __any(scr0[2] != 0.f) != 0;
+        float sdot = 0.f, dsum = 0.f;
+        auto close_record = [&](const int c, const f32x4 rec, const float dd) -> f32x4 {
+            const int b = b0 + an, t = T - 1 - (16 * c + as);
+            const bool ok = b < B && t >= 0 && t < T;
+            const float ds = ok ? rec[0] * (dd - sdot) : 0.f;
+            if (ok) { a.dscore_out[(size_t)b * T + t] = ds; dsum += ds; }
+            return f32x4{rec[0], ds, 1.f, 0.f};
+        };
+        if (open) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const int e = lane + 64 * i, n = e / H; sm.dpv[n][e - n * H] = dpe[i]; }
+            float sd = fmaf(dpl[0], pol[0], fmaf(dpl[1], pol[1], dpl[2] * pol[2]));
+            sd = oct_sum(sd);
+            sdot = sd + dpp_quad<0x140>(sd);                         // dpooled . pooled: sum over the 16 lanes of the trial
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) dot_piece(rr0[q], q, d0, d1);
+            scr0 = close_record(0, scr0, d0 + d1);
+        }
+        *reinterpret_cast<f32x4 *>(&sm.sc[0][0][0][0] + 4 * lane) = scr0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(&sm.xs[0][0][0][0] + 4 * (lane + 64 * q)) = x_at(b0, 0, lane + 64 * q);
         if (a.rng.on) {
@@ -482,29 +562,63 @@ __device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, con
         xstep_barrier(prof);
         for (int m0 = 0; m0 < n_steps; m0 += XCH) {
             const int c = m0 >> 4, cb = c & 1;
-            const f32x4 scr = sc_at(b0, c + 1);
+            asm volatile("" : "+v"(lane));
+            f32x4 scr = sc_at(b0, c + 1);
             f32x4 xr[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) xr[q] = x_at(b0, c + 1, lane + 64 * q);
-            f32x4 mr[MPL];
-            if (!a.rng.on) {
-#pragma unroll
-                for (int q = 0; q < MPL; ++q) mr[q] = mask_at(b0, c + 1, lane + 64 * q);
-            }
+            auto steps = [&](const int k0, const int k1) {
 #pragma unroll 1
-            for (int k = 0; k < XCH; ++k) {
-                if (a.rng.on) rng_row(b0, m0 + XCH + k, cb ^ 1);
-                if (k == XCH - 1) {
-                    *reinterpret_cast<f32x4 *>(&sm.sc[cb ^ 1][0][0][0] + 4 * lane) = scr;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(&sm.xs[cb ^ 1][0][0][0] + 4 * (lane + 64 * q)) = xr[q];
-                    if (!a.rng.on) {
-#pragma unroll
-                        for (int q = 0; q < MPL; ++q) *reinterpret_cast<f32x4 *>(&sm.mk[cb ^ 1][0][0][0] + 4 * (lane + 64 * q)) = mr[q];
-                    }
+                for (int k = k0; k < k1; ++k) {
+                    if (a.rng.on) rng_row(b0, m0 + XCH + k, cb ^ 1);
+                    xstep_barrier(prof);
                 }
-                xstep_barrier(prof);
+            };
+            // First part of the chunk: the top rows of the open records, requested six steps before they are used (in a train step they
+            // come from HBM behind the kernel's own stream of saved activations: a request used one step later stood at the barrier)
+            if (open) {
+                f32x4 rr[12];
+                const unsigned ro = row_off(b0, c + 1);
+#pragma unroll
+                for (int q = 0; q < 12; ++q) if (!(NSD_BX4_VAR & 4)) rr[q] = row_at(ro, q);
+                steps(0, 6);
+                float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) dot_piece(rr[q], q, d0, d1);
+                scr = close_record(c + 1, scr, d0 + d1);
+                steps(6, 8);
+            } else {
+                steps(0, 8);
             }
+            // Second half: the explicit multipliers in two batches of six requests (24 registers in flight, not 48).  Nobody reads buffer
+            // cb ^ 1 during this chunk (every reader is at a step of chunk c), so each batch is written as soon as it has landed.
+            constexpr int MH = MPL / 2;
+            static_assert(MPL == 2 * MH, "two equal batches");
+            asm volatile("" : "+v"(lane));
+            if (!a.rng.on) {
+                f32x4 mr[MH];
+#pragma unroll
+                for (int q = 0; q < MH; ++q) mr[q] = mask_at(b0, c + 1, lane + 64 * q);
+                steps(8, 11);
+#pragma unroll
+                for (int q = 0; q < MH; ++q) *reinterpret_cast<f32x4 *>(&sm.mk[cb ^ 1][0][0][0] + 4 * (lane + 64 * q)) = mr[q];
+#pragma unroll
+                for (int q = 0; q < MH; ++q) mr[q] = mask_at(b0, c + 1, lane + 64 * (MH + q));
+                steps(11, 14);
+#pragma unroll
+                for (int q = 0; q < MH; ++q) *reinterpret_cast<f32x4 *>(&sm.mk[cb ^ 1][0][0][0] + 4 * (lane + 64 * (MH + q))) = mr[q];
+            } else {
+                steps(8, 14);
+            }
+            *reinterpret_cast<f32x4 *>(&sm.sc[cb ^ 1][0][0][0] + 4 * lane) = scr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(&sm.xs[cb ^ 1][0][0][0] + 4 * (lane + 64 * q)) = xr[q];
+            steps(14, 16);
+        }
+        if (open) {                                                 // d attn.bias of the trial = sum_t dL/dscore_t
+            float bs = oct_sum(dsum);
+            bs += dpp_quad<0x140>(bs);
+            if (as == 0 && b0 + an < B) a.hslabs[(size_t)(b0 + an) * a.Ph + a.o_attn_b] = bs;
         }
     }
     prof_store(a.dbg, prof);

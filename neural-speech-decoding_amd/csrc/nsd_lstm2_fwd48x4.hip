@@ -47,7 +47,6 @@ constexpr int KP = NSD_X4_KP;     // k-columns of W_ih1 the P waves take (the re
                                   // build): KP = 32 / 36 / 40 / 44 / 48 -> 332 / 327 / 323 / 314 / 309 us per launch
 constexpr int SCH = 8;
 constexpr int TT_TMAX = 1024, TT_KMAX = 8, TT_W0S = 49;
-constexpr int TT_PARTS = NTHR / H;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -65,8 +64,9 @@ struct XSmem {
     float w3[TT_KMAX * 64];
     float vln[NTR][64], vx[NTR][64], vz[NTR][64], vdz[NTR][64], vdl[NTR][64], dp[NTR][64];
     float md[NTR][4];
+    float pst[NTR][64];           // pooling state handed to the trial's head wave: [0..47] weighted sum, [48] denominator, [49] running max
     float red[16];
-    float part[TT_PARTS][H];
+    float part[NTR * 12][H];      // d attn.weight partials of (trial, wave of the team, 16-lane row)
 };
 
 // (file scope: the helper roles and the tail are real function calls -- inlined into one body with the compute roles, the kernel
@@ -515,127 +515,35 @@ __device__ __forceinline__ void pool_stage(const int stage, PoolRun &p, XSmem &s
     }
 }
 
-// Sum over the 192 threads (3 waves) of a TEAM; every team of the workgroup calls it at the same time (the barriers are the workgroup's)
-constexpr int TEAM = NTHR / NTR;                                   // 192 threads = 3 waves per trial
-constexpr int TPARTS = TEAM / H;                                   // 4
-__device__ __forceinline__ float team_sum(float v, float *red /* [NTHR / 64] */, const int tid) {
-    v = wave_sum(v);
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    const int w0 = 3 * (tid / TEAM);
-    const float s = (red[w0] + red[w0 + 1]) + red[w0 + 2];
-    __syncthreads();
-    return s;
-}
-
-// The tail of the fused train head, ALL FOUR TRIALS AT ONCE: team n = waves 3n .. 3n + 2 takes trial n (after the pooling waves left
-// dpooled / the softmax statistics of every trial in LDS and the layer-1 waves' h rows are in memory): alpha_t, dL/dscore_t =
-// alpha_t (dpooled . top_t - sum_s alpha_s dpooled . top_s), d attn.weight, d attn.bias.  (One trial after the other with all twelve
-// waves on it, the tail took 37 us of a 300-us launch: its phases are latency -- barriers, the rows read back from memory -- not work.)
-__device__ __forceinline__ void train_tail4(const Lstm2FwdArgs &a, XSmem &sm, const int tid, const int b0) {
-    const int T = a.T;
-    const int n = tid / TEAM, tt = tid - n * TEAM;                  // team = trial, thread of the team
-    const int b = b0 + n;
-    const bool vb = b < a.B;
-    float *sc = sm.sc[n];
-    const float *top = a.hseq1 + (size_t)(vb ? b : 0) * T * H;
-    const float mx = sm.md[n][0], rden = sm.md[n][1];
-    constexpr int NQ = (TT_TMAX + TEAM - 1) / TEAM;                 // 6 time steps per thread at most
-    float al[NQ], dd[NQ];
-    float lsd = 0.f;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int t = tt + q * TEAM;
-        al[q] = 0.f; dd[q] = 0.f;
-        if (t < T && vb) {
-            al[q] = __expf(sc[t] - mx) * rden;
-            const float4 *rowp = reinterpret_cast<const float4 *>(top + (size_t)t * H);
-            float d0 = 0.f, d1 = 0.f;
-#pragma unroll 3
-            for (int j4 = 0; j4 < H / 4; ++j4) {
-                const float4 v = rowp[j4];
-                const float4 p = *reinterpret_cast<const float4 *>(&sm.dp[n][4 * j4]);
-                d0 = fmaf(v.x, p.x, d0); d1 = fmaf(v.y, p.y, d1); d0 = fmaf(v.z, p.z, d0); d1 = fmaf(v.w, p.w, d1);
-            }
-            dd[q] = d0 + d1;
-            lsd = fmaf(al[q], dd[q], lsd);
-        }
-    }
-    const float sdot = team_sum(lsd, sm.red, tid);
-    float lb = 0.f;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int t = tt + q * TEAM;
-        if (t < T && vb) {
-            const float ds = al[q] * (dd[q] - sdot);
-            a.alpha[(size_t)b * T + t] = al[q];
-            a.dscore[(size_t)b * T + t] = ds;
-            *reinterpret_cast<float4 *>(a.adpack + ((size_t)b * T + t) * 4) = make_float4(al[q], ds, 0.f, 0.f);
-            sc[t] = ds;
-            lb += ds;
-        }
-    }
-    const float dab = team_sum(lb, sm.red, tid);                    // (its barriers also publish sc[] = dscore)
-    float *slab = a.hslabs + (size_t)(vb ? b : 0) * a.Ph;
-    if (tt == 0 && vb) slab[a.o_attn_b] = dab;
-    // d attn.weight[j] = sum_t dscore_t top_t[j]: thread (part, j) of the team sums the steps t == part (mod 4)
-    {
-        const int part = tt / H, j = tt - part * H;
-        float s0 = 0.f, s1 = 0.f;
-        if (vb) {
-            // eight rows in flight per thread (the rows are L2 hits by now; one row per iteration was one L2 latency per row: 63 of them)
-            for (int t = part; t < T; t += 8 * TPARTS) {
-                float v[8], w[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int tq = t + q * TPARTS;
-                    const bool ok = tq < T;
-                    v[q] = top[(size_t)(ok ? tq : 0) * H + j];
-                    w[q] = ok ? sc[ok ? tq : 0] : 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q += 2) { s0 = fmaf(w[q], v[q], s0); s1 = fmaf(w[q + 1], v[q + 1], s1); }
-            }
-        }
-        sm.part[n * TPARTS + part][j] = s0 + s1;
-    }
-    __syncthreads();
-    if (tt < H && vb) {
-        float s = 0.f;
-#pragma unroll
-        for (int p = 0; p < TPARTS; ++p) s += sm.part[n * TPARTS + p][tt];
-        slab[a.o_attn_w + tt] = s;
-    }
-    __syncthreads();
-}
-
-// what every wave does after the last step of a trial group when the head is fused
-__device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a_in, const int tid, const int b0_in) {
-    XSmem &sm = g_sm;
-    const int b0 = __builtin_amdgcn_readfirstlane(b0_in);
-    const Lstm2FwdArgs a = uniform_copy(a_in);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's h rows are in memory before the workgroup reads them back
-    __syncthreads();                                                // ... and the pooling waves have left the four trials' dense-head results in LDS
-    if (!ablated(a.ablate, 8388608)) train_tail4(a, sm, tid, b0);
-}
-
-// the dense head of trial n by one wave alone: lstm_eeg_model.py:38-39 forward, mean CE, and their backward down to dL/dpooled
-__device__ __forceinline__ void dense_head(const Lstm2FwdArgs &a, XSmem &sm, const int lane, const int b, const int n, const PoolRun &pr,
-                                           const float lnw, const float lnb, const float b0v, const float b3v) {
+// the dense head of trial n by one wave alone: lstm_eeg_model.py:38-39 forward, mean CE, and their backward down to dL/dpooled.
+// (The gradients of the two weight matrices are outer products of vectors it leaves in LDS: the whole team writes them afterwards.)
+struct HeadPre { float lnw, lnb, b0v, b3v, sl_f, mk_f; int label; };
+// (requested BEFORE the wave's share of the top rows, so that the head can start while those are still in flight)
+__device__ __forceinline__ HeadPre dense_head_pre(const Lstm2FwdArgs &a, const int lane, const int b) {
     const int K = a.K, F = a.F;
-    const bool vb = b < a.B;
-    const int bs = vb ? b : a.B - 1;
-    float sl_f = (lane < F && a.rrelu_slope) ? a.rrelu_slope[(size_t)bs * F + lane] : a.eval_slope;
-    float mk_f = (lane < F && a.drop_head) ? a.drop_head[(size_t)bs * F + lane] : 1.f;
+    const int bs = b < a.B ? b : a.B - 1;
+    HeadPre h;
+    h.lnw = lane < H ? a.ln_w[lane] : 0.f; h.lnb = lane < H ? a.ln_b[lane] : 0.f;
+    h.b0v = lane < F ? a.fc0_b[lane] : 0.f; h.b3v = lane < K ? a.fc3_b[lane] : 0.f;
+    h.sl_f = (lane < F && a.rrelu_slope) ? a.rrelu_slope[(size_t)bs * F + lane] : a.eval_slope;
+    h.mk_f = (lane < F && a.drop_head) ? a.drop_head[(size_t)bs * F + lane] : 1.f;
     if (a.rng.on && lane < F) {                                     // same values as nsd_train_masks streams base+1 / base+2
         const uint64_t idx = (uint64_t)bs * F + lane;
         const float u = (float)(nsd_rand_u32(a.rng.seed, a.rng.base + 1u, idx) >> 8) * (1.0f / 16777216.0f);
-        sl_f = 0.125f + ((float)(1.0 / 3.0) - 0.125f) * u;
-        mk_f = nsd_rand_u32(a.rng.seed, a.rng.base + 2u, idx) >= a.rng.thr_head ? a.rng.keep_head : 0.f;
+        h.sl_f = 0.125f + ((float)(1.0 / 3.0) - 0.125f) * u;
+        h.mk_f = nsd_rand_u32(a.rng.seed, a.rng.base + 2u, idx) >= a.rng.thr_head ? a.rng.keep_head : 0.f;
     }
-    const int label = a.labels[bs];
-    const float rden = 1.0f / pr.den;
-    const float p = lane < H ? pr.pooled * rden : 0.f;
+    h.label = a.labels[bs];
+    return h;
+}
+__device__ __forceinline__ void dense_head(const Lstm2FwdArgs &a, XSmem &sm, const int lane, const int b, const int n, const HeadPre &hp) {
+    const int K = a.K, F = a.F;
+    const bool vb = b < a.B;
+    const int bs = vb ? b : a.B - 1;
+    const float lnw = hp.lnw, lnb = hp.lnb, b0v = hp.b0v, b3v = hp.b3v, sl_f = hp.sl_f, mk_f = hp.mk_f;
+    const int label = hp.label;
+    const float rden = 1.0f / sm.pst[n][48];
+    const float p = lane < H ? sm.pst[n][lane] * rden : 0.f;
     if (lane < H && vb) a.pooled[(size_t)b * H + lane] = p;
     const float mu = wave_sum(p) * (1.0f / H);
     const float dlt = lane < H ? p - mu : 0.f;
@@ -677,11 +585,7 @@ __device__ __forceinline__ void dense_head(const Lstm2FwdArgs &a, XSmem &sm, con
         sm.vdz[n][lane] = dz;
         if (vb) slab[a.o_fc0_b + lane] = dz;
     }
-    if (vb) {
-        for (int e2 = lane; e2 < K * F; e2 += 64) slab[a.o_fc3_w + e2] = sm.vdl[n][e2 / F] * sm.vz[n][e2 % F];
-        if (lane < K) slab[a.o_fc3_b + lane] = dl;
-        for (int e2 = lane; e2 < F * H; e2 += 64) { const int f = e2 / H; slab[a.o_fc0_w + e2] = sm.vdz[n][f] * sm.vln[n][e2 - f * H]; }
-    }
+    if (vb && lane < K) slab[a.o_fc3_b + lane] = dl;
     float dxh = 0.f;
     if (lane < H) {
         float dv = 0.f;
@@ -694,7 +598,157 @@ __device__ __forceinline__ void dense_head(const Lstm2FwdArgs &a, XSmem &sm, con
     const float dpl = lane < H ? rstd * (dxh - m1 - xh * m2b) : 0.f;
     sm.dp[n][lane] = dpl;
     if (lane < H && vb) a.dpooled[(size_t)b * H + lane] = dpl;
-    if (lane == 0) { sm.md[n][0] = pr.mrun; sm.md[n][1] = rden; }
+    if (lane == 0) { sm.md[n][0] = sm.pst[n][49]; sm.md[n][1] = rden; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused train head after the last step, ALL FOUR TRIALS AT ONCE: team n = waves 3n .. 3n + 2 takes trial n.
+//   1. every wave requests its share of the trial's top rows (h1, which the layer-1 waves streamed out): lane (r = lane >> 4, c = lane & 15
+//      < 12) of wave w takes the 16-byte piece c of row 12 k + 4 w + r, k = 0 .. TB-1 -- one coalesced 768-byte request per instruction,
+//      all TB of a batch in flight; T <= 264 is ONE batch, whose rows then stay in registers for both passes over them
+//   2. wave 0 of the team runs the dense head of its trial (LayerNorm .. CE and back to dL/dpooled) while the rows arrive
+//   3. pass 1: alpha_t, dd_t = dpooled . top_t (16-lane DPP sums), sdot = sum_t alpha_t dd_t over the team
+//   4. dL/dscore_t = alpha_t (dd_t - sdot): one thread per t, coalesced stores
+//   5. pass 2: d attn.weight = sum_t dL/dscore_t top_t from the same registers (a second sweep when T > 264), d attn.bias; the outer
+//      products of the dense weights' gradients are spread over the whole team
+// (Before: the dense heads two per pooling wave, 16.5 us; one row per thread with three requests in flight, then a second sweep with
+// eight rows per thread in flight, 25 us of a 292-us launch -- latency, not work.)
+// ------------------------------------------------------------------------------------------------
+constexpr int TEAM = NTHR / NTR;                                   // 192 threads = 3 waves per trial
+constexpr int TB = 16;                                             // requests per batch and lane
+constexpr int TBROWS = 12 * TB;                                    // 264 rows per batch and team
+__device__ __forceinline__ float row16_sum(float v) { v = oct_sum(v); v += dpp_quad<0x140>(v); return v; }
+
+// Sum over the 192 threads (3 waves) of a TEAM; every team of the workgroup calls it at the same time (the barriers are the workgroup's)
+__device__ __forceinline__ float team_sum(float v, float *red /* [NTHR / 64] */, const int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const int w0 = 3 * (tid / TEAM);
+    const float s = (red[w0] + red[w0 + 1]) + red[w0 + 2];
+    __syncthreads();
+    return s;
+}
+
+__device__ __forceinline__ void train_tail4(const Lstm2FwdArgs &a, XSmem &sm, const int tid, const int b0) {
+    static_assert(sizeof(sm.ms) >= sizeof(float) * NTR * TT_TMAX, "dd_t / dL/dscore_t live in the (dead) multiplier staging area");
+    const int T = a.T, K = a.K, F = a.F;
+    const int n = __builtin_amdgcn_readfirstlane(tid / TEAM), tt = tid - n * TEAM;    // team = trial, thread of the team
+    const int w = __builtin_amdgcn_readfirstlane(tt >> 6), lane = tid & 63, r = lane >> 4, c = lane & 15;
+    const int b = b0 + n;
+    const bool vb = b < a.B;
+    float *sc = sm.sc[n];                                           // raw scores -> alpha_t
+    float *ddv = &sm.ms[0][0][0][0] + n * TT_TMAX;                  // dd_t -> dL/dscore_t
+    // (range check on the vector offset: rows beyond T and the pieces c >= 12 read as zero, a padding trial has no rows at all)
+    const rsrc_t top = make_rsrc(a.hseq1 + (size_t)(vb ? b : 0) * T * H, vb ? (long)T * H * 4 : 0);
+    const unsigned vo = c < 12 ? (unsigned)(((4 * w + r) * H + 4 * c) * 4) : VOFF_DROP;
+    if (a.defer_att) {
+        // The backward pass of this batch runs lstm2_bwd48x4_kernel, which walks the top rows anyway and forms dL/dscore_t, d attn.weight
+        // and d attn.bias on its way (sdot = dpooled . pooled needs no pass over the rows).  Left here: the dense head, alpha_t, and the
+        // records marked as open.  (Reading the rows back costs this kernel 49 MB per pass at B = 1 024: ~30 us of a 292-us launch.)
+        HeadPre hp = {};
+        if (w == 0) hp = dense_head_pre(a, lane, b);
+        if (w == 0 && !ablated(a.ablate, 4194304)) dense_head(a, sm, lane, b, n, hp);
+        __syncthreads();
+        const float mx = sm.md[n][0], rden = sm.md[n][1];
+        if (vb) {
+            for (int t = tt; t < T; t += TEAM) {
+                const float al = __expf(sc[t] - mx) * rden;
+                a.alpha[(size_t)b * T + t] = al;
+                *reinterpret_cast<float4 *>(a.adpack + ((size_t)b * T + t) * 4) = make_float4(al, 0.f, 1.f, 0.f);
+            }
+            float *slab = a.hslabs + (size_t)b * a.Ph;
+            for (int e2 = tt; e2 < K * F; e2 += TEAM) slab[a.o_fc3_w + e2] = sm.vdl[n][e2 / F] * sm.vz[n][e2 % F];
+            for (int e2 = tt; e2 < F * H; e2 += TEAM) { const int f = e2 / H; slab[a.o_fc0_w + e2] = sm.vdz[n][f] * sm.vln[n][e2 - f * H]; }
+        }
+        __syncthreads();
+        return;
+    }
+    const int nb = (T + TBROWS - 1) / TBROWS;
+    f32x4 v[TB];
+    auto load = [&](const int kb) {
+        const unsigned vk = vo + (unsigned)kb * (unsigned)(TBROWS * H * 4);
+#pragma unroll
+        for (int k = 0; k < TB; ++k) {
+            const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(top, (int)(vk + (unsigned)(k * 12 * H * 4)), 0, 0);
+            v[k] = f32x4{__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
+        }
+    };
+    HeadPre hp = {};
+    if (w == 0) hp = dense_head_pre(a, lane, b);
+    load(0);
+    if (w == 0 && !ablated(a.ablate, 4194304)) dense_head(a, sm, lane, b, n, hp);
+    __syncthreads();
+    const float mx = sm.md[n][0], rden = sm.md[n][1];
+    f32x4 dp4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < 12) dp4 = *reinterpret_cast<const f32x4 *>(&sm.dp[n][4 * c]);
+    float lsd = 0.f;
+    auto pass1 = [&](const int kb) {
+#pragma unroll
+        for (int k = 0; k < TB; ++k) {
+            const int t = kb * TBROWS + 12 * k + 4 * w + r;
+            const bool ok = t < T;
+            const float d = row16_sum(fmaf(v[k][0], dp4[0], v[k][1] * dp4[1]) + fmaf(v[k][2], dp4[2], v[k][3] * dp4[3]));
+            const float al = ok ? __expf(sc[ok ? t : 0] - mx) * rden : 0.f;
+            if (c == 0) {
+                lsd = fmaf(al, d, lsd);
+                if (ok) { sc[t] = al; ddv[t] = d; }
+            }
+        }
+    };
+    pass1(0);
+    for (int kb = 1; kb < nb; ++kb) { load(kb); pass1(kb); }
+    const float sdot = team_sum(lsd, sm.red, tid);
+    float lb = 0.f;
+    for (int t = tt; t < T; t += TEAM) {
+        const float al = sc[t], ds = al * (ddv[t] - sdot);
+        if (vb) {
+            a.alpha[(size_t)b * T + t] = al;
+            a.dscore[(size_t)b * T + t] = ds;
+            *reinterpret_cast<float4 *>(a.adpack + ((size_t)b * T + t) * 4) = make_float4(al, ds, 0.f, 0.f);
+        }
+        ddv[t] = ds;
+        lb += ds;
+    }
+    const float dab = team_sum(lb, sm.red, tid);                    // (its barriers also publish ddv[] = dL/dscore)
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto pass2 = [&](const int kb) {
+#pragma unroll
+        for (int k = 0; k < TB; ++k) {
+            const int t = kb * TBROWS + 12 * k + 4 * w + r;
+            const bool ok = t < T;
+            const float ds = ok ? ddv[ok ? t : 0] : 0.f;
+            acc[0] = fmaf(ds, v[k][0], acc[0]); acc[1] = fmaf(ds, v[k][1], acc[1]);
+            acc[2] = fmaf(ds, v[k][2], acc[2]); acc[3] = fmaf(ds, v[k][3], acc[3]);
+        }
+    };
+    if (nb == 1) pass2(0);
+    else for (int kb = 0; kb < nb; ++kb) { load(kb); pass2(kb); }
+    if (c < 12) *reinterpret_cast<f32x4 *>(&sm.part[n * 12 + 4 * w + r][4 * c]) = acc;
+    float *slab = a.hslabs + (size_t)(vb ? b : 0) * a.Ph;
+    if (vb) {
+        if (tt == 0) slab[a.o_attn_b] = dab;
+        for (int e2 = tt; e2 < K * F; e2 += TEAM) slab[a.o_fc3_w + e2] = sm.vdl[n][e2 / F] * sm.vz[n][e2 % F];
+        for (int e2 = tt; e2 < F * H; e2 += TEAM) { const int f = e2 / H; slab[a.o_fc0_w + e2] = sm.vdz[n][f] * sm.vln[n][e2 - f * H]; }
+    }
+    __syncthreads();
+    if (tt < H && vb) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 12; p += 2) { s0 += sm.part[n * 12 + p][tt]; s1 += sm.part[n * 12 + p + 1][tt]; }
+        slab[a.o_attn_w + tt] = s0 + s1;
+    }
+    __syncthreads();
+}
+
+// what every wave does after the last step of a trial group when the head is fused
+__device__ __attribute__((noinline)) void tail_all(const Lstm2FwdArgs &a_in, const int tid, const int b0_in) {
+    XSmem &sm = g_sm;
+    const int b0 = __builtin_amdgcn_readfirstlane(b0_in);
+    const Lstm2FwdArgs a = uniform_copy(a_in);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's h rows are in memory before the workgroup reads them back
+    __syncthreads();                                                // ... and the pooling waves have left the four trials' pooling state in LDS
+    if (!ablated(a.ablate, 8388608)) train_tail4(a, sm, tid, b0);
 }
 
 // pooling wave `pw` (0 / 1) takes trials 2 pw and 2 pw + 1 of the group.  Chunk c of a trial (t = 8c .. 8c + 7) is complete in the
@@ -702,7 +756,8 @@ __device__ __forceinline__ void dense_head(const Lstm2FwdArgs &a, XSmem &sm, con
 // run in the macro steps 8c + 10 .. 8c + 17.
 __device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a_in, const int pw_in, const int lane, const int n_steps_in, const int grp_in) {
     XSmem &sm = g_sm;
-    const int pw = __builtin_amdgcn_readfirstlane(pw_in), n_steps = __builtin_amdgcn_readfirstlane(n_steps_in), grp = __builtin_amdgcn_readfirstlane(grp_in);
+    const int pw = __builtin_amdgcn_readfirstlane(pw_in), n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);
+    (void)grp_in;
     const Lstm2FwdArgs a = uniform_copy(a_in);
     const int T = a.T, K = a.K, F = a.F;
     float awp[6];
@@ -713,12 +768,9 @@ __device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a_in, co
         for (int e = lane; e < F * H; e += 64) { const int f = e / H; sm.w0[f * TT_W0S + (e - f * H)] = a.fc0_w[e]; }
         for (int e = lane; e < K * F; e += 64) sm.w3[e] = a.fc3_w[e];
     }
-    const float lnw = lane < H ? a.ln_w[lane] : 0.f, lnb = lane < H ? a.ln_b[lane] : 0.f;
-    const float b0v = lane < F ? a.fc0_b[lane] : 0.f, b3v = lane < K ? a.fc3_b[lane] : 0.f;
     Prof prof = prof_init(a.dbg);
     const int last_q = SCH * ((T - 1) / SCH) + SCH - 1;             // last stage-step: stage 3 of the second trial of the last chunk
     {
-        const int b0 = grp * NTR;
         PoolRun pr[2];
         pool_reset(pr[0]); pool_reset(pr[1]);
         auto stage_step = [&](const int q) {
@@ -733,9 +785,11 @@ __device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a_in, co
             xstep_barrier(prof);
         }
         for (int q = n_steps - 10 > 0 ? n_steps - 10 : 0; q <= last_q; ++q) stage_step(q);     // (the ring is complete and stable now)
-        if (!ablated(a.ablate, 4194304)) {
-        dense_head(a, sm, lane, b0 + 2 * pw, 2 * pw, pr[0], lnw, lnb, b0v, b3v);
-        dense_head(a, sm, lane, b0 + 2 * pw + 1, 2 * pw + 1, pr[1], lnw, lnb, b0v, b3v);
+        // the pooling state goes to the head waves of the tail (tail_all: one wave per trial, the four of them at once)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (lane < H) sm.pst[2 * pw + i][lane] = pr[i].pooled;
+            if (lane == 0) { sm.pst[2 * pw + i][48] = pr[i].den; sm.pst[2 * pw + i][49] = pr[i].mrun; }
         }
     }
     prof_store(a.dbg, prof);

@@ -195,7 +195,7 @@ def ws_view(ws: torch.Tensor, spec: ModelSpec, B: int, T: int, region: str) -> t
     H, L, F = spec.H, spec.L, spec.F
     shapes = {"hseq": (L, B, T, H), "cseq": (L, B, T, H), "gact": (L, B, T, H, 4), "inseq": (max(L - 1, 0), B, T, H),
               "top": (B, T, H), "alpha": (B, T), "pooled": (B, H), "fc0_pre": (B, F), "dscore": (B, T),
-              "dpooled": (B, H), "loss": (B,)}
+              "dpooled": (B, H), "loss": (B,), "adpack": (B, T, 4)}
     shp = shapes[region]
     n = 1
     for v in shp:

@@ -1075,6 +1075,53 @@ def test_four_trials_per_workgroup_backward_on_the_matrix_pipe(nsd, dev, ref_sta
             ops.force_bwd48(0)
 
 
+@pytest.mark.parametrize("B,T", [(4, 5), (7, 33), (9, 250), (5, 14), (2, 1), (3, 625)])
+def test_four_trial_kernels_share_the_attention_backward(nsd, dev, ref_state, B, T):
+    """When both passes of a batch run the four-trial kernels, the fused head of the forward kernel does not walk the top rows a second
+    time: it leaves alpha_t and OPEN {alpha, dscore} records, and the backward kernel -- which reads the saved activations anyway --
+    forms dL/dscore_t = alpha_t dpooled . (top_t - pooled), d attn.weight (in the layer-1 recurrence's lanes) and d attn.bias.  Held
+    to the closed form of the same forward kernel (backward pinned to the two-trial kernel: the forward then runs its own tail): same
+    alpha / dscore regions of the workspace, same gradients to 2e-5 of the largest element, explicit masks and in-kernel streams; a second
+    backward pass over the same workspace finds the records still open and gives the same gradients."""
+    from nsd_amd import _lib, ops
+    spec = ops.ModelSpec()
+    flat_np = orc.flatten_state(ref_state, D)
+    flat = _t(flat_np, dev)
+    xn, yn = synth_x(B, T, seed=B + T), synth_labels(B, seed=B + T)
+    x, y = _t(xn, dev), _t(yn.astype(np.int32), dev)
+    dln, sln, dhn = counter_masks(B, T, 48, 32, seed=3 * B + T)
+    dl, sl, dh = _t(dln, dev), _t(sln, dev), _t(dhn, dev)
+    variants = [dict(drop_lstm=dl, rrelu_slope=sl, drop_head=dh, fused_head=True)]
+    if ops.rng_path(spec, B, T):
+        variants.append(dict(rng=dict(seed=0x1234ABCD, base_stream=44, p_lstm=0.6, p_head=0.6)))
+    with _lib.diagnostic_library():
+        try:
+            ops.force_fwd48(4)
+            for kw in variants:
+                res = {}
+                for nb in (2, 4):
+                    ops.force_bwd48(nb)
+                    ws = ops.new_workspace(spec, B, T, dev)
+                    ws.fill_(float("nan"))
+                    logits = torch.full((B, spec.K), float("nan"), device=dev)
+                    grads = torch.empty_like(flat)
+                    ops.train_step_grads(spec, flat, x, ws, y, logits, grads, **kw)
+                    torch.cuda.synchronize()
+                    res[nb] = (logits.clone(), grads.clone(), ops.ws_view(ws, spec, B, T, "alpha").clone(), ops.ws_view(ws, spec, B, T, "dscore").clone())
+                    if nb == 4:
+                        pack = ops.ws_view(ws, spec, B, T, "adpack")
+                        assert bool((pack[..., 2] == 1.0).all()), "the records of a deferred forward are marked open"
+                (l2, g2, a2, s2), (l4, g4, a4, s4) = res[2], res[4]
+                assert torch.equal(l2, l4)
+                assert torch.isfinite(g4).all() and torch.isfinite(s4).all()
+                assert (a2 - a4).abs().max().item() < 1e-6
+                assert (s2 - s4).abs().max().item() <= 2e-5 * max(s2.abs().max().item(), 1e-6) + 1e-8, ((s2 - s4).abs().max().item(), s2.abs().max().item())
+                assert (g2 - g4).abs().max().item() <= 2e-5 * g2.abs().max().item() + 1e-9, (kw.keys(), (g2 - g4).abs().max().item(), g2.abs().max().item())
+        finally:
+            ops.force_fwd48(0)
+            ops.force_bwd48(0)
+
+
 @pytest.mark.parametrize("C,K,B,T", [(5, 4, 10, 37), (1, 2, 5, 20), (8, 8, 13, 50)])
 def test_four_trial_kernels_other_channel_and_class_counts(nsd, dev, C, K, B, T):
     """The four-trial forward / backward kernels with fewer EEG channels than the 8 their x staging is laid out for (zero weights /

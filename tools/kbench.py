@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--ablate", default="0")
     ap.add_argument("--mask", type=int, default=1)
     ap.add_argument("--prof", action="store_true")
+    ap.add_argument("--rng", action="store_true", help="the train-mode streams drawn in the kernels (what bench.py's step runs) instead of explicit tensors")
     args = ap.parse_args()
     import nsd_amd
     from nsd_amd import ops
@@ -64,11 +65,22 @@ def main():
         os.environ["NSD_ABLATE"] = str(ab)
         logits, _ = ops.train_forward(spec, flat, x, ws, drop_lstm=dl)
         ops.train_backward(spec, flat, x, ws, logits, labels=y, drop_lstm=dl)
+        rng = _lib.Rng(0x1234ABCD, 44, 0.6, 0.6)
+        lg0 = torch.empty(B, 3, device=dev)
+        if args.rng:      # leave the workspace as the fused forward of the step leaves it
+            L.nsd_lstm_head_train_rng(C.byref(d), pp, xp, C.byref(rng), y.data_ptr(), 1.0 / B, flags, wsp, wsn, lg0.data_ptr(), st)
+            bwd = lambda: L.nsd_lstm_bwd_rng(C.byref(d), pp, xp, C.byref(rng), flags, wsp, wsn, st)
+        else:
+            bwd = lambda: L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, wsn, None, st)
         f_med, f_min = timed(lambda: L.nsd_lstm_fwd(C.byref(d), pp, xp, dlp, flags, wsp, wsn, st), args.iters)
-        b_med, b_min = timed(lambda: L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, wsn, None, st), args.iters)
+        if args.rng:
+            L.nsd_lstm_head_train_rng(C.byref(d), pp, xp, C.byref(rng), y.data_ptr(), 1.0 / B, flags, wsp, wsn, lg0.data_ptr(), st)
+        b_med, b_min = timed(bwd, args.iters)
         sl = ops.rrelu_noise(1, 1, (B, 32), dev); dh = ops.dropout_mask(1, 2, 0.6, (B, 32), dev)
         lg = torch.empty(B, 3, device=dev)
-        if hasattr(L, "nsd_lstm_head_train"):
+        if args.rng:
+            h_med, h_min = timed(lambda: L.nsd_lstm_head_train_rng(C.byref(d), pp, xp, C.byref(rng), y.data_ptr(), 1.0 / B, flags, wsp, wsn, lg.data_ptr(), st), args.iters)
+        elif hasattr(L, "nsd_lstm_head_train"):
             h_med, h_min = timed(lambda: L.nsd_lstm_head_train(C.byref(d), pp, xp, dlp, sl.data_ptr(), dh.data_ptr(), y.data_ptr(),
                                                                1.0 / B, flags, wsp, wsn, lg.data_ptr(), st), args.iters)
         else:
@@ -88,7 +100,7 @@ def main():
                         roles = ["L1", "L1", "L1", "P", "L0", "L0", "L0", "P", "stage", "idle", "idle", "P"]
                         nst = ((T + 2 + 15) // 16) * 16
                 else:
-                    L.nsd_lstm_bwd(C.byref(d), pp, xp, dlp, flags, wsp, wsn, None, st)
+                    bwd()
                     roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1"] * 3 + ["dW"] * 6 + ["loader"]
                     nst = 4 * ((((T + 2) // 4 + 1) + 1) & ~1)
                     if B >= 576:                     # four trials per workgroup (nsd_lstm2_bwd48x4.hip): role = f(wave & 3, wave >> 2)
