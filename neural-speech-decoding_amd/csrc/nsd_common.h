@@ -116,6 +116,29 @@ __device__ __forceinline__ A uniform_copy(const A &in) {
     return out;
 }
 
+// The dense head's weights -> LDS once per workgroup (fc.0 [F][H] with row stride W0S, fc.3 [K][F] as it is), by ONE wave, sixteen requests
+// of a lane in flight at a time.  (As `for (e = lane; e < n; e += 64) lds[..] = w[e]` hipcc emits one load, a full wait and one LDS
+// write per trip: 26 round trips to the L2 in front of the workgroup's first step barrier, ~14 us of a launch.)
+template <int HH, int W0S>
+__device__ __forceinline__ void stage_head_weights(const float *fc0_w, const float *fc3_w, const int F, const int K, float *w0, float *w3, const int lane) {
+    typedef const __attribute__((address_space(1))) float *gw_p;
+    const int n0 = F * HH, n3 = K * F;
+    for (int e0 = 0; e0 < n0; e0 += 64 * 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int e = e0 + lane + 64 * i; v[i] = ((gw_p)fc0_w)[e < n0 ? e : 0]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int e = e0 + lane + 64 * i; if (e < n0) { const int f = e / HH; w0[f * W0S + (e - f * HH)] = v[i]; } }
+    }
+    for (int e0 = 0; e0 < n3; e0 += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int e = e0 + lane + 64 * i; v[i] = ((gw_p)fc3_w)[e < n3 ? e : 0]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int e = e0 + lane + 64 * i; if (e < n3) w3[e] = v[i]; }
+    }
+}
+
 // in-kernel train-mode streams (see nsd_rng in nsd.h): thresholds and keep factors precomputed on the host
 struct RngArgs {
     uint64_t seed;

@@ -728,8 +728,7 @@ __device__ __forceinline__ void tpool_role(const Lstm2FwdArgs &a, FSmem<NB> &sm,
 #pragma unroll
     for (int n = 1; n < NB; ++n) pr[n] = pr[0];
     // head weights: staged once per workgroup (LDS), per-lane vectors in registers
-    for (int e = lane; e < F * H; e += 64) { const int f = e / H; sm.w0[f * TT_W0S + (e - f * H)] = a.fc0_w[e]; }
-    for (int e = lane; e < K * F; e += 64) sm.w3[e] = a.fc3_w[e];
+    stage_head_weights<H, TT_W0S>(a.fc0_w, a.fc3_w, F, K, sm.w0, sm.w3, lane);
     const float lnw = lane < H ? a.ln_w[lane] : 0.f, lnb = lane < H ? a.ln_b[lane] : 0.f;
     const float b0v = lane < F ? a.fc0_b[lane] : 0.f, b3v = lane < K ? a.fc3_b[lane] : 0.f;
     Prof prof = prof_init(a.dbg);

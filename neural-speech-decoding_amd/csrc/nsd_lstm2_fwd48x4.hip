@@ -765,8 +765,7 @@ __device__ __attribute__((noinline)) void pool_role(const Lstm2FwdArgs &a_in, co
     for (int u = 0; u < 6; ++u) awp[u] = a.attn_w[6 * (lane & 7) + u];
     const float ab = a.attn_b[0];
     if (pw == 0) {                                                  // head weights: staged once per workgroup
-        for (int e = lane; e < F * H; e += 64) { const int f = e / H; sm.w0[f * TT_W0S + (e - f * H)] = a.fc0_w[e]; }
-        for (int e = lane; e < K * F; e += 64) sm.w3[e] = a.fc3_w[e];
+        stage_head_weights<H, TT_W0S>(a.fc0_w, a.fc3_w, F, K, sm.w0, sm.w3, lane);
     }
     Prof prof = prof_init(a.dbg);
     const int last_q = SCH * ((T - 1) / SCH) + SCH - 1;             // last stage-step: stage 3 of the second trial of the last chunk
