@@ -372,7 +372,7 @@ extern "C" int nsd_debug_gemm_stamps(unsigned long long *out) { return hipMemcpy
 #define GSTAMP(i) do { } while (0)
 #endif
 namespace dma {
-constexpr int TM = 256, TN = 256, ROWB = GK * 2;                // bytes per LDS row
+constexpr int TM = 256, TN = 256, NTH = 512, ROWB = GK * 2;     // bytes per LDS row
 constexpr int OPB = TM * ROWB;                                   // bytes of one operand image (32 KB)
 constexpr unsigned OOB = 0x7fffff00u;                            // a byte offset beyond num_records of the descriptors below
 
@@ -382,17 +382,11 @@ constexpr unsigned OOB = 0x7fffff00u;                            // a byte offse
 // the same moment: one chunk (~2 000 cycles) of flight time against an HBM latency of ~4 500 under load left every chunk waiting.
 // It gets THREE stages -- requested two chunks ahead, its DMA stays in flight across the chunk barrier (counted vmcnt, raw
 // s_barrier) -- and the LDS is full: (2 + 3) x 32 KB = 160 KB.
-// NW waves: 8 = wave tiles of 128 x 64 (two waves per SIMD), 4 = 128 x 128 (ONE wave per SIMD, 256 accumulator registers).  Per 16-deep
-// k step the CU's waves read (rows of A + rows of B per wave) x 32 B of fragments: 8 x 192 x 32 = 48 KB against 4 x 256 x 32 = 32 KB,
-// for 512 cycles of matrix-pipe time in which the LDS moves 64 KB at most -- with the 16 KB of DMA writes per step on top the
-// 8-wave shape keeps the LDS ~100 % busy (measured: fragment reads + DMA alone take 82 % of the kernel's time), the 4-wave shape 75 %.
-template <int EPI, int SA, int SB, int NW>
-__device__ __forceinline__ void gemm_bf16_dma_body(const GemmArgs &g) {
+template <int EPI, int SA, int SB>
+__global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmArgs g) {
     extern __shared__ __align__(16) unsigned char smem[];       // [SA A images | SB B images], the ONLY LDS object of the kernel
-    constexpr int NJ = 16 / NW;                                 // 32-column accumulator tiles per wave: 2 (8 waves) or 4 (4 waves)
-    constexpr int ND = 32 / NW;                                 // DMA instructions per operand, chunk and wave: 4 or 8 (8 rows each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;                    // wave tile: rows 128 wm .., columns 32 NJ wn ..
+    const int wm = wave & 1, wn = wave >> 1;                    // wave tile: rows 128 wm .., columns 64 wn ..
     // XCD-aware tile order: as gemm_bf16_big_kernel
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nt = tiles_m * tiles_n, tpx = (nt + 7) / 8;
     const bool remap = gridDim.x == (unsigned)(8 * tpx) && nt >= 16;
@@ -407,23 +401,23 @@ __device__ __forceinline__ void gemm_bf16_dma_body(const GemmArgs &g) {
     const long c_lo = (long)blockIdx.z * per, c_hi = (c_lo + per < nchunks) ? c_lo + per : nchunks;
     const long k_lo = c_lo * GK, k_hi = (c_hi * GK < g.K) ? c_hi * GK : g.K;
 
-    f32x16 acc[4][NJ];
+    f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = zero16();
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
 
     // descriptors based at the tile's first row: lane offsets stay far below 2^31 (checked at launch)
     const nsd_rsrc ra = make_rsrc(g.A + (long)m0 * g.lda, 0x7ffffe00u), rb = make_rsrc(g.B + (long)n0 * g.ldb, 0x7ffffe00u);
-    // this lane's piece of instruction i: row 8 NW i + 8 wave + (lane >> 3), LDS piece lane & 7 = source piece (lane & 7) ^ ((row >> 1) & 7)
-    unsigned va[ND], vb[ND];
-    int kpiece;                                                 // source k piece of this lane (the same for all rows: 8 NW i + 8 wave keeps (row >> 1) & 7)
+    // this lane's piece of instruction i: row 64 i + 8 wave + (lane >> 3), LDS piece lane & 7 = source piece (lane & 7) ^ ((row >> 1) & 7)
+    unsigned va[4], vb[4];
+    int kpiece;                                                 // source k piece of this lane (the same for all 4 rows: 64 i + 8 wave keeps (row >> 1) & 7)
     {
         const int rl = lane >> 3, sw = (((8 * wave + rl) >> 1) & 7);
         kpiece = (lane & 7) ^ sw;
 #pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const int r = 8 * NW * i + 8 * wave + rl;
+        for (int i = 0; i < 4; ++i) {
+            const int r = 64 * i + 8 * wave + rl;
             va[i] = m0 + r < g.M ? (unsigned)(r * g.lda * 2 + kpiece * 16) : OOB;
             vb[i] = n0 + r < g.N ? (unsigned)(r * g.ldb * 2 + kpiece * 16) : OOB;
         }
@@ -432,27 +426,27 @@ __device__ __forceinline__ void gemm_bf16_dma_body(const GemmArgs &g) {
     unsigned char *const Abase = smem, *const Bbase = smem + (size_t)SA * OPB;
     const long ntile = k_lo < k_hi ? (k_hi - k_lo + GK - 1) / GK : 0;
     // request chunk t of one operand into its image t % S (nothing is issued beyond the split's range: the counted waits below
-    // assume exactly ND DMA instructions per operand and chunk, so a chunk that does not exist is "requested" out of range: zeros)
-    // DMA instruction i (0..ND-1) of chunk t of an operand: rows 8 NW i + 8 wave .. of the image t % S
+    // assume exactly 4 DMA instructions per operand and chunk, so a chunk that does not exist is "requested" out of range: zeros)
+    // DMA instruction i (0..3) of chunk t of an operand: rows 64 i + 8 wave .. of the image t % S
     auto dma_a = [&](const long t, const int i) {
         unsigned char *dst = Abase + (size_t)(t % SA) * OPB + (size_t)wave * 8 * ROWB;
         const long k0 = k_lo + t * GK;
         const bool kok = t < ntile && k0 + 8 * kpiece < k_hi;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + i * 8 * NW * ROWB), 16, kok ? va[i] : OOB, t < ntile ? (int)(k0 * 2) : 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(dst + i * 64 * ROWB), 16, kok ? va[i] : OOB, t < ntile ? (int)(k0 * 2) : 0, 0, 0);
     };
     auto dma_b = [&](const long t, const int i) {
         unsigned char *dst = Bbase + (size_t)(t % SB) * OPB + (size_t)wave * 8 * ROWB;
         const long k0 = k_lo + t * GK;
         const bool kok = t < ntile && k0 + 8 * kpiece < k_hi;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(dst + i * 8 * NW * ROWB), 16, kok ? vb[i] : OOB, t < ntile ? (int)(k0 * 2) : 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(dst + i * 64 * ROWB), 16, kok ? vb[i] : OOB, t < ntile ? (int)(k0 * 2) : 0, 0, 0);
     };
     auto stage_a = [&](const long t) {
 #pragma unroll
-        for (int i = 0; i < ND; ++i) dma_a(t, i);
+        for (int i = 0; i < 4; ++i) dma_a(t, i);
     };
     auto stage_b = [&](const long t) {
 #pragma unroll
-        for (int i = 0; i < ND; ++i) dma_b(t, i);
+        for (int i = 0; i < 4; ++i) dma_b(t, i);
     };
     // fragment addresses: row base + (lane & 31), k piece (2 ks + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)   (row bases are multiples of 32)
     const int fsw = ((lane & 31) >> 1) & 7, fkq = lane >> 5;
@@ -467,8 +461,7 @@ __device__ __forceinline__ void gemm_bf16_dma_body(const GemmArgs &g) {
         if (SB == 3) stage_b(1);
         // issue order inside chunk t of the loop: [2-stage operand: chunk t+1] [3-stage operand: chunk t+2]; what must have landed
         // at the end of chunk t is chunk t+1 of both: everything but the 4 youngest instructions where a 3-stage operand exists
-        if (SA == 3 || SB == 3) { if (ND == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (SA == 3 || SB == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #if NSD_GEMM_ABL & 8
         unsigned long long st_acc[4] = {0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
@@ -476,23 +469,23 @@ __device__ __forceinline__ void gemm_bf16_dma_body(const GemmArgs &g) {
         for (long t = 0; t < ntile; ++t) {
             // (the barrier before this point ended every wave's reads of chunk t-1: its images are free)
             GSTAMP(0);
-            const unsigned char *As = Abase + (size_t)(t % SA) * OPB + (size_t)(128 * wm) * ROWB, *Bs = Bbase + (size_t)(t % SB) * OPB + (size_t)(32 * NJ * wn) * ROWB;
-            bf16x8 fa[2][4], fb[2][NJ];
-            auto frags = [&](const int ks, bf16x8 (&a)[4], bf16x8 (&b)[NJ]) {
+            const unsigned char *As = Abase + (size_t)(t % SA) * OPB + (size_t)(128 * wm) * ROWB, *Bs = Bbase + (size_t)(t % SB) * OPB + (size_t)(64 * wn) * ROWB;
+            bf16x8 fa[2][4], fb[2][2];
+            auto frags = [&](const int ks, bf16x8 (&a)[4], bf16x8 (&b)[2]) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(As + i * 32 * ROWB + koff[ks]);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(Bs + j * 32 * ROWB + koff[ks]);
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(Bs + j * 32 * ROWB + koff[ks]);
             };
             // The chunk's 8 DMA instructions are spread over its 32 MFMAs, one behind every fourth: issued in one burst at the top
             // of the chunk they took a quarter of the chunk's time (the CU's vector-memory path moves 64 B per clock: 64 KB per
             // chunk) during which both waves of every SIMD stood in the issue queue and no MFMA ran.  Order: first the operand with
             // two stages (its chunk t+1 must land by the end of THIS chunk), then the one with three (chunk t+2: a chunk of slack).
-            auto dma_step = [&](const int n) {                   // n = 0 .. 2 ND - 1
+            auto dma_step = [&](const int n) {                   // n = 0..7
                 if (NSD_GEMM_ABL & 1) return;
                 constexpr bool A_FIRST = SA == 2;
-                const bool first_half = n < ND;
-                const int i = n & (ND - 1);
+                const bool first_half = n < 4;
+                const int i = n & 3;
                 if (first_half == A_FIRST) dma_a(t + (SA - 1), i); else dma_b(t + (SB - 1), i);
             };
             if (!(NSD_GEMM_ABL & 4) || t == 0) frags(0, fa[0], fb[0]);
@@ -503,20 +496,18 @@ __device__ __forceinline__ void gemm_bf16_dma_body(const GemmArgs &g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
+                    for (int j = 0; j < 2; ++j)
                         if (!(NSD_GEMM_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
                         else acc[i][j][0] += (float)fa[ks & 1][i][0] * (float)fb[ks & 1][j][0];
-                    // one DMA instruction behind every fourth MFMA: 8 per chunk and wave (8 waves), 16 (4 waves)
-                    if (NW == 4 || (i & 1)) {
+                    if (i & 1) {
                         __builtin_amdgcn_sched_barrier(0);
-                        dma_step(NW == 4 ? 4 * ks + i : 2 * ks + (i >> 1));
+                        dma_step(2 * ks + (i >> 1));
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
             GSTAMP(1);                                          // fragment reads + MFMAs
-            if (SA == 3 || SB == 3) { if (ND == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (SA == 3 || SB == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             GSTAMP(2);                                          // wait for the DMA
             __builtin_amdgcn_s_barrier();
             GSTAMP(3);                                          // barrier
@@ -526,18 +517,13 @@ __device__ __forceinline__ void gemm_bf16_dma_body(const GemmArgs &g) {
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (out-of-range requests of the last chunks: nothing may be in flight when the LDS is released)
     }
-    gemm_epilogue<EPI, 4, NJ>(g, acc, m0 + 128 * wm, n0 + 32 * NJ * wn, lane);
+    gemm_epilogue<EPI, 4, 2>(g, acc, m0 + 128 * wm, n0 + 64 * wn, lane);
 }
-// (two kernels, not one with __launch_bounds__(64 * NW): with a template-dependent bound hipcc emits no host stub for the kernel)
-template <int EPI, int SA, int SB>
-__global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmArgs g) { gemm_bf16_dma_body<EPI, SA, SB, 8>(g); }
-template <int EPI, int SA, int SB>
-__global__ __launch_bounds__(256) void gemm_bf16_dma4_kernel(const GemmArgs g) { gemm_bf16_dma_body<EPI, SA, SB, 4>(g); }
 
-template <int EPI, int SA, int SB, int NW>
+template <int EPI, int SA, int SB>
 int launch_one(const GemmArgs &g, const dim3 grid, hipStream_t st) {
     static bool once = false;                                   // up to 160 KB of dynamic LDS needs the opt-in (per kernel, once per process)
-    auto *kp = NW == 8 ? &gemm_bf16_dma_kernel<EPI, SA, SB> : &gemm_bf16_dma4_kernel<EPI, SA, SB>;
+    auto *kp = &gemm_bf16_dma_kernel<EPI, SA, SB>;
     constexpr int LDS = (SA + SB) * OPB;
     if (!once) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -546,33 +532,27 @@ int launch_one(const GemmArgs &g, const dim3 grid, hipStream_t st) {
         }
         once = true;
     }
-    hipLaunchKernelGGL(kp, grid, dim3(64 * NW), LDS, st, g);
+    hipLaunchKernelGGL(kp, grid, dim3(NTH), LDS, st, g);
     NSD_CHECK_LAUNCH("gemm_bf16_dma_kernel");
     return NSD_OK;
 }
-template <int SA, int SB, int NW>
+template <int SA, int SB>
 int launch_stages(const GemmArgs &g, const dim3 grid, hipStream_t st) {
     switch (g.epi) {
-    case GEMM_EPI_F32: return launch_one<GEMM_EPI_F32, SA, SB, NW>(g, grid, st);
-    case GEMM_EPI_BF16: return launch_one<GEMM_EPI_BF16, SA, SB, NW>(g, grid, st);
-    case GEMM_EPI_TILE_BF16: return launch_one<GEMM_EPI_TILE_BF16, SA, SB, NW>(g, grid, st);
-    case GEMM_EPI_TILE_WAVE_BF16: return launch_one<GEMM_EPI_TILE_WAVE_BF16, SA, SB, NW>(g, grid, st);
+    case GEMM_EPI_F32: return launch_one<GEMM_EPI_F32, SA, SB>(g, grid, st);
+    case GEMM_EPI_BF16: return launch_one<GEMM_EPI_BF16, SA, SB>(g, grid, st);
+    case GEMM_EPI_TILE_BF16: return launch_one<GEMM_EPI_TILE_BF16, SA, SB>(g, grid, st);
+    case GEMM_EPI_TILE_WAVE_BF16: return launch_one<GEMM_EPI_TILE_WAVE_BF16, SA, SB>(g, grid, st);
     default: nsd_set_error("gemm_bf16: unknown epilogue %d", g.epi); return NSD_E_INVALID;
     }
 }
-template <int NW>
-int launch_waves(const GemmArgs &g, const dim3 grid, hipStream_t st) {
+int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
     // the operand with (many) more rows is the one streamed from HBM: it gets the third stage
     static const int force = [] { const char *e = getenv("NSD_GEMM_DMA_STAGES"); return e ? atoi(e) : 0; }();   // test hook: 22 / 23 / 32
     const int mode = force ? force : (g.M >= 4 * g.N ? 32 : (g.N >= 4 * g.M ? 23 : 22));
-    if (mode == 32) return launch_stages<3, 2, NW>(g, grid, st);
-    if (mode == 23) return launch_stages<2, 3, NW>(g, grid, st);
-    return launch_stages<2, 2, NW>(g, grid, st);
-}
-int launch_epi(const GemmArgs &g, const dim3 grid, hipStream_t st) {
-    static const int waves = [] { const char *e = getenv("NSD_GEMM_DMA_WAVES"); return e ? atoi(e) : 0; }();    // test hook: 4 / 8 (A/B runs, parity)
-    if (waves == 8) return launch_waves<8>(g, grid, st);
-    return launch_waves<4>(g, grid, st);
+    if (mode == 32) return launch_stages<3, 2>(g, grid, st);
+    if (mode == 23) return launch_stages<2, 3>(g, grid, st);
+    return launch_stages<2, 2>(g, grid, st);
 }
 }  // namespace dma
 
