@@ -30,6 +30,7 @@
 // HBM traffic = saved activations read once + one slab of partial gradients per workgroup at the end.
 #include "nsd_args.h"
 #include "nsd_prof.h"
+#include "nsd_bf16.h"
 
 namespace {
 
@@ -59,11 +60,14 @@ constexpr int DWD = NSD_BX4_DWD;
 #define NSD_BX4_B96 1
 #endif
 #ifndef NSD_BX4_CHD
-#define NSD_BX4_CHD 4
+#define NSD_BX4_CHD 2
 #endif
 #ifndef NSD_BX4_VAR
 #define NSD_BX4_VAR 0             // timing experiments (never in the library): 1 no d attn.weight in C1, 2 records never open, 4 open without the row requests
 #endif
+constexpr int WK = 16;            // k rows of a weight-gradient window: 4 macro steps x 4 trials = the K of one v_mfma_f32_32x32x16_bf16
+constexpr int ARS = 224;          // bf16 elements per k row of the da windows: 192 + pad (448 B = 192 mod 256: the four k rows of a transposed read's block fall into four different 64-byte bank groups)
+constexpr int BRS = 96;           // ... of the row windows (192 B)
 constexpr int CHD = NSD_BX4_CHD;   // steps a cell lane requests its saved activations ahead (= unroll of the recurrences' step loop; even, 16 % CHD == 0)   // steps the dW waves' B rows are requested ahead (= unroll of their step loop; 16 % DWD == 0)
 
 struct BSmem {
@@ -72,7 +76,10 @@ struct BSmem {
     float mk[2][NTR][XCH][H];     // layer-0 dropout multipliers of t = T + 1 - m, 16 macro steps per chunk
     float sc[2][NTR][XCH][4];     // {alpha, dscore, open, -} of t = T - 1 - m (open = 1: the record came without dscore, see the aux wave)
     float dpv[NTR][H];            // dL/dpooled of the group's trials (the aux wave's own copy, open records only)
-    float xs[2][NTR][XCH][16];    // x[t = T + 2 - m][channel] (channels >= C: zeros), the B operand of dW_ih0
+    float xs[2][NTR][XCH][16];    // x[t = T + 1 - m][channel] (channels >= C: zeros), the layer-0 window's columns 48..63
+    // split-bf16 operand windows of the weight gradients (see "weight gradients" below): [layer][hi, lo][window m >> 2 & 1][k = 4 (m & 3) + trial][..]
+    unsigned short wa[2][2][2][WK][ARS];   // da, k-major: column = k' = 4 unit + gate (written by the cell lanes)
+    unsigned short wb[2][2][2][WK][BRS];   // saved rows, k-major: layer 1 {h1[t-1] | in1[t]}, layer 0 {h0[t-1] | x[t] (16 columns) | -} (written by the rows wave)
 };
 __shared__ __align__(16) BSmem g_bsm;
 
@@ -110,6 +117,49 @@ __device__ __forceinline__ float rows_reduce_scatter(const f32x4 a) {
     const float s13 = __uint_as_float(p13[0]) + __uint_as_float(p13[1]);
     const u32x2 q = __builtin_amdgcn_permlane16_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradients: dW[192 x 48] = sum over (trial, step) of da (x) row -- a GEMM whose K runs over time, fp32 in, fp32 out.  As
+// v_mfma_f32_4x4x1 outer products they were half of the kernel's matrix-pipe time (432 + 48 of a step's 912 instructions, 8 cycles each).
+// Now: every fp32 operand is split into two bf16 (x = hi + lo + e, hi = bf16(x), lo = bf16(x - hi), |e| <= 2^-18 |x|) and a product is
+// THREE bf16 MFMAs with fp32 accumulation, hi.hi + hi.lo + lo.hi (the dropped lo.lo is <= 2^-16 of the product, bf16 products are exact
+// in fp32): v_mfma_f32_32x32x16_bf16 with K = 16 = four macro steps x four trials, 3 x 30 tiles per four steps = 22.5 instructions
+// of 32 cycles per step instead of 480 of 8.  The operands meet in LDS as k-major bf16 windows (two windows per layer, one being
+// filled while the other is read): the cell lanes write the da of their cell (one ds_write_b64 per half: the four gates of a unit
+// are adjacent columns), the rows wave the saved rows; the dW waves take both with ds_read_b64_tr_b16 (block = 4 k rows x 16 columns
+// -> the 8 consecutive k of one column an MFMA lane wants; nsd_bf16.h).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_bf16(const f32x4 v, u32x2 &hi, u32x2 &lo) {
+    hi[0] = pack_bf16x2(v[0], v[1]);
+    hi[1] = pack_bf16x2(v[2], v[3]);
+    lo[0] = pack_bf16x2(v[0] - bf16_lo(hi[0]), v[1] - bf16_hi(hi[0]));
+    lo[1] = pack_bf16x2(v[2] - bf16_lo(hi[1]), v[3] - bf16_hi(hi[1]));
+}
+// window row of macro step m, trial j; `col` = first of four adjacent columns
+__device__ __forceinline__ void put_da(BSmem &sm, const int layer, const int m, const int j, const int col, const f32x4 v) {
+    u32x2 hi, lo;
+    split_bf16(v, hi, lo);
+    const int w = (m >> 2) & 1, k = 4 * (m & 3) + j;
+    *reinterpret_cast<u32x2 *>(&sm.wa[layer][0][w][k][col]) = hi;
+    *reinterpret_cast<u32x2 *>(&sm.wa[layer][1][w][k][col]) = lo;
+}
+__device__ __forceinline__ void put_row(BSmem &sm, const int layer, const int m, const int j, const int col, const f32x4 v) {
+    u32x2 hi, lo;
+    split_bf16(v, hi, lo);
+    const int w = (m >> 2) & 1, k = 4 * (m & 3) + j;
+    *reinterpret_cast<u32x2 *>(&sm.wb[layer][0][w][k][col]) = hi;
+    *reinterpret_cast<u32x2 *>(&sm.wb[layer][1][w][k][col]) = lo;
+}
+// operand fragment of v_mfma_f32_32x32x16_bf16 from a k-major window: lane l (G = l >> 4, i = l & 15) gives the address of k row
+// 8 (G >> 1) + 4 e + (i >> 2), columns c0 + 16 (G & 1) + 4 (i & 3) .. + 3 and receives column c0 + (l & 31), k = 8 (l >> 5) + 4 e + 0..3
+template <int RS>
+__device__ __forceinline__ bf16x8 window_frag(const unsigned short *win, const int c0, const int lane) {
+    const int G = lane >> 4, i = lane & 15;
+    const unsigned short *p = win + (8 * (G >> 1) + (i >> 2)) * RS + c0 + 16 * (G & 1) + 4 * (i & 3);
+    const s16x4 e0 = lds_read_tr16(reinterpret_cast<const bf16_t *>(p));
+    const s16x4 e1 = lds_read_tr16(reinterpret_cast<const bf16_t *>(p + 4 * RS));
+    return cat_tr(e0, e1);
 }
 
 // W^T rows of a transposed product for lane (ks = lane >> 4, ub = (lane >> 2) & 3, i = lane & 3): w[s] = W[row(k' = 48 ks + s)][16 g + 4 ub + i],
@@ -250,6 +300,7 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
                 }
                 if (active) ct = cpk;                               // c[t-1] is the cell state of the next step handled
                 *reinterpret_cast<f32x4 *>(&sm.da[k & 1][LAYER][j][4 * u]) = dav;      // (zeros for inactive steps / padding trials: dW and X1 add nothing)
+                put_da(sm, LAYER, m, j, 4 * u, dav);                // the weight gradients' operand: row (step, trial) of the window being filled
                 prof_mark<4, true>(prof);                           // seg4: cell backward, da in LDS
                 xstep_barrier(prof);
             }
@@ -269,12 +320,6 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
     }
 }
 
-template <int TR>
-__device__ __forceinline__ void dwx_trial(const float (&a3)[4], const float bx, f32x4 (&acc3)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc3[q] = mfma_outer<TR>(a3[q], bx, acc3[q]);
-}
-
 // ------------------------------------------------------------------------------------------------
 // X1: d_in1[t] = W_ih1^T da1[t], t = T - m (da1 written at macro step m - 1) -> LDS for the layer-0 recurrence of macro step m + 1
 // ------------------------------------------------------------------------------------------------
@@ -284,15 +329,9 @@ __device__ __attribute__((noinline)) void x1_role(const Lstm2BwdArgs &a_in, cons
     const Lstm2BwdArgs a = uniform_copy(a_in);
     const int r = lane >> 4, ub = (lane >> 2) & 3, j = lane & 3;
     const int u = 16 * g + 4 * ub + r;
-    const int T = a.T, B = a.B, C = a.C;
+    const int T = a.T, B = a.B;
     float wv[H];
     load_wT(a.w_ih1, g, lane, wv);
-    // dW_ih0 = da0 (x) x[t] (outer-product form, see the dW waves): row tiles 4g .. 4g + 3 of k', the one 16-column tile of the channels
-    const int a3_off = ((lane >> 2) & 3) * VSD + 16 * (4 * g) + 4 * (lane >> 4) + (lane & 3);      // + 16 q: lane (rb, tr, i)
-    const int xc = 4 * ((lane >> 2) & 3) + (lane & 3);              // B operand lane (tr = lane >> 4, cb, jj): channel 4 cb + jj
-    f32x4 acc3[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc3[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     Prof prof = prof_init(a.dbg);
     const int ngrp = (B + NTR - 1) / NTR;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
@@ -306,92 +345,44 @@ __device__ __attribute__((noinline)) void x1_role(const Lstm2BwdArgs &a_in, cons
                 const int m = m0 + k, t1p = T - m;
                 if (NSD_BX4_X1_SLEEP) __builtin_amdgcn_s_sleep(NSD_BX4_X1_SLEEP);
                 if (t1p >= 0 && t1p < T) sm.din1[k & 1][j][u] = transposed_product(wv, &sm.da[(k + 1) & 1][1][j][48 * r], a.ablate);
-                const float *da0 = &sm.da[(k + 1) & 1][0][0][0];
-                float a3[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a3[q] = da0[a3_off + 16 * q];
-                const float bx = sm.xs[(m >> 4) & 1][lane >> 4][m & (XCH - 1)][xc];       // x[T + 2 - m] of trial lane >> 4 (staged by the aux wave)
-                if (m >= 1 && !ablated(a.ablate, 1)) {
-                    dwx_trial<0>(a3, bx, acc3);
-                    dwx_trial<1>(a3, bx, acc3);
-                    dwx_trial<2>(a3, bx, acc3);
-                    dwx_trial<3>(a3, bx, acc3);
-                }
                 xstep_barrier(prof);
             }
         }
     }
     prof_store(a.dbg, prof);
-    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
-    const int rb = lane >> 4;
-    if (xc < C) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kp = 16 * (4 * g + q) + 4 * rb + i;
-                slab[a.o_w_ih0 + (size_t)((kp & 3) * H + (kp >> 2)) * C + xc] = acc3[q][i];
-            }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// dW waves.  Wave d: matrix Q = d >> 1 (0: dW_hh1 = da1 (x) h1[t-1], 1: dW_ih1 = da1 (x) in1[t], 2: dW_hh0 = da0 (x) h0[t-1]), row tiles
-// 6 (d & 1) .. + 5 (16 rows of k' each), all three 16-column tiles.  (dW_ih0 = da0 (x) x[t], one column tile, rides in the X1 waves.)
+// rows wave: the saved rows of macro step m -- layer 1 (t = T-1-m): h1[t-1] | in1[t]; layer 0 (t = T+1-m): h0[t-1] | x[t] -- requested
+// DWD steps ahead (three 16-byte buffer loads per lane, lanes 0..47 = (trial, 4 columns); x comes staged from the aux wave, lanes
+// 48..63), split into bf16 halves and written into the row windows at the k row of (step, trial): what the cell lanes do for da.
+// Rows of inactive steps, of t - 1 < 0 and of padding trials read as zeros (switched off at the ADDRESS).
 // ------------------------------------------------------------------------------------------------
-template <int TR>
-__device__ __forceinline__ void dw_trial(const float (&av)[6], const float (&bv)[3], f32x4 (&acc)[6][3]) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct) acc[q][ct] = mfma_outer<TR>(av[q], bv[ct], acc[q][ct]);
-}
-
-
-__device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, const int d_in, const int lane, const int n_steps_in) {
+__device__ __attribute__((noinline)) void rows_role(const Lstm2BwdArgs &a_in, const int lane, const int n_steps_in) {
     BSmem &sm = g_bsm;
-    const int d = __builtin_amdgcn_readfirstlane(d_in), n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);
+    const int n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);
     const Lstm2BwdArgs a = uniform_copy(a_in);
-    const int Q = d >> 1, half = d & 1;
     const int T = a.T, B = a.B;
-    // A operand: lane (rb = lane >> 4, tr = (lane >> 2) & 3, i = lane & 3) = da[tr][16 rt + 4 rb + i]; B operand: lane (tr = lane >> 4, cb, jj)
-    const int a_rb = lane >> 4, a_tr = (lane >> 2) & 3, a_i = lane & 3;
-    const int b_tr = lane >> 4, b_cb = (lane >> 2) & 3, b_jj = lane & 3;
-    const int layerQ = Q == 2 ? 0 : 1;
-    const float *src = Q == 0 ? a.hseq1 : Q == 1 ? a.in1seq : a.hseq0;
     const long bth4 = (long)B * T * H * 4;
-    const rsrc_t r_s = make_rsrc(src, bth4);
-    f32x4 acc[6][3];
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct) acc[q][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int a_off = a_tr * VSD + 16 * (6 * half) + 4 * a_rb + a_i;          // + 16 q
+    const rsrc_t r_h1 = make_rsrc(a.hseq1, bth4), r_in1 = make_rsrc(a.in1seq, bth4), r_h0 = make_rsrc(a.hseq0, bth4);
+    const bool hb = lane < 48;                                      // lanes with a piece of the HBM rows
+    const int j = hb ? lane / 12 : (lane - 48) >> 2;                // trial
+    const int c4 = hb ? lane - 12 * j : lane & 3;                   // piece (four columns) of the 48-float row / of the 16 staged x floats
+    const int col0 = hb ? 4 * c4 : 48 + 4 * c4;                     // third piece: layer-0 window column (h0 | x)
     Prof prof = prof_init(a.dbg);
     const int ngrp = (B + NTR - 1) / NTR;
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
-        const int bb = grp * NTR + b_tr;
-        const bool vb = bb < B;
-        const unsigned vo = vb ? (unsigned)(((size_t)bb * T * H + 3 * (4 * b_cb + b_jj)) * 4) : VOFF_DROP;
-        // B rows of macro step m (pairing with the da written at macro step m - 1); out of range: zeros
-        auto prefetch = [&](const int m, float (&bv)[3]) {
-            const int t = Q == 2 ? T + 2 - m : T - m;               // the step whose da is used
-            const int tt = Q == 1 ? t : t - 1;                      // row of the saved sequence
-            const bool ok = t >= 0 && t < T && tt >= 0;
-            const int tc = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
-            const unsigned voe = ok ? vo : VOFF_DROP;               // (the ADDRESS is switched, not the value: a select on the loaded value is a wait for the load)
-            // ONE 12-byte load per lane: columns 3c .. 3c + 2, c = 4 cb + jj -- "column tile" v of the accumulators = the columns = v (mod 3).
-            // (Every vector-memory instruction of the step costs ~2.5 us per launch whatever it moves: three dword loads were three of them.)
-            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-#if NSD_BX4_B96
-            const u32x3 v3 = __builtin_amdgcn_raw_buffer_load_b96(r_s, (int)voe, tc * (H * 4), 0);
-            bv[0] = __uint_as_float(v3[0]); bv[1] = __uint_as_float(v3[1]); bv[2] = __uint_as_float(v3[2]);
-#else
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) bv[ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_s, (int)(voe + 4u * ct), tc * (H * 4), 0));
-#endif
+        const int b = grp * NTR + j;
+        const unsigned vo = (hb && b < B) ? (unsigned)(((size_t)b * T * H + 4 * c4) * 4) : VOFF_DROP;
+        auto prefetch = [&](const int m, f32x4 (&bv)[3]) {
+            const int t1 = T - 1 - m, t0 = T + 1 - m;
+            const bool ok1 = t1 >= 0 && t1 < T, ok0 = t0 >= 0 && t0 < T;
+            auto cl = [&](const int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
+            bv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_h1, (int)((ok1 && t1 >= 1) ? vo : VOFF_DROP), cl(t1 - 1) * (H * 4), 0));
+            bv[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_in1, (int)(ok1 ? vo : VOFF_DROP), cl(t1) * (H * 4), 0));
+            bv[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_h0, (int)((ok0 && t0 >= 1) ? vo : VOFF_DROP), cl(t0 - 1) * (H * 4), 0));
         };
-        float bq[DWD][3];
+        f32x4 bq[DWD][3];
 #pragma unroll
         for (int k = 0; k < DWD; ++k) prefetch(k, bq[k]);
         xstep_barrier(prof);
@@ -399,37 +390,91 @@ __device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, cons
 #pragma unroll
             for (int k = 0; k < DWD; ++k) {
                 const int m = m0 + k;
-                const float *dal = &sm.da[(m + 1) & 1][layerQ][0][0];
-                float av[6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) av[q] = dal[a_off + 16 * q];
-                if (NSD_BX4_DW_SLEEP) __builtin_amdgcn_s_sleep(NSD_BX4_DW_SLEEP);      // (let the recurrences' products through the matrix pipe first)
-                if (m >= 1 && !ablated(a.ablate, 1)) {
-                    dw_trial<0>(av, bq[k], acc);
-                    dw_trial<1>(av, bq[k], acc);
-                    dw_trial<2>(av, bq[k], acc);
-                    dw_trial<3>(av, bq[k], acc);
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(&sm.xs[(m >> 4) & 1][j][m & (XCH - 1)][hb ? 0 : 4 * c4]);      // (lanes >= 48 use it)
+                if (hb) {
+                    put_row(sm, 1, m, j, 4 * c4, bq[k][0]);
+                    put_row(sm, 1, m, j, 48 + 4 * c4, bq[k][1]);
                 }
+                put_row(sm, 0, m, j, col0, hb ? bq[k][2] : xv);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!ablated(a.ablate, 8)) prefetch(m + DWD, bq[k]);     // (behind the MFMAs that read these registers: the loads land in place)
+                if (!ablated(a.ablate, 8)) prefetch(m + DWD, bq[k]);     // (behind the last use of these registers: the loads land in place)
                 xstep_barrier(prof);
             }
         }
     }
     prof_store(a.dbg, prof);
-    // accumulator tile -> slab: lane (rb = lane >> 4, cb, jj) register i = dW[k' = 16 rt + 4 rb + i][3 (4 cb + jj) + ct]
-    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
-    const long base = Q == 0 ? a.o_w_hh1 : Q == 1 ? a.o_w_ih1 : a.o_w_hh0;
-    const int rb = lane >> 4, cb = (lane >> 2) & 3, jj = lane & 3;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW waves.  Five waves of six 32 x 32 accumulator tiles: d = 0..2 layer 1, rows k' = 64 d .. + 63 (two row tiles) x the 96 columns
+// {dW_hh1 | dW_ih1} (three column tiles); d = 3, 4 layer 0, rows 96 (d - 3) .. + 95 (three row tiles) x the 64 columns {dW_hh0 | dW_ih0
+// (16, C used) | -} (two column tiles).  The window of macro steps 4w .. 4w + 3 is complete behind the barrier of step 4w + 3 and is
+// overwritten from step 4w + 8 on: its products are spread over steps 4w + 4 .. 4w + 7, one column tile per step (three MFMAs per tile:
+// hi.hi, lo.hi, hi.lo); the last window of a trial group is taken behind the loop.
+// ------------------------------------------------------------------------------------------------
+template <int LAYER>
+__device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, const int d_in, const int lane, const int n_steps_in) {
+    BSmem &sm = g_bsm;
+    constexpr int NM = LAYER == 1 ? 2 : 3, NN = LAYER == 1 ? 3 : 2;   // row / column tiles of this wave
+    const int d = __builtin_amdgcn_readfirstlane(d_in), n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);
+    const Lstm2BwdArgs a = uniform_copy(a_in);
+    const int B = a.B;
+    const int row0 = 32 * NM * d;                                   // first k' of this wave
+    f32x16 acc[NM][NN];
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int mi = 0; mi < NM; ++mi)
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
+        for (int ni = 0; ni < NN; ++ni) acc[mi][ni] = zero16();
+    // one column tile of window w: B fragments once, A fragments per row tile
+    auto part = [&](const int w, const int ni) {
+        const bf16x8 bh = window_frag<BRS>(&sm.wb[LAYER][0][w][0][0], 32 * ni, lane);
+        const bf16x8 bl = window_frag<BRS>(&sm.wb[LAYER][1][w][0][0], 32 * ni, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kp = 16 * (6 * half + q) + 4 * rb + i;
-                slab[base + (size_t)((kp & 3) * H + (kp >> 2)) * H + 3 * (4 * cb + jj) + ct] = acc[q][ct][i];
+        for (int mi = 0; mi < NM; ++mi) {
+            const bf16x8 ah = window_frag<ARS>(&sm.wa[LAYER][0][w][0][0], row0 + 32 * mi, lane);
+            const bf16x8 al = window_frag<ARS>(&sm.wa[LAYER][1][w][0][0], row0 + 32 * mi, lane);
+            if (!ablated(a.ablate, 1)) {
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mi][ni], 0, 0, 0);
             }
+        }
+    };
+    Prof prof = prof_init(a.dbg);
+    const int ngrp = (B + NTR - 1) / NTR;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        xstep_barrier(prof);
+        for (int m0 = 0; m0 < n_steps; m0 += 4) {
+            const int w = ((m0 >> 2) + 1) & 1;                      // the window completed at macro step m0 - 1
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (NSD_BX4_DW_SLEEP) __builtin_amdgcn_s_sleep(NSD_BX4_DW_SLEEP);
+                if (m0 >= 4 && k < NN) part(w, k);
+                xstep_barrier(prof);
+            }
+        }
+        const int wl = ((n_steps >> 2) + 1) & 1;                    // the group's last window
+#pragma unroll
+        for (int k = 0; k < NN; ++k) part(wl, k);
+    }
+    prof_store(a.dbg, prof);
+    // accumulator tile -> slab: register r of lane l = dW[k' = row0 + 32 mi + mfma32_row(r, l)][column 32 ni + (l & 31) of the window]
+    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int mi = 0; mi < NM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NN; ++ni) {
+            const int c = 32 * ni + (lane & 31);
+            long base; int cc, ld;
+            if (LAYER == 1) { base = c < H ? a.o_w_hh1 : a.o_w_ih1; cc = c < H ? c : c - H; ld = H; }
+            else            { base = c < H ? a.o_w_hh0 : a.o_w_ih0; cc = c < H ? c : c - H; ld = c < H ? H : a.C; }
+            const bool okc = LAYER == 1 || c < H + a.C;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kp = row0 + 32 * mi + mfma32_row(r, lane);
+                if (okc) slab[base + (size_t)((kp & 3) * H + (kp >> 2)) * ld + cc] = acc[mi][ni][r];
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -483,7 +528,7 @@ __device__ __attribute__((noinline)) void aux_role(const Lstm2BwdArgs &a_in, con
     // x rows of chunk c: 4 trials x 16 steps x 16 floats (channels >= C: zeros) = 256 float4, 4 per lane
     const rsrc_t r_x = make_rsrc(a.x, (long)B * T * a.C * 4);
     auto x_at = [&](const int b0, const int c, const int e) -> f32x4 {        // e: float4 index in [0, NTR*XCH*4)
-        const int n = e >> 6, s = (e >> 2) & 15, q = e & 3, b = b0 + n, t = T + 2 - (16 * c + s);
+        const int n = e >> 6, s = (e >> 2) & 15, q = e & 3, b = b0 + n, t = T + 1 - (16 * c + s);
         const bool ok = b < B && t >= 0 && t < T;
         f32x4 v;
 #pragma unroll
@@ -634,20 +679,39 @@ __global__ __launch_bounds__(NTHR) void lstm2_bwd48x4_kernel(Lstm2BwdArgs a) {
     if (NSD_BX4_ONLY_ROLE == 1) chain_role<1>(a, g, lane, n_steps);
     else if (NSD_BX4_ONLY_ROLE == 2) chain_role<0>(a, g, lane, n_steps);
     else if (NSD_BX4_ONLY_ROLE == 3) x1_role(a, g, lane, n_steps);
-    else if (NSD_BX4_ONLY_ROLE == 4) dw_role(a, g, lane, n_steps);
+    else if (NSD_BX4_ONLY_ROLE == 4) dw_role<1>(a, g, lane, n_steps);
+    else if (NSD_BX4_ONLY_ROLE == 5) dw_role<0>(a, g & 1, lane, n_steps);
+    else if (NSD_BX4_ONLY_ROLE == 6) rows_role(a, lane, n_steps);
     else aux_role(a, lane, n_steps);
     return;
 #endif
 #ifndef NSD_BX4_PRIO
 #define NSD_BX4_PRIO 0
 #endif
+#ifndef NSD_BX4_MAP
+#define NSD_BX4_MAP 0
+#endif
     constexpr int PC = NSD_BX4_PRIO == 0 ? 3 : NSD_BX4_PRIO == 1 ? 0 : 1, PX = NSD_BX4_PRIO == 0 ? 2 : NSD_BX4_PRIO == 1 ? 0 : 1, PD = NSD_BX4_PRIO == 2 ? 3 : 0;
+#if NSD_BX4_MAP == 0
+    // SIMDs 0..2: the two recurrences + two of {five dW waves, rows wave}; SIMD 3: the three X1 waves + aux (matrix pipe per step and
+    // SIMD: 96 x 8 + ~2 x 144 cycles / 144 x 8)
+    if (g < 3 && q == 0)      { __builtin_amdgcn_s_setprio(PC); chain_role<1>(a, g, lane, n_steps); }
+    else if (g < 3 && q == 1) { __builtin_amdgcn_s_setprio(PC); chain_role<0>(a, g, lane, n_steps); }
+    else if (g < 3 && q == 2) { __builtin_amdgcn_s_setprio(PD); dw_role<1>(a, g, lane, n_steps); }
+    else if (g < 2)           { __builtin_amdgcn_s_setprio(PD); dw_role<0>(a, g, lane, n_steps); }
+    else if (g == 2)          { __builtin_amdgcn_s_setprio(PD); rows_role(a, lane, n_steps); }
+    else if (q < 3)           { __builtin_amdgcn_s_setprio(PX); x1_role(a, q, lane, n_steps); }
+    else                      aux_role(a, lane, n_steps);
+#else
+    // the round-4 placement: X1 beside the recurrences of its SIMD, the dW / rows waves on SIMD 3
     if (g < 3 && q == 0)      { __builtin_amdgcn_s_setprio(PC); chain_role<1>(a, g, lane, n_steps); }
     else if (g < 3 && q == 1) { __builtin_amdgcn_s_setprio(PC); chain_role<0>(a, g, lane, n_steps); }
     else if (g < 3 && q == 2) { __builtin_amdgcn_s_setprio(PX); x1_role(a, g, lane, n_steps); }
-    else if (g < 3)           { __builtin_amdgcn_s_setprio(PD); dw_role(a, g, lane, n_steps); }                 // dW waves 0..2
-    else if (q < 3)           { __builtin_amdgcn_s_setprio(PD); dw_role(a, 3 + q, lane, n_steps); }             // dW waves 3..5
+    else if (g < 3)           { __builtin_amdgcn_s_setprio(PD); dw_role<1>(a, g, lane, n_steps); }
+    else if (q < 2)           { __builtin_amdgcn_s_setprio(PD); dw_role<0>(a, q, lane, n_steps); }
+    else if (q == 2)          { __builtin_amdgcn_s_setprio(PD); rows_role(a, lane, n_steps); }
     else                      aux_role(a, lane, n_steps);
+#endif
     // a workgroup without a trial group (grid = the workspace's slab count) has written a zero slab: every role's sums are zero
 }
 
