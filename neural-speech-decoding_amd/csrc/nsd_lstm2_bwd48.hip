@@ -21,6 +21,9 @@
 // once (gates, c, h, in1, x) + one slab of partial gradients per workgroup at the end.
 #include "nsd_args.h"
 #include "nsd_prof.h"
+#include "nsd_bf16.h"
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -46,12 +49,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // put the memory latency (>= 1 us under load) on the recurrence.  A dedicated loader wave streams them one
 // 8-step chunk ahead with LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous) into a double-buffered
 // LDS stage; the chain only does LDS reads.
+// One trial per workgroup: the weight gradients' operands as k-major bf16 windows of 16 macro steps (see "dW waves" below):
+// [layer][hi, lo][window (m >> 4) & 1][k = m & 15][column]
+constexpr int WK = 16;
+constexpr int ARS = 224;            // bf16 elements per k row of the da windows: 192 + pad (448 B = 192 mod 256: the four k rows of a transposed read's block fall into four different 64-byte bank groups)
+constexpr int BRS = 96;             // ... of the row windows: layer 1 {h1[t-1] | in1[t]}, layer 0 {h0[t-1] | x[t] (16 columns, C used) | -}
+struct DwWin {
+    unsigned short wa[2][2][2][WK][ARS];
+    unsigned short wb[2][2][2][WK][BRS];
+};
+struct NoWin {};
 template <int NB>
 struct Smem {
     float ring[2][RING][NB][G4];           // [layer][macro step % RING][trial][gate*48+unit]
     float din1[2][NB][H];
     float stage[2][NB][2][CHUNK][REC];     // [buffer][trial][layer][step in chunk][record]  (linear per trial)
-    float xst[2][NB][CHUNK][8];            // x[T+2-m] rows for the x1 waves (dW_ih0), same chunking
+    float xst[2][NB][CHUNK][8];            // (two trials per workgroup only) x[T+2-m] rows for the x1 waves (dW_ih0), same chunking
+    typename std::conditional<NB == 1, DwWin, NoWin>::type win;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -217,7 +231,8 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
                 const int e = (k + PREV) & (RING - 1);
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
-                    const float2 xv = *reinterpret_cast<const float2 *>(&sm.xst[sb][n][k][2 * s]);
+                    float2 xv = {0.f, 0.f};
+                    if (NB == 2) xv = *reinterpret_cast<const float2 *>(&sm.xst[sb][n][k][2 * s]);
                     if (t1p >= 0 && t1p < T) {
                         float inp = slice_dot_t(&sm.ring[1][e][n][12 * kk], wp);
                         if (a.residual && b0 + n < B) {
@@ -228,7 +243,7 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
                         }
                         if (s == 0) sm.din1[k & 1][n][j] = inp;
                     }
-                    if (t0p >= 0 && t0p < T && b0 + n < B) {
+                    if (NB == 2 && t0p >= 0 && t0p < T && b0 + n < B) {       // (one trial per workgroup: dW_ih0 rides in the dW waves' layer-0 window)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const float d = sm.ring[0][e][n][g * H + j];
@@ -243,6 +258,7 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
     }
     prof_store(a.dbg, prof);
     float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    if (NB == 2)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (c0 < C) slab[a.o_w_ih0 + (size_t)(g * H + j) * C + c0] = dWih0[g][0];
@@ -378,6 +394,202 @@ __device__ __forceinline__ void dw_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// dW waves, ONE trial per workgroup (the benchmark's 256 trials): the sums over time as split-bf16 products.  Every fp32 operand is
+// x = hi + lo + e (hi = bf16(x), lo = bf16(x - hi), |e| <= 2^-18 |x|) and a product is hi.hi + lo.hi + hi.lo on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (bf16 products are exact in fp32; the dropped lo.lo is <= 2^-16 of a product):
+// K = 16 macro steps per instruction, 30 tiles x 3 instructions of 32 cycles per 16 steps = 180 matrix-pipe cycles per step and CU
+// against 864 for the fp32 form (27 v_mfma_f32_16x16x4_f32 of 32 cycles per step).  Wave w owns rows 32 w .. + 31 of all four
+// matrices (five 32 x 32 tiles: {dW_hh1 | dW_ih1} = three column tiles, {dW_hh0 | dW_ih0 | -} = two).  Operands meet in LDS as
+// k-major bf16 windows of 16 steps, two per layer (one being filled while the other is read):
+//   da      converted by the wave that owns the rows, one step behind the chains, from the fp32 ring (nothing changes for the chains);
+//   rows    h1[t-1], in1[t], h0[t-1], x[t]: ONE dword request per lane and step by waves 0..3 (four steps ahead), written for everyone;
+//   reads   ds_read_b64_tr_b16 (nsd_bf16.h): block = 4 k rows x 16 columns -> the 8 consecutive k of a column that an MFMA lane wants.
+// The window of steps 16 W .. 16 W + 15 is complete behind the barrier of step 16 W + 16; its five tiles are taken at steps
+// 16 W + 17 .. + 21, the last window of a trial behind the loop (its da sits in the ring until the next trial's chains start).
+// ------------------------------------------------------------------------------------------------
+#ifndef NSD_DW16_NOINLINE
+#define DW16_INLINE __forceinline__
+#else
+#define DW16_INLINE __attribute__((noinline))
+#endif
+template <class F, int... I>
+__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+__device__ __forceinline__ void split1_bf16(const float v, unsigned short &hi, unsigned short &lo) {
+    const unsigned h = pack_bf16x2(v, 0.f);
+    hi = (unsigned short)h;
+    lo = (unsigned short)pack_bf16x2(v - bf16_lo(h), 0.f);
+}
+template <int RS>
+__device__ __forceinline__ bf16x8 window_frag(const unsigned short *win, const int c0, const int lane) {
+    // lane l (G = l >> 4, i = l & 15) gives the address of k row 8 (G >> 1) + 4 e + (i >> 2), columns c0 + 16 (G & 1) + 4 (i & 3) .. + 3
+    // and receives column c0 + (l & 31), k = 8 (l >> 5) + 4 e + 0..3
+    const int G = lane >> 4, i = lane & 15;
+    const unsigned short *p = win + (8 * (G >> 1) + (i >> 2)) * RS + c0 + 16 * (G & 1) + 4 * (i & 3);
+    const s16x4 e0 = lds_read_tr16(reinterpret_cast<const bf16_t *>(p));
+    const s16x4 e1 = lds_read_tr16(reinterpret_cast<const bf16_t *>(p + 4 * RS));
+    return cat_tr(e0, e1);
+}
+
+__device__ __forceinline__ void split4_bf16(const f32x4 v, u32x2 &hi, u32x2 &lo) {
+    hi[0] = pack_bf16x2(v[0], v[1]);
+    hi[1] = pack_bf16x2(v[2], v[3]);
+    lo[0] = pack_bf16x2(v[0] - bf16_lo(hi[0]), v[1] - bf16_hi(hi[0]));
+    lo[1] = pack_bf16x2(v[2] - bf16_lo(hi[1]), v[3] - bf16_hi(hi[1]));
+}
+
+// Duties beside the wave's five tiles (instruction count matters more than anything else in this kernel: every role shares its SIMD
+// with a recurrence): waves 0..2 the rows h1[t-1] / in1[t] / h0[t-1] and wave 3 x[t], FOUR steps per request (lane = (step, 16-byte
+// piece) or (step, channel)), split and written every fourth step; waves 4, 5 the da of layer 1 / 0, every step, four columns per lane.
+__device__ DW16_INLINE void dw16_role(const Lstm2BwdArgs &a_in, Smem<1> &sm, const int w_in, const int lane, const int n_steps_in) {
+    const int w = __builtin_amdgcn_readfirstlane(w_in), n_steps = __builtin_amdgcn_readfirstlane(n_steps_in);
+    const Lstm2BwdArgs a = uniform_copy(a_in);
+    DwWin &win = sm.win;
+    const int T = a.T, B = a.B, C = a.C;
+    Prof prof = prof_init(a.dbg);
+    f32x16 acc[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q] = zero16();
+    // (lanes 48..63 of a 48-piece duty repeat the pieces 32..47: same address, same value, no branch)
+    const int l48 = lane < 48 ? lane : lane - 16;
+    // row duty of waves 0..2: lane (step s = l48 / 12, piece c4): 16 bytes; wave 3: lane (step s = lane >> 4, channel lane & 15): 4 bytes
+    const float *src = w == 0 ? a.hseq1 : w == 1 ? a.in1seq : w == 2 ? a.hseq0 : a.x;
+    const int rw = w == 3 ? C : H;                                  // floats per time step of the source
+    const int rs = w == 3 ? lane >> 4 : l48 / 12, rp = w == 3 ? lane & 15 : l48 - 12 * rs;
+    const int rl = w < 2 ? 1 : 0;                                   // layer of the window the rows go to
+    const int rc = w == 3 ? H + rp : (w == 1 ? H : 0) + 4 * rp;     // first window column of this lane
+    const long sbytes = (long)B * T * rw * 4;
+    const __amdgpu_buffer_rsrc_t r_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (int)(sbytes > 0x7fffffffL ? 0x7fffffffL : sbytes), 0x00020000);
+    constexpr unsigned DROP = 0x80000000u;
+    // layer-0 dropout multipliers drawn in the kernel: one value per dW lane and chunk, a chunk ahead like the loader (as before)
+    const int L = w * 64 + lane, mk_k = L / H, mk_j = L - mk_k * H;
+    auto gen_mask = [&](const int chunk, const int b) {
+        const int t = T + 1 - (chunk * CHUNK + mk_k);
+        if (t >= 0 && t < T)
+            sm.stage[chunk & 1][0][0][mk_k][240 + mk_j] =
+                nsd_rand_u32(a.rng.seed, a.rng.base, ((uint64_t)b * T + t) * H + mk_j) < a.rng.thr_lstm ? 0.f : a.rng.keep_lstm;
+    };
+    bf16x8 ah, al;                                                  // this wave's rows of a window, kept over the window's tiles of one layer
+    auto a_frags = [&](const int W, const int layer) {
+        ah = window_frag<ARS>(&win.wa[layer][0][W & 1][0][0], 32 * w, lane);
+        al = window_frag<ARS>(&win.wa[layer][1][W & 1][0][0], 32 * w, lane);
+    };
+    auto tile = [&](const int W, auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int layer = q < 3 ? 1 : 0, ni = q < 3 ? q : q - 3;
+        if (q == 0 || q == 3) a_frags(W, layer);
+        const bf16x8 bh = window_frag<BRS>(&win.wb[layer][0][W & 1][0][0], 32 * ni, lane);
+        const bf16x8 bl = window_frag<BRS>(&win.wb[layer][1][W & 1][0][0], 32 * ni, lane);
+        if (!ablated(a.ablate, 1)) {
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[q], 0, 0, 0);
+        }
+    };
+    // the row windows start as zeros: a row that is never written (the second half of a trial's last window when the step count is
+    // 8 mod 16) meets zero da -- it has to be finite
+    {
+        u32x4 *z = reinterpret_cast<u32x4 *>(&win.wb[0][0][0][0][0]);
+        constexpr int NZ = (int)(sizeof(win.wb) / 16);
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (int e = w * 64 + lane; e < NZ; e += 6 * 64) z[e] = zero;
+    }
+    const int ngrp = B;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int b = grp;
+        if (a.rng.on) gen_mask(0, b);
+        // rows of macro steps m .. m + 3 (this lane: m + rs); out of range -> zeros (switched off at the ADDRESS)
+        auto request = [&](const int m) -> f32x4 {
+            const int t = (rl == 1 ? T - 1 : T + 1) - m - rs;
+            const int tt = (w == 1 || w == 3) ? t : t - 1;
+            const bool ok = t >= 0 && t < T && tt >= 0 && (w != 3 || rp < C);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (w == 3) {
+                const unsigned off = ok ? (unsigned)((((size_t)b * T + tt) * C + rp) * 4) : DROP;
+                v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_s, (int)off, 0, 0));
+            } else {
+                const unsigned off = ok ? (unsigned)((((size_t)b * T + tt) * H + 4 * rp) * 4) : DROP;
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_s, (int)off, 0, 0));
+            }
+            return v;
+        };
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (w < 4) bq = request(0);
+        step_barrier<false>(prof);      // pairs with the stage-initialisation barrier of the other roles
+        auto half = [&](const int m0, auto phc) {
+            constexpr int PH = decltype(phc)::value;
+            static_for([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int m = m0 + k;
+                constexpr int p = PH + k;                            // m & 15
+                const int wi = (m >> 4) & 1;
+                if (w >= 4 && m >= 1) {                              // da of macro step m - 1 (written by the chains at that step)
+                    const int mm = m - 1, cl = 5 - w;
+                    const int t = cl == 1 ? T - 1 - mm : T + 1 - mm;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(&sm.ring[cl][mm & (RING - 1)][0][4 * l48]);
+                    if (!(t >= 0 && t < T)) v = f32x4{0.f, 0.f, 0.f, 0.f};       // (the chains do not write on inactive steps)
+                    u32x2 hi, lo;
+                    split4_bf16(v, hi, lo);
+                    *reinterpret_cast<u32x2 *>(&win.wa[cl][0][(mm >> 4) & 1][mm & 15][4 * l48]) = hi;
+                    *reinterpret_cast<u32x2 *>(&win.wa[cl][1][(mm >> 4) & 1][mm & 15][4 * l48]) = lo;
+                }
+                if (w < 4 && (k & 3) == 0) {                         // the rows of steps m .. m + 3, requested four steps ago
+                    if (w == 3) {
+                        unsigned short hi, lo;
+                        split1_bf16(bq[0], hi, lo);
+                        win.wb[0][0][wi][p + rs][rc] = hi;
+                        win.wb[0][1][wi][p + rs][rc] = lo;
+                    } else {
+                        u32x2 hi, lo;
+                        split4_bf16(bq, hi, lo);
+                        *reinterpret_cast<u32x2 *>(&win.wb[rl][0][wi][p + rs][rc]) = hi;
+                        *reinterpret_cast<u32x2 *>(&win.wb[rl][1][wi][p + rs][rc]) = lo;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    bq = request(m + 4);
+                }
+                if (a.rng.on && k == 1) gen_mask((m >> 3) + 1, b);  // second step of a chunk: the old records are dead
+                if (p >= 1 && p <= 5 && m >= 17) tile((m - 17) >> 4, std::integral_constant<int, (p >= 1 && p <= 5) ? p - 1 : 0>{});
+                step_barrier<false, DW_SLEEP>(prof);
+            }, std::make_integer_sequence<int, 8>{});
+        };
+        for (int m0 = 0; m0 < n_steps; m0 += 16) {
+            half(m0, std::integral_constant<int, 0>{});
+            if (m0 + 8 < n_steps) half(m0 + 8, std::integral_constant<int, 8>{});
+        }
+        // behind the loop: the last window's tiles.  Its row of the last macro step (always an inactive one: n_steps >= T + 3) and, when
+        // the step count is 8 mod 16, its second half get zeros in THIS wave's da columns.
+        {
+            const int Wl = (n_steps - 1) >> 4, cl = lane >> 5, cc = 32 * w + (lane & 31);
+            const int k0 = (n_steps - 1) & 15;
+            for (int k = k0; k < 16; ++k) {
+                win.wa[cl][0][Wl & 1][k][cc] = 0;
+                win.wa[cl][1][Wl & 1][k][cc] = 0;
+            }
+            tile(Wl, std::integral_constant<int, 0>{});
+            tile(Wl, std::integral_constant<int, 1>{});
+            tile(Wl, std::integral_constant<int, 2>{});
+            tile(Wl, std::integral_constant<int, 3>{});
+            tile(Wl, std::integral_constant<int, 4>{});
+        }
+    }
+    prof_store(a.dbg, prof);
+    // accumulator tile -> slab: register r of lane l = dW[row 32 w + mfma32_row(r, l)][window column 32 ni + (l & 31)]
+    float *slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int layer = q < 3 ? 1 : 0, c = 32 * (q < 3 ? q : q - 3) + (lane & 31);
+        const long base = layer == 1 ? (c < H ? a.o_w_hh1 : a.o_w_ih1) : (c < H ? a.o_w_hh0 : a.o_w_ih0);
+        const int ld = (layer == 0 && c >= H) ? C : H, col = c < H ? c : c - H;
+        const bool okc = layer == 1 || c < H + C;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * w + mfma32_row(r, lane);
+            if (okc) slab[base + (size_t)row * ld + col] = acc[q][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // loader wave: LDS-DMA stream of the saved activations, one chunk ahead of the chain.
 // A chunk image is 18 wave-wide 1 KB pieces per trial (+ one 256 B piece of x rows).  What a lane copies
 // in piece q never changes except for the time index, so the address recipe is decoded ONCE per lane
@@ -466,14 +678,14 @@ __device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm,
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
         loader_issue<NB, 0, NQ>(a, sm, d, 0, 0, b0);
-        loader_issue_x<NB>(a, sm, 0, 0, b0, lane);
+        if (NB == 2) loader_issue_x<NB>(a, sm, 0, 0, b0, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         step_barrier<true>(prof);
         for (int m0 = 0; m0 < n_steps; m0 += CHUNK) {
             const int chunk = m0 / CHUNK, nb = (chunk + 1) & 1;
             const bool on = !ablated(a.ablate, 16);
             // next chunk: 3 pieces per step during steps 0..5 (+ x rows at step 0); all landed before step 7 ends
-            if (on) { loader_issue<NB, 0, 3>(a, sm, d, chunk + 1, nb, b0); loader_issue_x<NB>(a, sm, chunk + 1, nb, b0, lane); }
+            if (on) { loader_issue<NB, 0, 3>(a, sm, d, chunk + 1, nb, b0); if (NB == 2) loader_issue_x<NB>(a, sm, chunk + 1, nb, b0, lane); }
             step_barrier<true, LD_SLEEP>(prof);
             if (on) loader_issue<NB, 3, 6>(a, sm, d, chunk + 1, nb, b0);
             step_barrier<true, LD_SLEEP>(prof);
@@ -507,7 +719,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     if (wave < 3)       { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 1, tid, n_steps); }
     else if (wave < 6)  { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 0, tid - 192, n_steps); }
     else if (wave < 9)  { __builtin_amdgcn_s_setprio(2); x1_role<NB>(a, sm, tid - 384, n_steps); }
-    else if (wave < 15) dw_role<NB>(a, sm, wave - 9, tid & 63, n_groups);
+    else if (wave < 15) { if constexpr (NB == 1) dw16_role(a, sm, wave - 9, tid & 63, n_steps); else dw_role<NB>(a, sm, wave - 9, tid & 63, n_groups); }
     else                { __builtin_amdgcn_s_setprio(1); loader_role<NB>(a, sm, tid & 63, n_steps); }
 }
 

@@ -1013,7 +1013,13 @@ def test_four_trials_per_workgroup_forward_on_the_matrix_pipe(nsd, dev, ref_stat
                 # the same regions of the workspace are written (NaN elsewhere in both), with the same values to rounding
                 assert bool((torch.isnan(w1) == torch.isnan(w4)).all()), int((torch.isnan(w1) != torch.isnan(w4)).sum().item())
                 wd = torch.where(torch.isnan(w1), torch.zeros_like(w1), (w1 - w4).abs())
-                assert wd.max().item() < 2e-5, wd.max().item()
+                # saved activations, head intermediates: 2e-5 absolute.  The slabs of partial weight gradients behind them are sums of
+                # split-bf16 products (each within 3 x 2^-18 of the fp32 product, the rounding points move with the forward kernel's last
+                # bits): 3e-5 of the region's largest element
+                _, wl = ops.workspace_layout(spec, B, T)
+                assert wd[:wl.slabs].max().item() < 2e-5, wd[:wl.slabs].max().item()
+                sl_max = torch.nan_to_num(w1[wl.slabs:], nan=0.0).abs().max().item()
+                assert wd[wl.slabs:].max().item() <= 2e-5 + 3e-5 * sl_max, (wd[wl.slabs:].max().item(), sl_max)
                 if vi < 2:                                        # explicit masks: the oracle saw the same ones
                     assert np.abs(l4.cpu().numpy() - fw["logits"]).max() < LOGIT_TOL
             ops.force_fwd48(4)
