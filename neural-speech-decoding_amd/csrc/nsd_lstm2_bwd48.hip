@@ -716,6 +716,27 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     const int n_groups = (((a.T + 2) / 4 + 1) + 1) & ~1;
     const int n_steps = 4 * n_groups;
     // issue priority follows the critical path: the two recurrences first, then the hand-off to layer 0
+    if constexpr (NB == 1) {
+#ifndef NSD_B48_MAP
+#define NSD_B48_MAP 1
+#endif
+        // Roles by SIMD (waves w and w + 4 share one; a SIMD's instructions per step are what bounds the step -- per-wave stamps:
+        // the younger recurrence of a SIMD that carries two runs at 1 065 cycles of work against 840 -- so the SIMDs with TWO
+        // recurrences get the four light dW waves (rows duty), the other two the x1 waves, the da converters and the loader):
+        //   SIMD 0: chain1_0 chain0_1 dW0 dW2 | SIMD 1: chain1_1 chain0_2 dW1 dW3 | SIMD 2: chain1_2 x1_0 x1_2 dW5 | SIMD 3: chain0_0 x1_1 dW4 loader
+        constexpr int ROLE[16] = {0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 2, 3, 3, 3, 3, 4};        // 0 chain1, 1 chain0, 2 x1, 3 dW, 4 loader
+        constexpr int PART[16] = {0, 1, 2, 0, 1, 2, 0, 1, 0, 1, 2, 4, 2, 3, 5, 0};
+        const int lane = tid & 63;
+        if (NSD_B48_MAP == 1) {
+            const int role = ROLE[wave], part = PART[wave];
+            if (role == 0)      { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 1, 64 * part + lane, n_steps); }
+            else if (role == 1) { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 0, 64 * part + lane, n_steps); }
+            else if (role == 2) { __builtin_amdgcn_s_setprio(2); x1_role<NB>(a, sm, 64 * part + lane, n_steps); }
+            else if (role == 3) dw16_role(a, sm, part, lane, n_steps);
+            else                { __builtin_amdgcn_s_setprio(1); loader_role<NB>(a, sm, lane, n_steps); }
+            return;
+        }
+    }
     if (wave < 3)       { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 1, tid, n_steps); }
     else if (wave < 6)  { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 0, tid - 192, n_steps); }
     else if (wave < 9)  { __builtin_amdgcn_s_setprio(2); x1_role<NB>(a, sm, tid - 384, n_steps); }

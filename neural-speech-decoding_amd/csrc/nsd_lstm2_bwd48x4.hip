@@ -62,6 +62,9 @@ constexpr int DWD = NSD_BX4_DWD;
 #ifndef NSD_BX4_CHD
 #define NSD_BX4_CHD 2
 #endif
+#ifndef NSD_BX4_CONV
+#define NSD_BX4_CONV 0            // who splits da into the bf16 windows: 0 the cell lanes (from their registers, at the step), 1 the rows wave (from the fp32 vectors in LDS, one step behind)
+#endif
 #ifndef NSD_BX4_VAR
 #define NSD_BX4_VAR 0             // timing experiments (never in the library): 1 no d attn.weight in C1, 2 records never open, 4 open without the row requests
 #endif
@@ -300,7 +303,7 @@ __device__ __attribute__((noinline)) void chain_role(const Lstm2BwdArgs &a_in, c
                 }
                 if (active) ct = cpk;                               // c[t-1] is the cell state of the next step handled
                 *reinterpret_cast<f32x4 *>(&sm.da[k & 1][LAYER][j][4 * u]) = dav;      // (zeros for inactive steps / padding trials: dW and X1 add nothing)
-                put_da(sm, LAYER, m, j, 4 * u, dav);                // the weight gradients' operand: row (step, trial) of the window being filled
+                if (!NSD_BX4_CONV) put_da(sm, LAYER, m, j, 4 * u, dav);     // the weight gradients' operand: row (step, trial) of the window being filled
                 prof_mark<4, true>(prof);                           // seg4: cell backward, da in LDS
                 xstep_barrier(prof);
             }
@@ -396,6 +399,22 @@ __device__ __attribute__((noinline)) void rows_role(const Lstm2BwdArgs &a_in, co
                     put_row(sm, 1, m, j, 48 + 4 * c4, bq[k][1]);
                 }
                 put_row(sm, 0, m, j, col0, hb ? bq[k][2] : xv);
+                if (NSD_BX4_CONV) {                                  // da of macro step m - 1, both layers: 384 pieces of four columns, six per lane
+                    if (m >= 1) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            const int rem = lane + 64 * (i % 3), jj = rem / 48, pc = rem - 48 * jj;
+                            put_da(sm, i / 3, m - 1, jj, 4 * pc, *reinterpret_cast<const f32x4 *>(&sm.da[(m + 1) & 1][i / 3][jj][4 * pc]));
+                        }
+                    }
+                    if (m == n_steps - 1) {                          // (the last macro step is an inactive one: zeros, nobody converts it)
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            const int rem = lane + 64 * (i % 3), jj = rem / 48, pc = rem - 48 * jj;
+                            put_da(sm, i / 3, m, jj, 4 * pc, f32x4{0.f, 0.f, 0.f, 0.f});
+                        }
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (!ablated(a.ablate, 8)) prefetch(m + DWD, bq[k]);     // (behind the last use of these registers: the loads land in place)
                 xstep_barrier(prof);
@@ -449,7 +468,8 @@ __device__ __attribute__((noinline)) void dw_role(const Lstm2BwdArgs &a_in, cons
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (NSD_BX4_DW_SLEEP) __builtin_amdgcn_s_sleep(NSD_BX4_DW_SLEEP);
-                if (m0 >= 4 && k < NN) part(w, k);
+                if (!NSD_BX4_CONV) { if (m0 >= 4 && k < NN) part(w, k); }
+                else               { if (m0 >= 4 && k >= 1 && k - 1 < NN) part(w, k - 1); }     // (the window is complete one step later)
                 xstep_barrier(prof);
             }
         }
