@@ -57,6 +57,9 @@ constexpr int BRS = 96;             // ... of the row windows: layer 1 {h1[t-1] 
 struct DwWin {
     unsigned short wa[2][2][2][WK][ARS];
     unsigned short wb[2][2][2][WK][BRS];
+    // per-step factors of the cells, prepared one step ahead by the loader wave (see prep below): [macro step & 1][layer][unit]
+    // {d c_t / d h_t, f_t, gradient from above (layer 1) or dropout multiplier (layer 0), -, i'g, c[t-1] f', i g', tanh(c_t) o'}
+    float pf[2][2][H][8];
 };
 struct NoWin {};
 template <int NB>
@@ -115,6 +118,38 @@ __device__ __forceinline__ void load_wT(const float *w, const int og, const int 
         }
 }
 
+// One trial per workgroup: the per-step factors of one layer's cells for macro step mn, from the staged records -- what every gate
+// lane of the recurrences used to form for itself, once per unit and one step ahead (by x1 waves 0 / 1 for layer 1 / 0; by the loader
+// wave for a trial's first step).  c_t is the c[t-1] field of the record one macro step earlier (c[T-1], `cT1`, at the first step).
+struct PrepIn { float4 gc; float cprev, ct, mk; float2 ad; };
+__device__ __forceinline__ PrepIn prep_load(const Lstm2BwdArgs &a, Smem<1> &sm, const int mn, const int layer, const int u, const float cT1) {
+    const int T = a.T;
+    const int t = layer == 1 ? T - 1 - mn : T + 1 - mn;
+    const float *rec = &sm.stage[(mn >> 3) & 1][0][layer][mn & 7][0];
+    const float *recp = &sm.stage[((mn - 1) >> 3) & 1][0][layer][(mn - 1) & 7][0];
+    PrepIn in;
+    in.gc = *reinterpret_cast<const float4 *>(rec + 4 * u);
+    in.cprev = t > 0 ? rec[192 + u] : 0.f;
+    in.ct = t == T - 1 ? cT1 : recp[192 + u];
+    in.ad = make_float2(0.f, 0.f); in.mk = 1.f;
+    if (layer == 1) in.ad = *reinterpret_cast<const float2 *>(rec + 240);
+    else if (a.mask || a.rng.on) in.mk = rec[240 + u];
+    return in;
+}
+__device__ __forceinline__ void prep_finish(Smem<1> &sm, const PrepIn &in, const int mn, const int layer, const int u, const float dpu, const float awu) {
+    const float ig = in.gc.x, fg = in.gc.y, gg = in.gc.z, og = in.gc.w;
+    const float tc = fast_tanh(in.ct);
+    const float x = layer == 1 ? fmaf(in.ad.x, dpu, in.ad.y * awu) : in.mk;
+    float *o = &sm.win.pf[mn & 1][layer][u][0];
+    *reinterpret_cast<float4 *>(o) = make_float4(og * (1.f - tc * tc), fg, x, 0.f);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(gg * (ig * (1.f - ig)), in.cprev * (fg * (1.f - fg)), ig * (1.f - gg * gg), tc * (og * (1.f - og)));
+}
+__device__ __forceinline__ void prep_layer(const Lstm2BwdArgs &a, Smem<1> &sm, const int mn, const int layer, const int u,
+                                           const float dpu, const float awu, const float cT1) {
+    const PrepIn in = prep_load(a, sm, mn, layer, u, cT1);
+    prep_finish(sm, in, mn, layer, u, dpu, awu);
+}
+
 template <int NB>
 __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, const int layer, const int r,
                                            const int n_steps) {
@@ -137,8 +172,8 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
         for (int n = 0; n < NB; ++n) {
             const int b = b0 + n;
             dc[n] = 0.f; dhrec[n] = 0.f;
-            dpj[n] = (layer == 1 && b < B) ? a.dpooled[(size_t)b * H + j] : 0.f;
-            ct[n] = (b < B) ? cseq[((size_t)b * T + (T - 1)) * H + j] : 0.f;   // c[T-1] of the first step
+            dpj[n] = (NB == 2 && layer == 1 && b < B) ? a.dpooled[(size_t)b * H + j] : 0.f;
+            ct[n] = (NB == 2 && b < B) ? cseq[((size_t)b * T + (T - 1)) * H + j] : 0.f;   // c[T-1] of the first step
         }
         step_barrier<false>(prof);      // chunk 0 of the stage has been written by the loader wave
 
@@ -151,6 +186,24 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
                 const int t = layer == 1 ? (T - 1 - m) : (T + 1 - m);
                 const bool active = (t >= 0 && t < T);
                 const bool prev_active = (t + 1 >= 0 && t + 1 < T);
+                if constexpr (NB == 1) {
+                    // One trial per workgroup: everything that does not depend on the recurrence comes READY from the loader wave's
+                    // prep of the previous step (two LDS reads instead of six and ~20 instructions less per step in the six waves whose
+                    // instruction streams ARE the step: the same factors as below, formed once per unit instead of once per gate lane)
+                    const float *pfl = &sm.win.pf[k & 1][layer][j][0];
+                    const float4 pf = *reinterpret_cast<const float4 *>(pfl);
+                    const float qr = pfl[4 + s];
+                    const float dout = layer == 1 ? pf.z : sm.din1[(k + 1) & 1][0][j] * pf.z;
+                    if (prev_active) dhrec[0] = slice_dot_t(&sm.ring[layer][(k + RING - 1) & (RING - 1)][0][12 * kk], wp);
+                    if (active) {
+                        const float dht = dout + dhrec[0];
+                        const float dct = fmaf(dht, pf.x, dc[0]);
+                        const float mine = (s == 3 ? dht : dct) * qr;
+                        dc[0] = dct * pf.y;
+                        db += mine;
+                        sm.ring[layer][k][0][s * H + j] = mine;
+                    }
+                } else
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     // ---- everything that does not depend on the recurrence: the step's record from the LDS stage, the
@@ -218,6 +271,14 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
         float dpj[NB];
 #pragma unroll
         for (int n = 0; n < NB; ++n) dpj[n] = (a.residual && b0 + n < B) ? a.dpooled[(size_t)(b0 + n) * H + j] : 0.f;
+        // prep duty (one trial per workgroup): wave 0 of the role prepares layer 1's factors of the NEXT macro step, wave 1 layer 0's
+        const int pw = r >> 6, pu = (r & 63) < H ? (r & 63) : (r & 63) - 16, pl = pw == 0 ? 1 : 0;
+        float p_dp = 0.f, p_aw = 0.f, p_c = 0.f;
+        if (NB == 1 && pw < 2) {
+            p_dp = a.dpooled[(size_t)b0 * H + pu];
+            p_aw = a.attn_w[pu];
+            p_c = (pl == 1 ? a.cseq1 : a.cseq0)[((size_t)b0 * T + (T - 1)) * H + pu];
+        }
         step_barrier<false>(prof);
 
         for (int m0 = 0; m0 < n_steps; m0 += CHUNK) {
@@ -233,8 +294,14 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
                 for (int n = 0; n < NB; ++n) {
                     float2 xv = {0.f, 0.f};
                     if (NB == 2) xv = *reinterpret_cast<const float2 *>(&sm.xst[sb][n][k][2 * s]);
+                    PrepIn pin;
+                    if constexpr (NB == 1) { if (pw < 2) pin = prep_load(a, sm, m + 1, pl, pu, p_c); }      // (requested ahead of the mat-vec: its latency hides there)
                     if (t1p >= 0 && t1p < T) {
+#ifdef NSD_B48_X1ABL
+                        float inp = sm.ring[1][e][n][r];
+#else
                         float inp = slice_dot_t(&sm.ring[1][e][n][12 * kk], wp);
+#endif
                         if (a.residual && b0 + n < B) {
                             // dout1[t1p] = alpha*dpooled + dscore*attn_w: the scalars sit in the record of macro step m-1
                             // (for k == 0 that is step 7 of the other stage buffer)
@@ -243,6 +310,7 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
                         }
                         if (s == 0) sm.din1[k & 1][n][j] = inp;
                     }
+                    if constexpr (NB == 1) { if (pw < 2) prep_finish(sm, pin, m + 1, pl, pu, p_dp, p_aw); }
                     if (NB == 2 && t0p >= 0 && t0p < T && b0 + n < B) {       // (one trial per workgroup: dW_ih0 rides in the dW waves' layer-0 window)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -675,15 +743,43 @@ __device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm,
     loader_decode<NB>(a, lane, d);
     Prof prof = prof_init(a.dbg);
     const int ngrp = (a.B + NB - 1) / NB;
+    const int T = a.T;
+    const int u = lane < H ? lane : lane - 16;                      // prep of a trial's first step: this lane's unit (lanes 48..63 repeat units 32..47)
     for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
         const int b0 = grp * NB;
+        float dpu = 0.f, awu = 0.f, cT1[2] = {0.f, 0.f};
+        if constexpr (NB == 1) {                                    // (ordinary loads only in front of the trial's first DMA)
+            dpu = a.dpooled[(size_t)b0 * H + u];
+            awu = a.attn_w[u];
+            cT1[1] = a.cseq1[((size_t)b0 * T + (T - 1)) * H + u];
+            cT1[0] = a.cseq0[((size_t)b0 * T + (T - 1)) * H + u];
+        }
         loader_issue<NB, 0, NQ>(a, sm, d, 0, 0, b0);
         if (NB == 2) loader_issue_x<NB>(a, sm, 0, 0, b0, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NB == 1) { prep_layer(a, sm, 0, 1, u, dpu, awu, cT1[1]); prep_layer(a, sm, 0, 0, u, dpu, awu, cT1[0]); }
         step_barrier<true>(prof);
         for (int m0 = 0; m0 < n_steps; m0 += CHUNK) {
             const int chunk = m0 / CHUNK, nb = (chunk + 1) & 1;
             const bool on = !ablated(a.ablate, 16);
+            if constexpr (NB == 1) {
+                // next chunk: 4 pieces per step during steps 0..4; all landed before step 6 ends -- the x1 waves prepare the factors of the
+                // chunk's first step during step 7
+                if (on) loader_issue<NB, 0, 4>(a, sm, d, chunk + 1, nb, b0);
+                step_barrier<true, LD_SLEEP>(prof);
+                if (on) loader_issue<NB, 4, 8>(a, sm, d, chunk + 1, nb, b0);
+                step_barrier<true, LD_SLEEP>(prof);
+                if (on) loader_issue<NB, 8, 12>(a, sm, d, chunk + 1, nb, b0);
+                step_barrier<true, LD_SLEEP>(prof);
+                if (on) loader_issue<NB, 12, 16>(a, sm, d, chunk + 1, nb, b0);
+                step_barrier<true, LD_SLEEP>(prof);
+                if (on) loader_issue<NB, 16, 18>(a, sm, d, chunk + 1, nb, b0);
+                step_barrier<true, LD_SLEEP>(prof);
+                step_barrier<true, LD_SLEEP>(prof);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                step_barrier<true, LD_SLEEP>(prof);
+                step_barrier<true, LD_SLEEP>(prof);
+            } else {
             // next chunk: 3 pieces per step during steps 0..5 (+ x rows at step 0); all landed before step 7 ends
             if (on) { loader_issue<NB, 0, 3>(a, sm, d, chunk + 1, nb, b0); if (NB == 2) loader_issue_x<NB>(a, sm, chunk + 1, nb, b0, lane); }
             step_barrier<true, LD_SLEEP>(prof);
@@ -700,6 +796,7 @@ __device__ __forceinline__ void loader_role(const Lstm2BwdArgs &a, Smem<NB> &sm,
             step_barrier<true, LD_SLEEP>(prof);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             step_barrier<true, LD_SLEEP>(prof);
+            }
         }
     }
     prof_store(a.dbg, prof);
@@ -718,20 +815,32 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     // issue priority follows the critical path: the two recurrences first, then the hand-off to layer 0
     if constexpr (NB == 1) {
 #ifndef NSD_B48_MAP
-#define NSD_B48_MAP 1
+#define NSD_B48_MAP 2
 #endif
         // Roles by SIMD (waves w and w + 4 share one; a SIMD's instructions per step are what bounds the step -- per-wave stamps:
         // the younger recurrence of a SIMD that carries two runs at 1 065 cycles of work against 840 -- so the SIMDs with TWO
         // recurrences get the four light dW waves (rows duty), the other two the x1 waves, the da converters and the loader):
         //   SIMD 0: chain1_0 chain0_1 dW0 dW2 | SIMD 1: chain1_1 chain0_2 dW1 dW3 | SIMD 2: chain1_2 x1_0 x1_2 dW5 | SIMD 3: chain0_0 x1_1 dW4 loader
+#if NSD_B48_MAP == 2
+        //   SIMD 0: chain1_0 chain0_1 x1_2 dW0 | SIMD 1: chain1_1 chain0_2 dW4 dW1 | SIMD 2: chain1_2 x1_0 dW2 dW5 | SIMD 3: chain0_0 x1_1 dW3 loader
+        constexpr int ROLE[16] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4};
+        constexpr int PART[16] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 4, 2, 3, 0, 1, 5, 0};
+#else
         constexpr int ROLE[16] = {0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 2, 3, 3, 3, 3, 4};        // 0 chain1, 1 chain0, 2 x1, 3 dW, 4 loader
         constexpr int PART[16] = {0, 1, 2, 0, 1, 2, 0, 1, 0, 1, 2, 4, 2, 3, 5, 0};
+#endif
         const int lane = tid & 63;
-        if (NSD_B48_MAP == 1) {
+        if (NSD_B48_MAP >= 1) {
             const int role = ROLE[wave], part = PART[wave];
-            if (role == 0)      { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 1, 64 * part + lane, n_steps); }
-            else if (role == 1) { __builtin_amdgcn_s_setprio(3); chain_role<NB>(a, sm, 0, 64 * part + lane, n_steps); }
-            else if (role == 2) { __builtin_amdgcn_s_setprio(2); x1_role<NB>(a, sm, 64 * part + lane, n_steps); }
+#ifndef NSD_B48_PC
+#define NSD_B48_PC 2
+#endif
+#ifndef NSD_B48_PX
+#define NSD_B48_PX 3
+#endif
+            if (role == 0)      { __builtin_amdgcn_s_setprio(NSD_B48_PC); chain_role<NB>(a, sm, 1, 64 * part + lane, n_steps); }
+            else if (role == 1) { __builtin_amdgcn_s_setprio(NSD_B48_PC); chain_role<NB>(a, sm, 0, 64 * part + lane, n_steps); }
+            else if (role == 2) { __builtin_amdgcn_s_setprio(NSD_B48_PX); x1_role<NB>(a, sm, 64 * part + lane, n_steps); }
             else if (role == 3) dw16_role(a, sm, part, lane, n_steps);
             else                { __builtin_amdgcn_s_setprio(1); loader_role<NB>(a, sm, lane, n_steps); }
             return;
