@@ -27,8 +27,13 @@
 
 namespace {
 
+#ifndef NSD_B48_X1M
+#define NSD_B48_X1M 1             // one trial per workgroup: the hand-off d_in1 = W_ih1^T da1 as v_mfma_f32_4x4x1 over FOUR steps at a time (layer 0 runs 5 macro steps behind layer 1 instead of 2)
+#endif
 constexpr int H = 48;
 constexpr int G4 = 192;
+// macro steps layer 0 runs behind layer 1, minus the 2 of the step-by-step hand-off
+constexpr int dl0(const int nb) { return (nb == 1 && NSD_B48_X1M) ? 3 : 0; }
 constexpr int RING = 8;
 constexpr int NTHREADS = 1024;
 #ifndef NSD_DW_SLEEP
@@ -60,6 +65,7 @@ struct DwWin {
     // per-step factors of the cells, prepared one step ahead by the loader wave (see prep below): [macro step & 1][layer][unit]
     // {d c_t / d h_t, f_t, gradient from above (layer 1) or dropout multiplier (layer 0), -, i'g, c[t-1] f', i g', tanh(c_t) o'}
     float pf[2][2][H][8];
+    float din1x[8][H];               // d_in1 of layer-1 macro step c at [c & 7] (the four-step hand-off)
 };
 struct NoWin {};
 template <int NB>
@@ -124,7 +130,7 @@ __device__ __forceinline__ void load_wT(const float *w, const int og, const int 
 struct PrepIn { float4 gc; float cprev, ct, mk; float2 ad; };
 __device__ __forceinline__ PrepIn prep_load(const Lstm2BwdArgs &a, Smem<1> &sm, const int mn, const int layer, const int u, const float cT1) {
     const int T = a.T;
-    const int t = layer == 1 ? T - 1 - mn : T + 1 - mn;
+    const int t = layer == 1 ? T - 1 - mn : T + 1 + dl0(1) - mn;
     const float *rec = &sm.stage[(mn >> 3) & 1][0][layer][mn & 7][0];
     const float *recp = &sm.stage[((mn - 1) >> 3) & 1][0][layer][(mn - 1) & 7][0];
     PrepIn in;
@@ -183,7 +189,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
 #pragma unroll
             for (int k = 0; k < CHUNK; ++k) {
                 const int m = m0 + k;
-                const int t = layer == 1 ? (T - 1 - m) : (T + 1 - m);
+                const int t = layer == 1 ? (T - 1 - m) : (T + 1 + dl0(NB) - m);
                 const bool active = (t >= 0 && t < T);
                 const bool prev_active = (t + 1 >= 0 && t + 1 < T);
                 if constexpr (NB == 1) {
@@ -193,7 +199,7 @@ __device__ __forceinline__ void chain_role(const Lstm2BwdArgs &a, Smem<NB> &sm, 
                     const float *pfl = &sm.win.pf[k & 1][layer][j][0];
                     const float4 pf = *reinterpret_cast<const float4 *>(pfl);
                     const float qr = pfl[4 + s];
-                    const float dout = layer == 1 ? pf.z : sm.din1[(k + 1) & 1][0][j] * pf.z;
+                    const float dout = layer == 1 ? pf.z : (NSD_B48_X1M ? sm.win.din1x[(k + 6 - dl0(NB)) & 7][j] : sm.din1[(k + 1) & 1][0][j]) * pf.z;
                     if (prev_active) dhrec[0] = slice_dot_t(&sm.ring[layer][(k + RING - 1) & (RING - 1)][0][12 * kk], wp);
                     if (active) {
                         const float dht = dout + dhrec[0];
@@ -332,6 +338,88 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
         if (c0 < C) slab[a.o_w_ih0 + (size_t)(g * H + j) * C + c0] = dWih0[g][0];
         if (c1 < C) slab[a.o_w_ih0 + (size_t)(g * H + j) * C + c1] = dWih0[g][1];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// x1 waves, one trial per workgroup: d_in1[c] = W_ih1^T da1[c] for FOUR layer-1 steps at a time on the matrix pipe -- exact fp32:
+// v_mfma_f32_4x4x1_16B_f32 with the four steps as the instruction's columns (what nsd_lstm2_bwd48x4.hip does with four trials: a wave
+// owns 16 output units and splits k over the four 16-lane rows, block (row ks, ub) = units 4 ub .. + 3 x k = 48 ks .. + 47 x 4 steps,
+// A = W^T resident in VGPRs, B = da1[k][step] straight from the ring (ONE ds_read_b128 per four MFMAs), then a reduce-scatter of the
+// four k slices over the rows with v_permlane32_swap / v_permlane16_swap).  48 MFMAs + 12 LDS reads per wave every fourth step
+// instead of 24 v_pk_fma_f32 + a 14-instruction reduction EVERY step; layer 0 runs 5 macro steps behind layer 1 instead of 2.
+// Waves 0 / 1 of the role also prepare the cells' factors of the next macro step (prep_load / prep_finish).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rows_reduce_scatter4(const f32x4 v) {
+    const u32x2v p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+    const u32x2v p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+    const float s02 = __uint_as_float(p02[0]) + __uint_as_float(p02[1]);
+    const float s13 = __uint_as_float(p13[0]) + __uint_as_float(p13[1]);
+    const u32x2v q = __builtin_amdgcn_permlane16_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ void x1m_role(const Lstm2BwdArgs &a, Smem<1> &sm, const int g, const int lane, const int n_steps) {
+    const int T = a.T, B = a.B;
+    const int ks = lane >> 4, ub = (lane >> 2) & 3, jc = lane & 3;  // MFMA operand coordinates: k slice, unit block, A: unit in block / B: step
+    float wv[H];
+#pragma unroll
+    for (int sidx = 0; sidx < H; ++sidx) wv[sidx] = a.w_ih1[(size_t)(48 * ks + sidx) * H + 16 * g + 4 * ub + jc];
+    const int uo = 16 * g + 4 * ub + ks;                            // after the reduce-scatter: this lane's unit, for step c0 + jc
+    const float awo = a.attn_w[uo];
+    // prep duty: wave 0 of the role prepares layer 1's factors of the NEXT macro step, wave 1 layer 0's
+    const int pu = lane < H ? lane : lane - 16, pl = g == 0 ? 1 : 0;
+    const float p_aw = a.attn_w[pu];
+    Prof prof = prof_init(a.dbg);
+    for (int grp = blockIdx.x; grp < B; grp += gridDim.x) {
+        const int b0 = grp;
+        const float dpo = a.residual ? a.dpooled[(size_t)b0 * H + uo] : 0.f;
+        float p_dp = 0.f, p_c = 0.f;
+        if (g < 2) {
+            p_dp = a.dpooled[(size_t)b0 * H + pu];
+            p_c = (pl == 1 ? a.cseq1 : a.cseq0)[((size_t)b0 * T + (T - 1)) * H + pu];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < H; s4 += 8)
+            asm volatile("" : "+v"(wv[s4]), "+v"(wv[s4 + 1]), "+v"(wv[s4 + 2]), "+v"(wv[s4 + 3]), "+v"(wv[s4 + 4]), "+v"(wv[s4 + 5]), "+v"(wv[s4 + 6]), "+v"(wv[s4 + 7]));
+        step_barrier<false>(prof);
+        for (int m0 = 0; m0 < n_steps; m0 += CHUNK) {
+#pragma unroll
+            for (int k = 0; k < CHUNK; ++k) {
+                const int m = m0 + k;
+                PrepIn pin;
+                if (g < 2) pin = prep_load(a, sm, m + 1, pl, pu, p_c);      // (requested ahead of the products: its latency hides there)
+                if ((k & 3) == 0 && m >= 4) {
+                    // layer-1 macro steps c0 .. c0 + 3 = m - 4 .. m - 1 (ring slots (k + 4 + j) & 7); a column past the trial's first step
+                    // (c > T - 1) holds stale da and is never used
+                    const float *vj = &sm.ring[1][(k + 4 + jc) & 7][0][48 * ks];
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+#pragma unroll
+                    for (int qb = 0; qb < 12; qb += 4) {
+                        f32x4 bq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(vj + 4 * (qb + q));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[4 * (qb + q) + 0], bq[q][0], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[4 * (qb + q) + 1], bq[q][1], acc1, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[4 * (qb + q) + 2], bq[q][2], acc2, 0, 0, 0);
+                            acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[4 * (qb + q) + 3], bq[q][3], acc3, 0, 0, 0);
+                        }
+                    }
+                    float inp = rows_reduce_scatter4((acc0 + acc1) + (acc2 + acc3));
+                    const int c = m - 4 + jc;
+                    if (a.residual) {       // dout1 = alpha * dpooled + dscore * attn_w passes through: the scalars sit in the record of macro step c
+                        const float *recp = &sm.stage[(c >> 3) & 1][0][1][c & 7][0];
+                        inp += fmaf(recp[240], dpo, recp[241] * awo);
+                    }
+                    sm.win.din1x[(k + 4 + jc) & 7][uo] = inp;
+                }
+                if (g < 2) prep_finish(sm, pin, m + 1, pl, pu, p_dp, p_aw);
+                step_barrier<false>(prof);
+            }
+        }
+    }
+    prof_store(a.dbg, prof);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -531,7 +619,7 @@ __device__ DW16_INLINE void dw16_role(const Lstm2BwdArgs &a_in, Smem<1> &sm, con
     // layer-0 dropout multipliers drawn in the kernel: one value per dW lane and chunk, a chunk ahead like the loader (as before)
     const int L = w * 64 + lane, mk_k = L / H, mk_j = L - mk_k * H;
     auto gen_mask = [&](const int chunk, const int b) {
-        const int t = T + 1 - (chunk * CHUNK + mk_k);
+        const int t = T + 1 + dl0(1) - (chunk * CHUNK + mk_k);
         if (t >= 0 && t < T)
             sm.stage[chunk & 1][0][0][mk_k][240 + mk_j] =
                 nsd_rand_u32(a.rng.seed, a.rng.base, ((uint64_t)b * T + t) * H + mk_j) < a.rng.thr_lstm ? 0.f : a.rng.keep_lstm;
@@ -567,7 +655,7 @@ __device__ DW16_INLINE void dw16_role(const Lstm2BwdArgs &a_in, Smem<1> &sm, con
         if (a.rng.on) gen_mask(0, b);
         // rows of macro steps m .. m + 3 (this lane: m + rs); out of range -> zeros (switched off at the ADDRESS)
         auto request = [&](const int m) -> f32x4 {
-            const int t = (rl == 1 ? T - 1 : T + 1) - m - rs;
+            const int t = (rl == 1 ? T - 1 : T + 1 + dl0(1)) - m - rs;
             const int tt = (w == 1 || w == 3) ? t : t - 1;
             const bool ok = t >= 0 && t < T && tt >= 0 && (w != 3 || rp < C);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -592,7 +680,7 @@ __device__ DW16_INLINE void dw16_role(const Lstm2BwdArgs &a_in, Smem<1> &sm, con
                 const int wi = (m >> 4) & 1;
                 if (w >= 4 && m >= 1) {                              // da of macro step m - 1 (written by the chains at that step)
                     const int mm = m - 1, cl = 5 - w;
-                    const int t = cl == 1 ? T - 1 - mm : T + 1 - mm;
+                    const int t = cl == 1 ? T - 1 - mm : T + 1 + dl0(1) - mm;
                     f32x4 v = *reinterpret_cast<const f32x4 *>(&sm.ring[cl][mm & (RING - 1)][0][4 * l48]);
                     if (!(t >= 0 && t < T)) v = f32x4{0.f, 0.f, 0.f, 0.f};       // (the chains do not write on inactive steps)
                     u32x2 hi, lo;
@@ -681,7 +769,7 @@ __device__ __forceinline__ void loader_decode(const Lstm2BwdArgs &a, const int l
         const int layer = e / (CHUNK * REC4);
         const int rem = e - layer * (CHUNK * REC4);
         const int k = rem / REC4, w = rem - k * REC4;
-        d[q].t0 = layer == 1 ? (T - 1 - k) : (T + 1 - k);
+        d[q].t0 = layer == 1 ? (T - 1 - k) : (T + 1 + dl0(NB) - k);
         d[q].row_bytes = 0;
         d[q].base = nullptr;
         if (w < 48) {
@@ -810,7 +898,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
     // every role runs the same number of barriers: 4 per 4-step group.  The last chain step is macro step T+1 and the x1
     // waves need T+2 (group (T+2)/4); rounded up to even because the loader walks whole 8-step chunks.  (The dW waves
     // finish the last group after the loop, on their own.)
-    const int n_groups = (((a.T + 2) / 4 + 1) + 1) & ~1;
+    const int n_groups = (((a.T + 2 + dl0(NB)) / 4 + 1) + 1) & ~1;
     const int n_steps = 4 * n_groups;
     // issue priority follows the critical path: the two recurrences first, then the hand-off to layer 0
     if constexpr (NB == 1) {
@@ -840,7 +928,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
 #endif
             if (role == 0)      { __builtin_amdgcn_s_setprio(NSD_B48_PC); chain_role<NB>(a, sm, 1, 64 * part + lane, n_steps); }
             else if (role == 1) { __builtin_amdgcn_s_setprio(NSD_B48_PC); chain_role<NB>(a, sm, 0, 64 * part + lane, n_steps); }
-            else if (role == 2) { __builtin_amdgcn_s_setprio(NSD_B48_PX); x1_role<NB>(a, sm, 64 * part + lane, n_steps); }
+            else if (role == 2) { __builtin_amdgcn_s_setprio(NSD_B48_PX); if (NSD_B48_X1M) x1m_role(a, sm, part, lane, n_steps); else x1_role<NB>(a, sm, 64 * part + lane, n_steps); }
             else if (role == 3) dw16_role(a, sm, part, lane, n_steps);
             else                { __builtin_amdgcn_s_setprio(1); loader_role<NB>(a, sm, lane, n_steps); }
             return;
