@@ -338,14 +338,18 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, preheat, extr
                 names = {fwd_key: "lstm2_fwd48x4_kernel" if x4 else "lstm2_fwd48_kernel", bwd_key: "lstm2_bwd48x4_kernel" if x4 else "lstm2_bwd48_kernel"}
                 bound = "mfma" if x4 else "fp32-valu"
                 common = ("fp32 path: arithmetic intensity ~110 FLOP/B >> ridge (~20) so the compute roof binds, not HBM; peak = 157.3 "
-                          "TFLOP/s fp32 (packed-FMA vector rate == f32 MFMA rate on gfx950); north_star's 40 % of HBM is out of reach "
-                          "for H=48 by construction (at the fp32 peak the step would still take 71 us per 256 trials = 18 % of 8 TB/s "
-                          "for its algorithmic bytes): see `hbm` for the measured HBM view; ")
-                why = common + ("four trials per workgroup: every product of a step is v_mfma_f32_4x4x1_16B_f32 (one per 8 cycles and SIMD = "
-                                "the fp32 rate), 456 per forward and 912 per backward step: the kernels are matrix-pipe-bound, the rest "
-                                "is the recurrence's serial tail per step (LDS hand-off, cell, barrier)" if x4 else
-                                "one trial per workgroup: the kernels are v_pk_fma_f32 (VALU) recurrences bound by instruction issue + "
-                                "the LDS hand-off of h per step")
+                          "TFLOP/s fp32 (packed-FMA vector rate == f32 MFMA rate on gfx950), held against the kernel's ALGORITHMIC fp32 "
+                          "FLOP; north_star's 40 % of HBM is out of reach for H=48 by construction (at the fp32 peak the step would "
+                          "still take 71 us per 256 trials = 18 % of 8 TB/s for its algorithmic bytes): see `hbm` for the measured HBM "
+                          "view; in the backward kernels the weight-gradient sums over time (47 % of their FLOP) run as split-bf16 "
+                          "products -- x = hi + lo, hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, every "
+                          "product within 3 x 2^-18 of the fp32 one -- while recurrences, hand-offs and the whole forward pass are exact "
+                          "fp32; ")
+                why = common + ("four trials per workgroup: every recurrent product is a v_mfma_f32_4x4x1_16B_f32 (one per 8 cycles and SIMD "
+                                "= the fp32 rate); a step is the recurrences' serial tail (LDS hand-off, cell, barrier) plus the matrix "
+                                "pipe's share" if x4 else
+                                "one trial per workgroup: v_pk_fma_f32 (VALU) recurrences whose per-step instruction streams are the step; "
+                                "the backward pass's layer hand-off runs as v_mfma_f32_4x4x1 over four steps at a time")
             else:
                 fwd_key, bwd_key = "scan_fwd", "scan_bwd"
                 names = dict(zip((fwd_key, bwd_key), scan_kernel_names(cfg)))
