@@ -1,24 +1,28 @@
 // nsd_lstm2_bwd48.hip -- BPTT of the two-layer H=48 LSTM, role-split workgroup (gfx950).
 //
 // Replaces autograd through self.lstm(x) (Neuro-Alpha-App/Utilities/lstm_eeg_model.py:34) for the reference
-// model shape (H=48, L=2, C<=8).  One 1024-thread workgroup (16 waves) owns NB trials and walks time
-// backwards with ONE barrier per step; the waves have different jobs so that only the true recurrence
-// is on the critical path and every register array stays small:
+// model shape (H=48, L=2, C<=8).  One 1024-thread workgroup (16 waves) owns NB trials and walks time backwards with ONE barrier per
+// step; the waves have different jobs so that only the true recurrence is on the critical path and every register array stays small.
 //
-//   waves 0-2   "chain 1"  layer-1 cell backward: dh_rec = W_hh1^T da1[t+1] (48 FMA/lane as 24 v_pk_fma_f32, weights
-//                          in VGPRs, 12 operands per lane from LDS, DPP reduction over 16 lanes) then the
-//                          element-wise cell backward for step t -> da1[t] into an LDS ring.
-//   waves 3-5   "chain 0"  the same for layer 0, two steps behind layer 1.
-//   waves 6-8   "x1"       d_in1[t] = W_ih1^T da1[t] (the gradient handed to layer 0) and dW_ih0 (K=8, VALU).
-//   wave  15    "loader" LDS-DMA stream of the saved activations, one 8-step chunk ahead (see below).
-//   waves 9-14  "dW"       weight gradients dW_hh1, dW_ih1, dW_hh0 = sum_t da[t] (x) operand[t] as
-//                          v_mfma_f32_16x16x4_f32 with K = 4 time steps per instruction: A = da tiles from
-//                          the LDS ring, B = h / input rows straight from the activations saved in HBM
-//                          (prefetched one 4-step group ahead).  The matrix pipe is otherwise idle, so
-//                          these 27 648 MAC/step cost the chain nothing.
+// ONE trial per workgroup (NB = 1: the benchmark's 256 trials on 256 CUs) -- per-wave stamps say a step is as long as the instruction
+// stream of its busiest wave, so everything that is not the recurrence has been taken out of the six recurrence waves:
+//   "chain 1" x3  layer-1 cell backward: dh_rec = W_hh1^T da1[t+1] (48 FMA/lane as 24 v_pk_fma_f32, weights in VGPRs, 12 operands per lane
+//                 from LDS, DPP reduction over 16 lanes), then FOUR operations on the cell's ready-made factors -> da1[t] into an LDS ring.
+//   "chain 0" x3  the same for layer 0, FIVE macro steps behind layer 1.
+//   "x1" x3       the hand-off d_in1 = W_ih1^T da1 for FOUR layer-1 steps at a time on the matrix pipe (v_mfma_f32_4x4x1, the steps as the
+//                 instruction's columns: exact fp32; x1m_role); waves 0 / 1 also PREPARE the next step's factors of layer 1 / 0 once per
+//                 unit from the staged records (prep_load / prep_finish: 32-byte records {dc/dh, f, gradient from above or multiplier, -,
+//                 i'g, c f', i g', tanh(c) o'}) -- what each of the four gate lanes of a unit used to form for itself.
+//   "dW" x6       weight gradients dW_hh1, dW_ih1, dW_hh0, dW_ih0 = sum_t da[t] (x) operand[t] as SPLIT-bf16 products on
+//                 v_mfma_f32_32x32x16_bf16, K = 16 macro steps per instruction (dw16_role): 180 matrix-pipe cycles per step instead of
+//                 864 for the fp32 form; waves 0..3 also bring the saved rows (four steps per request), waves 4, 5 convert da.
+//   "loader"      LDS-DMA stream of the saved activations, one 8-step chunk ahead; the factors of a trial's first step.
+//   Roles are placed by SIMD (wave & 3), priorities follow the measured critical waves (kernel body).
+// TWO trials per workgroup (NB = 2, batches of 257 .. 575 trials): the first-generation roles -- per-gate-lane factors in the chains,
+// x1 step by step on the VALU with dW_ih0, weight gradients as v_mfma_f32_16x16x4_f32 with K = 4 time steps (dw_role).
 //
-// LDS: da ring [2 layers][8 steps][NB][192] + d_in1 double buffer.  HBM traffic = saved activations read
-// once (gates, c, h, in1, x) + one slab of partial gradients per workgroup at the end.
+// LDS: da ring [2 layers][8 steps][NB][192] + staged records + (NB = 1) the bf16 operand windows, factor records and the d_in1 ring.
+// HBM traffic = saved activations read once (gates, c, h, in1, x) + one slab of partial gradients per workgroup at the end.
 #include "nsd_args.h"
 #include "nsd_prof.h"
 #include "nsd_bf16.h"
@@ -303,11 +307,7 @@ __device__ __forceinline__ void x1_role(const Lstm2BwdArgs &a, Smem<NB> &sm, con
                     PrepIn pin;
                     if constexpr (NB == 1) { if (pw < 2) pin = prep_load(a, sm, m + 1, pl, pu, p_c); }      // (requested ahead of the mat-vec: its latency hides there)
                     if (t1p >= 0 && t1p < T) {
-#ifdef NSD_B48_X1ABL
-                        float inp = sm.ring[1][e][n][r];
-#else
                         float inp = slice_dot_t(&sm.ring[1][e][n][12 * kk], wp);
-#endif
                         if (a.residual && b0 + n < B) {
                             // dout1[t1p] = alpha*dpooled + dscore*attn_w: the scalars sit in the record of macro step m-1
                             // (for k == 0 that is step 7 of the other stage buffer)
