@@ -13,20 +13,25 @@
 //     from ONE ds_read_b128 per four MFMAs; 48 MFMAs per wave and step, then a reduce-scatter of the four slices over the rows with
 //     v_permlane32_swap / v_permlane16_swap (3 swaps + 3 adds; semantics probed in tools/micro/permlane_probe.hip): lane (r, ub, j)
 //     ends up with dh of unit 4ub + r for trial j -- one cell per lane, every lane useful, the cell's backward in the lane;
-//   * the weight gradients dW[192 x 48] += da[.][trial] (x) operand[trial][.] as outer products: block (rb, cb) = 4 rows x 4 columns,
-//     A = da from LDS with CBSZ = 2 / ABID = trial (one register holds the four trials of a 16-row tile), B = the saved h / in1 / x
-//     rows from HBM with BLGP = 4 + trial (one register holds the four trials of a 16-column tile): 2 registers feed 4 MFMAs.
+//   * the weight gradients dW[192 x 48] += da[.][trial] (x) operand[trial][.] are a GEMM whose K runs over (step, trial): as 4x4x1 outer
+//     products they were half of the kernel's matrix-pipe time; they now run as SPLIT-bf16 products on v_mfma_f32_32x32x16_bf16 (x = hi
+//     + lo, hi.hi + lo.hi + hi.lo, fp32 accumulation, K = 16 = four steps x four trials; "weight gradients" below): 22.5 instructions of
+//     32 cycles per step instead of 480 of 8.
 //
 // 16 waves, role = f(SIMD g = wave & 3, slot q = wave >> 2); ONE barrier per macro step m:
-//   q 0, g 0..2  "C1"  layer-1 recurrence, t = T-1-m, units 16g..: W_hh1^T da1[t+1] -> dh -> cell backward -> da1[t] -> LDS
-//   q 1, g 0..2  "C0"  layer-0 recurrence, t = T+1-m: W_hh0^T da0[t+1] + multiplier * d_in1[t] -> da0[t] -> LDS
-//   q 2, g 0..2  "X1"  d_in1[t] = W_ih1^T da1[t], t = T-m (what layer 0 receives from layer 1); + dW_ih0 (four row tiles each)
-//   q 3, g 0..2 and g 3, q 0..2  "dW"  six waves: dW_hh1, dW_ih1, dW_hh0 (two waves each, 6 row tiles x 3 column tiles):
-//                      72 MFMAs per wave and step, B rows prefetched from HBM four steps ahead
-//   q 3, g 3     "aux" {alpha, dscore} of the layer-1 steps, the x rows and the layer-0 dropout multipliers (explicit tensor or the
+//   g 0..2, q 0  "C1"  layer-1 recurrence, t = T-1-m, units 16g..: W_hh1^T da1[t+1] -> dh -> cell backward -> da1[t] -> LDS (fp32 vector
+//                      for the products + the bf16 halves into the weight gradients' window)
+//   g 0..2, q 1  "C0"  layer-0 recurrence, t = T+1-m: W_hh0^T da0[t+1] + multiplier * d_in1[t] -> da0[t] -> LDS
+//   g 3,  q 0..2 "X1"  d_in1[t] = W_ih1^T da1[t], t = T-m (what layer 0 receives from layer 1)
+//   g 0..2, q 2  "dW"  layer 1: rows 64 g .. + 63 of {dW_hh1 | dW_ih1} (six 32 x 32 tiles);  g 0..1, q 3: layer 0, rows 96 g .. + 95 of
+//                      {dW_hh0 | dW_ih0 | -} (six tiles): one column tile of the last complete window per step
+//   g 2,  q 3  "rows"  the saved rows h1[t-1], in1[t], h0[t-1] (three 16-byte requests per lane and step, four steps ahead) and x[t]
+//                      (staged by the aux wave) -> bf16 halves -> the row windows
+//   g 3,  q 3  "aux"   {alpha, dscore} of the layer-1 steps, the x rows and the layer-0 dropout multipliers (explicit tensor or the
 //                      counter stream), one 16-step chunk ahead -> LDS; dL/dscore_t itself where the forward kernel left it open
-//   (232 / 232 / 232 / 216 MFMAs per step and SIMD.)  The saved activations of a cell (16 bytes of gates, c[t-1]) are prefetched by
-//   the lane that owns the cell, four steps ahead, with buffer loads whose time offset is scalar -- no staging through LDS.
+//   (matrix pipe per step and SIMD: 96 x 8 + ~2 x 144 cycles on SIMDs 0..2, 144 x 8 on SIMD 3.)  The saved activations of a cell (16
+//   bytes of gates, c[t-1]) are prefetched by the lane that owns the cell, two steps ahead, with buffer loads whose time offset is
+//   scalar -- no staging through LDS.
 // HBM traffic = saved activations read once + one slab of partial gradients per workgroup at the end.
 #include "nsd_args.h"
 #include "nsd_prof.h"
