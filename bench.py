@@ -72,7 +72,7 @@ CONFIGS = {
 # sources whose hash ties a recorded PMC traffic file to the kernels it was measured on
 KERNEL_SOURCES = {
     "fp32": ["nsd_lstm2_fwd48.hip", "nsd_lstm2_bwd48.hip", "nsd_lstm2_fwd48x4.hip", "nsd_lstm2_bwd48x4.hip", "nsd_lstm2.hip", "nsd_common.h", "nsd_args.h",
-             "nsd_prof.h"],
+             "nsd_prof.h", "nsd_bf16.h"],
     "bf16": ["nsd_scan.hip", "nsd_scan2.hip", "nsd_scan_common.h", "nsd_gemm_bf16.hip", "nsd_head_tm.hip", "nsd_seq.hip", "nsd_seq.h", "nsd_bf16.h",
              "nsd_common.h"],
 }
