@@ -104,7 +104,7 @@ def main():
                     roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1"] * 3 + ["dW"] * 6 + ["loader"]
                     nst = 4 * ((((T + 2) // 4 + 1) + 1) & ~1)
                     if B >= 576:                     # four trials per workgroup (nsd_lstm2_bwd48x4.hip): role = f(wave & 3, wave >> 2)
-                        roles = ["C1", "C1", "C1", "dW3", "C0", "C0", "C0", "dW4", "X1", "X1", "X1", "dW5", "dW0", "dW1", "dW2", "aux"]
+                        roles = ["C1", "C1", "C1", "X1", "C0", "C0", "C0", "X1", "dW1", "dW1", "dW1", "X1", "dW0", "dW0", "rows", "aux"]
                         nst = ((T + 3 + 15) // 16) * 16
                 torch.cuda.synchronize()
                 L.nsd_debug_profile_buffer(None)
