@@ -542,8 +542,10 @@ static int launch_bwd_h(const Lstm2BwdArgs &a, int nb, int grid, hipStream_t st)
     return 0;
 }
 
-// the backward kernels keep at most 2 trials per workgroup (register budget); larger batches loop
-static int pick_nb_bwd(int B) { const int nb = pick_nb(B); return nb > 2 ? 2 : nb; }
+// the backward kernels keep at most 2 trials per workgroup (register budget); larger batches loop.  Up to two trials per CU the
+// ONE-trial instantiation walks two trials one after the other: since round 4 it is the faster one per trial (H = 48: split-bf16 weight
+// gradients, prepared factors, four-step hand-off -- 2 x 127 us against 268-271 us of the two-trial instantiation at 320 .. 512 trials)
+static int pick_nb_bwd(int B) { const int nb = pick_nb(B); return nb > 2 ? 2 : (B <= 2 * nsd_num_cus() ? 1 : nb); }
 
 // number of workgroups (== slabs written) the backward kernel uses for batch B
 int nsd_lstm2_bwd_grid(int B) {
