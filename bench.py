@@ -53,7 +53,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-X4_MIN_B = 576                                 # csrc/nsd_lstm2.hip: batch from which the H = 48 path runs its four-trial matrix-pipe kernels
+X4_MIN_B = 513                                 # csrc/nsd_lstm2.hip: batch from which the H = 48 path runs its four-trial matrix-pipe kernels
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: fp32 vector == fp32 matrix rate; dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(8 * H) void lstm2_bwd_kernel(Lstm2BwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-constexpr int X4_MIN_B = 576;        // training batch from which the four-trial kernels are used (H = 48): tools/x4_sweep.py
+constexpr int X4_MIN_B = 513;        // training batch from which the four-trial kernels are used (H = 48): more than two trials per CU (tools/x4_sweep.py; 513 .. 575 trials are two passes of the two-trial kernels otherwise)
 
 // Which H = 48 forward instantiation a launch takes is a pure function of the launch in the product library.  The diagnostic twin
 // (libnsd_hip_diag.so: this file compiled with -DNSD_DIAG=1) can pin it -- 1 / 2 / 4 trials per workgroup, 0 = automatic -- so that

@@ -1070,7 +1070,7 @@ def test_four_trials_per_workgroup_backward_on_the_matrix_pipe(nsd, dev, ref_sta
                 assert (g2 - g4).abs().max().item() <= 2e-5 * g2.abs().max().item() + 1e-9, (kw.keys(), (g2 - g4).abs().max().item(), g2.abs().max().item())
                 if vi < 2:
                     _grad_close(g4.cpu().numpy() * 1.0, g_ref, D, rtol=3e-4)
-            # both new kernels together (what the product runs from 576 trials on), against the oracle
+            # both new kernels together (what the product runs from 513 trials on), against the oracle
             ops.force_fwd48(4)
             ops.force_bwd48(4)
             loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, xn, yn, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn)
@@ -1163,7 +1163,7 @@ def test_four_trial_kernels_other_channel_and_class_counts(nsd, dev, C, K, B, T)
 def test_four_trial_kernels_loop_over_trial_groups(nsd, dev, ref_state):
     """More trial groups than workgroups (B = 1 100 -> 275 groups of four on at most 256 workgroups): some workgroups walk two groups --
     state buffers re-zeroed, weights re-read, bias / weight-gradient sums carried across the groups -- through the PRODUCT's own
-    dispatch (no pinning: 1 100 >= the 576 trials from which the four-trial kernels are used)."""
+    dispatch (no pinning: 1 100 >= the 513 trials from which the four-trial kernels are used)."""
     from nsd_amd import ops
     B, T = 1100, 6
     flat_np = orc.flatten_state(ref_state, D)

@@ -96,14 +96,14 @@ def main():
                     # role table of lstm2_fwd48_kernel: SIMD g = wave & 3, slot q = wave >> 2
                     roles = ["L1", "L1", "L1", "P", "L0", "L0", "L0", "P", "saver", "spare", "spare", "P"]
                     nst = ((T + 2 + 31) // 32) * 32
-                    if B >= 576:                     # four trials per workgroup (nsd_lstm2_fwd48x4.hip): stage / pool helpers, 16-step chunks
+                    if B >= 513:                     # four trials per workgroup (nsd_lstm2_fwd48x4.hip): stage / pool helpers, 16-step chunks
                         roles = ["L1", "L1", "L1", "P", "L0", "L0", "L0", "P", "stage", "idle", "idle", "P"]
                         nst = ((T + 2 + 15) // 16) * 16
                 else:
                     bwd()
                     roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1"] * 3 + ["dW"] * 6 + ["loader"]
                     nst = 4 * ((((T + 2) // 4 + 1) + 1) & ~1)
-                    if B >= 576:                     # four trials per workgroup (nsd_lstm2_bwd48x4.hip): role = f(wave & 3, wave >> 2)
+                    if B >= 513:                     # four trials per workgroup (nsd_lstm2_bwd48x4.hip): role = f(wave & 3, wave >> 2)
                         roles = ["C1", "C1", "C1", "X1", "C0", "C0", "C0", "X1", "dW1", "dW1", "dW1", "X1", "dW0", "dW0", "rows", "aux"]
                         nst = ((T + 3 + 15) // 16) * 16
                 torch.cuda.synchronize()
