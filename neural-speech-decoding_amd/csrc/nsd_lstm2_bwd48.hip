@@ -944,6 +944,9 @@ __global__ __launch_bounds__(NTHREADS) void lstm2_bwd48_kernel(Lstm2BwdArgs a) {
 }  // namespace
 
 int nsd_lstm2_bwd48_launch(const Lstm2BwdArgs &a, int nb, int grid, hipStream_t st) {
+    // the one-trial instantiation's dW waves address the saved rows through buffer descriptors with 32-bit offsets (0x80000000 = "switched
+    // off"): a batch whose [B][T][H] arrays reach 2 GB takes the two-trial instantiation (64-bit addresses; any grid)
+    if (nb == 1 && (long)a.B * a.T * H * 4 >= 0x7fffffffL) nb = 2;
     switch (nb) {
     case 1: hipLaunchKernelGGL((lstm2_bwd48_kernel<1>), dim3(grid), dim3(NTHREADS), 0, st, a); break;
     case 2: hipLaunchKernelGGL((lstm2_bwd48_kernel<2>), dim3(grid), dim3(NTHREADS), 0, st, a); break;
