@@ -101,7 +101,7 @@ def main():
                         nst = ((T + 2 + 15) // 16) * 16
                 else:
                     bwd()
-                    roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1"] * 3 + ["dW"] * 6 + ["loader"]
+                    roles = ["chain1"] * 3 + ["chain0"] * 3 + ["x1+p1", "x1+p0", "x1", "dW4+cv", "dW2", "dW3", "dW0", "dW1", "dW5+cv", "loader"]   # one trial per workgroup: role map of lstm2_bwd48_kernel<1> (p: prepares a layer's factors, cv: converts a layer's da)
                     nst = 4 * ((((T + 2) // 4 + 1) + 1) & ~1)
                     if B >= 513:                     # four trials per workgroup (nsd_lstm2_bwd48x4.hip): role = f(wave & 3, wave >> 2)
                         roles = ["C1", "C1", "C1", "X1", "C0", "C0", "C0", "X1", "dW1", "dW1", "dW1", "X1", "dW0", "dW0", "rows", "aux"]
