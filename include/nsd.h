@@ -179,8 +179,10 @@ int nsd_lstm_bwd_rng(const nsd_dims *d, const float *params, const float *x, con
 
 /*
  * Stacked LSTM backward (BPTT) through lstm_eeg_model.py:34 with the activations kept by nsd_lstm_fwd.
- * Partial gradients go to the slabs.  dx (gradient w.r.t. the EEG window) is reserved: it MUST be NULL -- the
- * parameter gradients are the whole product of this path; a non-NULL dx returns NSD_E_INVALID and launches nothing.
+ * Partial gradients go to the slabs.  dx (optional, may be NULL): dL/dx [B,T,C], what autograd through self.lstm(x)
+ * (lstm_eeg_model.py:34) returns for the EEG window -- formed as da0 . W_ih0 behind the backward pass, for H = 48 (L = 2, C <= 8; the
+ * one-trial kernel then runs whatever the batch and leaves da0 IN PLACE of layer 0's saved gates: one backward per forward) and on the
+ * shape-generic path; on the other paths a non-NULL dx returns NSD_E_INVALID and launches nothing.  The parameter gradients never need it.
  */
 int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm,
                  uint32_t flags, float *workspace, int64_t workspace_bytes, float *dx, void *stream);

@@ -424,7 +424,10 @@ static int lstm_bwd_impl(const nsd_dims *d, const float *params, const float *x,
                          uint32_t flags, float *workspace, int64_t workspace_bytes, float *dx, void *stream) {
     if (nsd_check_dims(d) != NSD_OK) return NSD_E_INVALID;
     if (!params || !x || !workspace) { nsd_set_error("lstm_bwd: null pointer"); return NSD_E_INVALID; }
-    if (dx) { nsd_set_error("lstm_bwd: dx is reserved and must be NULL (include/nsd.h)"); return NSD_E_INVALID; }
+    // dx = dL/dx [B,T,C] (optional): H = 48 (the one-trial kernel leaves da0 in place of layer 0's saved gates: ONE backward per forward
+    // then) and the generic path (its da_seq holds layer 0 last); the other paths do not form it
+    const bool dx_ok = (fast_path_ok(d) && d->H == 48) || (!fast_path_ok(d) && !nsd_lstm_batched_ok(d, true));
+    if (dx && !dx_ok) { nsd_set_error("lstm_bwd: dx is available for H = 48 (L = 2, C <= 8) and on the generic path only (include/nsd.h)"); return NSD_E_INVALID; }
     nsd_ws_layout w;
     if (const int rc = check_ws(d, workspace, workspace_bytes, "lstm_bwd", &w)) return rc;
     if (d->B == 0) return NSD_OK;
@@ -436,11 +439,13 @@ static int lstm_bwd_impl(const nsd_dims *d, const float *params, const float *x,
                                     workspace + w.dscore, workspace + w.dpooled, workspace + w.da_seq, workspace + w.din,
                                     workspace + w.din + BTH, workspace + w.din + 2 * BTH, workspace + w.slabs,
                                     (flags & NSD_FLAG_BF16) != 0, (hipStream_t)stream);
-    if (!fast_path_ok(d))
-        return nsd_lstm_generic_bwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
+    if (!fast_path_ok(d)) {
+        if (const int rc = nsd_lstm_generic_bwd(d, pl, params, x, drop_lstm, (flags & NSD_FLAG_RESIDUAL) ? 1 : 0, workspace + w.hseq,
                                     workspace + w.cseq, workspace + w.gact, workspace + w.inseq, workspace + w.alpha,
                                     workspace + w.dscore, workspace + w.dpooled, workspace + w.da_seq, workspace + w.din,
-                                    workspace + w.din + BTH, workspace + w.slabs, (hipStream_t)stream);
+                                    workspace + w.din + BTH, workspace + w.slabs, (hipStream_t)stream)) return rc;
+        return dx ? nsd_dx_launch(workspace + w.da_seq, params + pl.w_ih[0], dx, (long)d->B * d->T, 4 * d->H, d->C, (hipStream_t)stream) : NSD_OK;
+    }
     Lstm2BwdArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x;
@@ -467,7 +472,9 @@ static int lstm_bwd_impl(const nsd_dims *d, const float *params, const float *x,
     a.residual = (flags & NSD_FLAG_RESIDUAL) ? 1 : 0;
     a.ablate = ablate_mask();
     if (rng) a.rng = *rng;
-    return nsd_lstm2_bwd_launch(a, d->H, (hipStream_t)stream);
+    if (dx) a.da0_out = workspace + w.gact;                         // (in place of layer 0's saved gates, 4H floats per step: see Lstm2BwdArgs)
+    if (const int rc = nsd_lstm2_bwd_launch(a, d->H, (hipStream_t)stream)) return rc;
+    return dx ? nsd_dx_launch(a.da0_out, params + pl.w_ih[0], dx, (long)d->B * d->T, 4 * d->H, d->C, (hipStream_t)stream) : NSD_OK;
 }
 
 int nsd_lstm_bwd(const nsd_dims *d, const float *params, const float *x, const float *drop_lstm, uint32_t flags,

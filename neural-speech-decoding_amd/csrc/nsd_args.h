@@ -44,6 +44,9 @@ struct Lstm2BwdArgs {
                                              // d attn.weight / d attn.bias of the trial to its head slab
     const float *pooled;                     // [B,H] (open records only)
     float *dscore_out;                       // [B,T]
+    float *da0_out;                          // null, or [B,T,4H]: the layer-0 pre-activation gradients da0[b][t][gate * H + unit] for the input
+                                             // gradient dx = da0 . W_ih0 (lstm2_bwd48_kernel<1> only; may alias gact0: a step's saved gates
+                                             // have been staged a chunk earlier)
     float *hslabs;                           // per-trial head-gradient slabs (stride Ph), offsets of attn.weight / attn.bias in them
     long Ph, o_attn_w, o_attn_b;
     float *slabs;
@@ -118,4 +121,6 @@ int nsd_adam_dev_launch(long n, float *p, const float *g, float *m, float *v, fl
 int nsd_step_inc_launch(long long *step_dev, hipStream_t st);
 int nsd_rrelu_noise_launch(uint64_t seed, uint32_t stream_id, long n, float *out, hipStream_t st);
 int nsd_loss_sum_launch(const float *loss, int B, float *out, hipStream_t st);
+// dx[r][c] = sum_k da0[r][k] * w_ih0[k][c]: r = (trial, step), k = gate * H + unit (nn.LSTM weight_ih_l0 is [4H][C] row-major)
+int nsd_dx_launch(const float *da0, const float *w_ih0, float *dx, long rows, int G4, int C, hipStream_t st);
 

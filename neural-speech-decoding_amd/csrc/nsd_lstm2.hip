@@ -602,6 +602,7 @@ int nsd_lstm2_bwd_launch(const Lstm2BwdArgs &a, int H, hipStream_t st) {
     case 48: {   // role-split kernels: four trials per workgroup on the matrix pipe (nsd_lstm2_bwd48x4.hip) from X4_MIN_B trials on, else
                  // one / two trials per workgroup (nsd_lstm2_bwd48.hip).  Same grid either way: the workspace holds one slab per workgroup.
         const int force_nb = nsd_diag_forced_bwd48();
+        if (a.da0_out) return nsd_lstm2_bwd48_launch(a, 1, grid, st);      // input gradient requested: the one-trial kernel writes da0 (any batch: it loops)
         if (nsd_lstm2_bwd48x4_ok(a) && (force_nb ? force_nb == 4 : a.B >= X4_MIN_B)) return nsd_lstm2_bwd48x4_launch(a, grid, st);
         return nsd_lstm2_bwd48_launch(a, nb, grid, st);
     }

@@ -683,6 +683,9 @@ __device__ DW16_INLINE void dw16_role(const Lstm2BwdArgs &a_in, Smem<1> &sm, con
                     const int t = cl == 1 ? T - 1 - mm : T + 1 + dl0(1) - mm;
                     f32x4 v = *reinterpret_cast<const f32x4 *>(&sm.ring[cl][mm & (RING - 1)][0][4 * l48]);
                     if (!(t >= 0 && t < T)) v = f32x4{0.f, 0.f, 0.f, 0.f};       // (the chains do not write on inactive steps)
+                    // the input gradient's operand (nsd_lstm_bwd with dx): da0 of the step leaves as it is, 768 bytes per step
+                    if (cl == 0 && a.da0_out && t >= 0 && t < T && lane < H)
+                        *reinterpret_cast<f32x4 *>(a.da0_out + ((size_t)b * T + t) * G4 + 4 * lane) = v;
                     u32x2 hi, lo;
                     split4_bf16(v, hi, lo);
                     *reinterpret_cast<u32x2 *>(&win.wa[cl][0][(mm >> 4) & 1][mm & 15][4 * l48]) = hi;
@@ -947,6 +950,7 @@ int nsd_lstm2_bwd48_launch(const Lstm2BwdArgs &a, int nb, int grid, hipStream_t 
     // the one-trial instantiation's dW waves address the saved rows through buffer descriptors with 32-bit offsets (0x80000000 = "switched
     // off"): a batch whose [B][T][H] arrays reach 2 GB takes the two-trial instantiation (64-bit addresses; any grid)
     if (nb == 1 && (long)a.B * a.T * H * 4 >= 0x7fffffffL) nb = 2;
+    if (a.da0_out && nb != 1) { nsd_set_error("lstm2_bwd48: the input gradient needs the one-trial instantiation (B * T * H * 4 < 2 GB)"); return NSD_E_INVALID; }
     switch (nb) {
     case 1: hipLaunchKernelGGL((lstm2_bwd48_kernel<1>), dim3(grid), dim3(NTHREADS), 0, st, a); break;
     case 2: hipLaunchKernelGGL((lstm2_bwd48_kernel<2>), dim3(grid), dim3(NTHREADS), 0, st, a); break;

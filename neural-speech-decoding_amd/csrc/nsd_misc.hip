@@ -292,6 +292,40 @@ __global__ __launch_bounds__(256) void loss_sum_kernel(const float *loss, int B,
     __syncthreads();
     if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// ------------------------------------------------------------------------------------------------
+// Input gradient of the stack: dL/dx[b][t][c] = sum_k da0[b][t][k] W_ih0[k][c] (what autograd through self.lstm(x) returns for x,
+// lstm_eeg_model.py:34).  Off the training path (the parameter gradients do not need it): a plain kernel, one wave per 64 rows,
+// the weight matrix staged in LDS, each lane one row x all channels.
+// ------------------------------------------------------------------------------------------------
+constexpr int DX_CMAX = 64;
+__global__ __launch_bounds__(256) void dx_kernel(const float *da0, const float *w_ih0, float *dx, long rows, int G4, int C) {
+    extern __shared__ __align__(16) float wl[];                    // [G4][C]
+    for (int e = threadIdx.x; e < G4 * C; e += 256) wl[e] = w_ih0[e];
+    __syncthreads();
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float *dr = da0 + r * G4;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int k = 0; k < G4; ++k) {
+            const float v = dr[k];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (c0 + i < C) acc[i] = fmaf(v, wl[k * C + c0 + i], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (c0 + i < C) dx[r * C + c0 + i] = acc[i];
+    }
+}
+int nsd_dx_launch(const float *da0, const float *w_ih0, float *dx, long rows, int G4, int C, hipStream_t st) {
+    if (rows <= 0) return NSD_OK;
+    if (C > DX_CMAX || (long)G4 * C * 4 > 160 * 1024) { nsd_set_error("dx: C = %d, 4H = %d outside the kernel's domain", C, G4); return NSD_E_INVALID; }
+    hipLaunchKernelGGL(dx_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), (size_t)G4 * C * 4, st, da0, w_ih0, dx, rows, G4, C);
+    NSD_CHECK_LAUNCH("dx");
+    return NSD_OK;
+}
+
 int nsd_loss_sum_launch(const float *loss, int B, float *out, hipStream_t st) {
     hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(256), 0, st, loss, B, out);
     NSD_CHECK_LAUNCH("loss_sum");

@@ -69,12 +69,19 @@ class _EEGFunction(torch.autograd.Function):
         spec = module.spec
         x, logits = ctx.saved_tensors
         drop_lstm, rrelu_slope, drop_head = ctx.masks
+        # the gradient w.r.t. the EEG window, where somebody asked for it (x.requires_grad): what autograd through self.lstm(x)
+        # (lstm_eeg_model.py:34) gives the reference's users; the kernels form it for H = 48 and on the generic path
+        if getattr(ctx, "gates_consumed", False):
+            raise NsdError("backward a second time after one that returned the input gradient: the H = 48 kernel forms dx in place of "
+                           "layer 0's saved gates -- run the forward pass again")
+        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        ctx.gates_consumed = dx is not None and spec.H == 48
         g = ops.train_backward(spec, module._flat, x, ctx.ws, logits, dlogits=dlogits.contiguous().float(),
                                drop_lstm=drop_lstm, rrelu_slope=rrelu_slope, drop_head=drop_head,
-                               residual=module.residual)
+                               residual=module.residual, dx=dx)
         offs, shapes = spec.offsets(), spec.shapes()
         grads = tuple(g[offs[n]:offs[n] + math.prod(shapes[n])].view(shapes[n]) for n in spec.names())
-        return (None, None, None) + grads          # (ctx.ws lives as long as the graph does: retain_graph may come back)
+        return (None, dx, None) + grads            # (ctx.ws lives as long as the graph does: retain_graph may come back)
 
 
 class _EEGSeqFunction(torch.autograd.Function):

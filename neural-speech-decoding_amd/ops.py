@@ -261,9 +261,11 @@ def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: tor
                    dlogits: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
                    scale: Optional[float] = None, drop_lstm=None, rrelu_slope=None, drop_head=None,
                    residual: bool = False, grads: Optional[torch.Tensor] = None,
-                   accumulate: bool = False) -> torch.Tensor:
+                   accumulate: bool = False, dx: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Backward through head + LSTM; returns the flat gradient vector (same layout as the parameters).
-    Give either dlogits [B,K], or int32 labels [B] (+ scale, default 1/B) for fused mean cross-entropy."""
+    Give either dlogits [B,K], or int32 labels [B] (+ scale, default 1/B) for fused mean cross-entropy.
+    `dx` [B,T,C] (optional output): the gradient w.r.t. the EEG window (H = 48 and the generic path; it consumes layer 0's saved gates
+    on the H = 48 path: no second backward on the same forward then)."""
     B, T, _ = x.shape
     d = spec.dims(B, T)
     L = _lib.lib()
@@ -281,7 +283,8 @@ def train_backward(spec: ModelSpec, flat: torch.Tensor, x: torch.Tensor, ws: tor
     wsp, wsn = _dev_f32(ws, "workspace"), _nbytes(ws)
     _call("nsd_head_bwd", x.device, C.byref(d), pp, _dev_f32(rrelu_slope, "rrelu_slope"), _dev_f32(drop_head, "drop_head"),
           _dev_f32(logits, "logits", (B, spec.K)), _dev_f32(dlogits, "dlogits", (B, spec.K)), lab_ptr, scale, wsp, wsn, STREAM)
-    _call("nsd_lstm_bwd", x.device, C.byref(d), pp, _dev_f32(x, "x"), _dev_f32(drop_lstm, "drop_lstm"), flags, wsp, wsn, None, STREAM)
+    _call("nsd_lstm_bwd", x.device, C.byref(d), pp, _dev_f32(x, "x"), _dev_f32(drop_lstm, "drop_lstm"), flags, wsp, wsn,
+          _dev_f32(dx, "dx", tuple(x.shape)) if dx is not None else None, STREAM)
     if grads is None:
         grads = torch.empty(spec.param_count, dtype=torch.float32, device=x.device)
         accumulate = False

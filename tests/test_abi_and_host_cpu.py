@@ -130,9 +130,11 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     rng = _lib.Rng(1, 4, 0.6, 0.6)
     assert L.nsd_lstm_head_train_rng(C.byref(d), fake, fake, C.byref(rng), fake, 1.0, 2, fake, need - 4, fake, None) == E_WS
     assert L.nsd_lstm_bwd_rng(C.byref(d), fake, fake, C.byref(rng), 2, fake, need - 4, None) == E_WS
-    # dx is reserved: header and implementation agree that it must be NULL
-    assert L.nsd_lstm_bwd(C.byref(d), fake, fake, None, 2, fake, need, fake, None) == -1
-    assert b"must be NULL" in L.nsd_last_error()
+    # dx is formed for H = 48 and on the generic path; elsewhere a non-NULL dx is refused before anything is launched
+    d64 = _lib.Dims(4, 10, 8, 64, 2, 3, 32)
+    need64 = L.nsd_workspace_bytes(C.byref(d64), None)
+    assert L.nsd_lstm_bwd(C.byref(d64), fake, fake, None, 2, fake, need64, fake, None) == -1
+    assert b"dx is available for H = 48" in L.nsd_last_error()
 
 
 def test_facade_surface_matches_reference(ref_state):

@@ -1204,3 +1204,51 @@ def test_split_bf16_weight_gradients_stay_within_their_bound(nsd, dev, ref_state
             worst[k] = float(np.abs(got[k] - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-12))
     print("split-bf16 weight gradients, max error / max element:", {k: f"{v:.2e}" for k, v in worst.items()})
     assert max(worst.values()) <= 2e-5, worst
+
+
+@pytest.mark.parametrize("B,T,H", [(5, 33, 48), (32, 250, 48), (300, 20, 48), (1030, 9, 48), (6, 17, 40)])
+def test_input_gradient_matches_torch_autograd(nsd, dev, ref_state, B, T, H):
+    """dL/dx of `EEG_LSTM.forward` (what autograd through self.lstm(x), lstm_eeg_model.py:34, returns for the EEG window): requested
+    through the module (x.requires_grad), formed by the kernels as da0 . W_ih0 -- for H = 48 by the one-trial backward kernel whatever
+    the batch (one trial per workgroup, two passes, more than four per CU), for another H on the shape-generic path -- and held to the
+    gradient that stock PyTorch computes on the CPU for the reference module's structure with the same state_dict (eval mode: no
+    random streams), 2e-4 of the largest element; the parameter gradients of the same backward call are checked alongside."""
+    from oracle.torch_ref import StackedTorchEEG
+    torch.manual_seed(100 + B)
+    ref = StackedTorchEEG(C=8, H=H, L=2, K=3).eval()
+    if H == 48:
+        ref.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref_state.items()}, strict=True)
+    state = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    m = _model(nsd, dev, state).eval()
+    xn, yn = synth_x(B, T, seed=B + T), synth_labels(B, seed=B + T).astype(np.int64)
+    xr = torch.from_numpy(xn).requires_grad_(True)
+    torch.nn.functional.cross_entropy(ref(xr), torch.from_numpy(yn)).backward()
+    xg = _t(xn, dev).requires_grad_(True)
+    torch.nn.functional.cross_entropy(m(xg), _t(yn, dev)).backward()
+    assert xg.grad is not None and tuple(xg.grad.shape) == (B, T, 8) and torch.isfinite(xg.grad).all()
+    err = (xg.grad.cpu() - xr.grad).abs().max().item()
+    scale = xr.grad.abs().max().item()
+    print(f"dx B={B} T={T} H={H}: max error {err:.3e}, largest element {scale:.3e}")
+    assert err <= 2e-4 * scale + 1e-9, (err, scale)
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        tol = 3e-4 * max(q.grad.abs().max().item(), 1e-6) + 2e-6
+        assert (p.grad.cpu() - q.grad).abs().max().item() <= tol, k
+
+
+def test_second_backward_after_an_input_gradient_is_refused(nsd, dev, ref_state):
+    """The H = 48 kernel forms dx in place of layer 0's saved gates: a graph that returned dx cannot be walked again (it says so);
+    without dx (the training case) retain_graph keeps working and gives the same parameter gradients twice."""
+    m = _model(nsd, dev, ref_state).eval()
+    x = _t(synth_x(4, 20), dev)
+    out = m(x).sum()
+    out.backward(retain_graph=True)
+    g1 = [p.grad.clone() for p in m.parameters()]
+    for p in m.parameters():
+        p.grad = None
+    out.backward()
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, m.parameters()))
+    xg = x.clone().requires_grad_(True)
+    out = m(xg).sum()
+    out.backward(retain_graph=True)
+    with pytest.raises(nsd.NsdError, match="saved gates"):
+        out.backward()
