@@ -415,6 +415,14 @@ __device__ __forceinline__ void x1m_role(const Lstm2BwdArgs &a, Smem<1> &sm, con
                     sm.win.din1x[(k + 4 + jc) & 7][uo] = inp;
                 }
                 if (g < 2) prep_finish(sm, pin, m + 1, pl, pu, p_dp, p_aw);
+                if (g == 2 && a.da0_out && m >= 1) {
+                    // the input gradient's operand (nsd_lstm_bwd with dx): da0 of macro step m - 1 leaves as it is, 768 bytes per step, from
+                    // the one wave of the role without a prep duty (in the dW waves the test alone cost the training kernel 8 us)
+                    const int t0 = T + 2 + dl0(1) - m;
+                    if (t0 >= 0 && t0 < T && lane < H)
+                        *reinterpret_cast<f32x4 *>(a.da0_out + ((size_t)b0 * T + t0) * G4 + 4 * lane) =
+                            *reinterpret_cast<const f32x4 *>(&sm.ring[0][(k + 7) & 7][0][4 * lane]);
+                }
                 step_barrier<false>(prof);
             }
         }
@@ -683,9 +691,6 @@ __device__ DW16_INLINE void dw16_role(const Lstm2BwdArgs &a_in, Smem<1> &sm, con
                     const int t = cl == 1 ? T - 1 - mm : T + 1 + dl0(1) - mm;
                     f32x4 v = *reinterpret_cast<const f32x4 *>(&sm.ring[cl][mm & (RING - 1)][0][4 * l48]);
                     if (!(t >= 0 && t < T)) v = f32x4{0.f, 0.f, 0.f, 0.f};       // (the chains do not write on inactive steps)
-                    // the input gradient's operand (nsd_lstm_bwd with dx): da0 of the step leaves as it is, 768 bytes per step
-                    if (cl == 0 && a.da0_out && t >= 0 && t < T && lane < H)
-                        *reinterpret_cast<f32x4 *>(a.da0_out + ((size_t)b * T + t) * G4 + 4 * lane) = v;
                     u32x2 hi, lo;
                     split4_bf16(v, hi, lo);
                     *reinterpret_cast<u32x2 *>(&win.wa[cl][0][(mm >> 4) & 1][mm & 15][4 * l48]) = hi;
