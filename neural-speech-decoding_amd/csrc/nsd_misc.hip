@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256) void dx_kernel(const float *da0, const float *
 }
 int nsd_dx_launch(const float *da0, const float *w_ih0, float *dx, long rows, int G4, int C, hipStream_t st) {
     if (rows <= 0) return NSD_OK;
-    if (C > DX_CMAX || (long)G4 * C * 4 > 64 * 1024) {      // (the staged weight matrix: dynamic LDS without an opt-in attribute) nsd_set_error("dx: C = %d, 4H = %d outside the kernel's domain", C, G4); return NSD_E_INVALID; }
+    // (the staged weight matrix: dynamic LDS without an opt-in attribute)
+    if (C > DX_CMAX || (long)G4 * C * 4 > 64 * 1024) { nsd_set_error("dx: C = %d, 4H = %d outside the kernel's domain", C, G4); return NSD_E_INVALID; }
     hipLaunchKernelGGL(dx_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), (size_t)G4 * C * 4, st, da0, w_ih0, dx, rows, G4, C);
     NSD_CHECK_LAUNCH("dx");
     return NSD_OK;
