@@ -1252,3 +1252,22 @@ def test_second_backward_after_an_input_gradient_is_refused(nsd, dev, ref_state)
     out.backward(retain_graph=True)
     with pytest.raises(nsd.NsdError, match="saved gates"):
         out.backward()
+
+
+@pytest.mark.parametrize("B,T", [(256, 11), (257, 12), (300, 33), (512, 9), (513, 9), (575, 7), (1025, 5)])
+def test_batch_bands_of_the_dispatch_vs_oracle(nsd, dev, ref_state, B, T):
+    """The product's own choice of kernels around its thresholds (csrc/nsd_lstm2.hip, 256 CUs): up to 256 trials one per workgroup;
+    257 .. 512 the two-trial forward + the one-trial backward walking two trials per workgroup; from 513 on the four-trial kernels
+    (129 .. 257 trial groups, padding trials in the last one).  Train step with explicit masks against the oracle: logits 1e-4,
+    gradients 3e-4 of each tensor's largest element; the fused and the unfused head agree."""
+    flat_np = orc.flatten_state(ref_state, D)
+    xn, yn = synth_x(B, T, seed=3 * B + T), synth_labels(B, seed=3 * B + T)
+    dln, sln, dhn = counter_masks(B, T, 48, 32, seed=B + 7 * T)
+    loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, xn, yn, D, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn)
+    res = []
+    for fused in (True, False):
+        out = _hip_step(nsd, dev, flat_np, xn, yn, fused, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn)
+        assert np.abs(out["logits"] - fw["logits"]).max() < LOGIT_TOL and abs(float(out["loss"].sum()) / B - loss_ref) < 5e-5
+        _grad_close(out["grads"], g_ref, D, rtol=3e-4)
+        res.append(out["grads"])
+    assert np.abs(res[0] - res[1]).max() <= 2e-5 * np.abs(res[0]).max()
