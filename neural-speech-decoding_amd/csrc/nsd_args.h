@@ -84,6 +84,9 @@ bool nsd_lstm2_fwd48_head_train_fits(int T, int F, int K);
 // four trials per workgroup, gate products on the matrix pipe (nsd_lstm2_fwd48x4.hip): training launches of the plain stack
 bool nsd_lstm2_fwd48x4_ok(const Lstm2FwdArgs &a);
 int nsd_lstm2_fwd48x4_launch(const Lstm2FwdArgs &a, int grid, hipStream_t st);
+// EXPERIMENTAL one-wave-per-layer forward (nsd_lstm2_fwd48w.hip): diagnostic twin only (nsd_diag_force_fwd48(8))
+bool nsd_lstm2_fwd48w_ok(const Lstm2FwdArgs &a);
+int nsd_lstm2_fwd48w_launch(const Lstm2FwdArgs &a, int grid, hipStream_t st);
 bool nsd_lstm2_bwd48x4_ok(const Lstm2BwdArgs &a);
 int nsd_lstm2_bwd48x4_launch(const Lstm2BwdArgs &a, int grid, hipStream_t st);
 int nsd_lstm_generic_fwd(const nsd_dims *d, const ParamLayout &pl, const float *params, const float *x, const float *drop_lstm,

@@ -507,7 +507,7 @@ extern "C" int nsd_diag_force_bwd48(int32_t nb) {
 }
 static int nsd_diag_forced_bwd48() { return g_force_bwd48; }
 extern "C" int nsd_diag_force_fwd48(int32_t nb) {
-    if (nb != 0 && nb != 1 && nb != 2 && nb != 4) { nsd_set_error("nsd_diag_force_fwd48: 0, 1, 2 or 4"); return NSD_E_INVALID; }
+    if (nb != 0 && nb != 1 && nb != 2 && nb != 4 && nb != 8) { nsd_set_error("nsd_diag_force_fwd48: 0, 1, 2, 4 or 8 (the experimental one-wave-per-layer kernel)"); return NSD_E_INVALID; }
     g_force_fwd48 = nb;
     return NSD_OK;
 }
@@ -572,6 +572,7 @@ int nsd_lstm2_fwd_launch(const Lstm2FwdArgs &a, int H, hipStream_t st) {
                  //    extension) and every CU has at least two trials.
         const int cus = nsd_num_cus();
         const int force_nb = nsd_diag_forced_fwd48();           // 0 in the product library (diagnostic build: nsd_diag_force_fwd48)
+        if (force_nb == 8 && nsd_lstm2_fwd48w_ok(a)) return nsd_lstm2_fwd48w_launch(a, a.B < cus ? a.B : cus, st);      // experiment (nsd_lstm2_fwd48w.hip)
         const bool x4 = nsd_lstm2_fwd48x4_ok(a) && (force_nb ? force_nb == 4 : a.B >= X4_MIN_B);
         if (x4) {
             // The backward pass of the same batch takes lstm2_bwd48x4_kernel under the same rule (nsd_lstm2_bwd_launch below; its domain

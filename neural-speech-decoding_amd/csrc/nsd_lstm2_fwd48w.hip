@@ -1,0 +1,303 @@
+// nsd_lstm2_fwd48w.hip -- EXPERIMENTAL forward of the two-layer H=48 LSTM (training launches without the fused head): ONE WAVE PER LAYER.
+//
+// Replaces self.lstm(x) (Neuro-Alpha-App/Utilities/lstm_eeg_model.py:16-22,34) like nsd_lstm2_fwd48.hip, with the recurrence laid out
+// the way tools/micro/wave_cell.hip probed it at the end of round 4: lane = unit (48 of 64 lanes), ALL four gates x 48 inputs in the
+// lane (96 v_pk_fma_f32 per step, 192 weight registers of a 512-register wave), no cross-lane reduction, the cell in the lane, h to the
+// wave's own LDS ring and back as broadcast reads -- program order instead of a workgroup barrier.  Four waves, one per SIMD:
+//   wave 0  "X"   layer-0 input projection W_ih0 x_t + biases (exp2 arguments) and the dropout multipliers of step t -> LDS rings
+//   wave 1  "L0"  layer 0: W_hh0 h0[t-1] + X[t], cell, h0[t] and the masked h0[t] -> rings; saves gates, h, c, in1
+//   wave 2  "P"   layer-1 input projection W_ih1 in1[t] + biases -> ring
+//   wave 3  "L1"  layer 1: W_hh1 h1[t-1] + P[t], cell; saves gates, h, c (+ top)
+// The waves hand off through PROGRESS COUNTERS in LDS (steps completed per role; a producer also waits for its consumer before it
+// overwrites a ring entry), not through s_barrier: with a workgroup barrier per step the probe's recurrence took 977 instead of 733
+// cycles.  Diagnostic twin only (nsd_diag_force_fwd48(8)): the train step's fused head has not been ported to this shape.
+#include "nsd_args.h"
+
+namespace {
+
+#ifndef NSD_F48W_SLEEP
+#define NSD_F48W_SLEEP 0            // s_sleep between two looks at a progress counter (0: spin)
+#endif
+#ifndef NSD_F48W_NOSAVE
+#define NSD_F48W_NOSAVE 0          // timing experiment: no saved activations
+#endif
+constexpr int H = 48;
+constexpr int RG = 16;               // ring depth (steps)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__host__ __device__ constexpr float gate_scale(const int g) { return g == 2 ? -2.f * LOG2E_F : -LOG2E_F; }
+constexpr float KC = -2.f * LOG2E_F;
+
+struct WSmem {
+    float xp[RG][H][4];              // layer-0 input projection + biases, exp2 arguments: [t % RG][unit][gate]
+    float pb[RG][H][4];              // layer-1 input projection + biases
+    float mk[RG][64];                // layer-0 dropout multipliers
+    float h0[RG][64], in1[RG][64], h1[RG][64];
+    int cnt[4];                      // steps completed: X, L0, P, L1
+};
+
+// (file-scope LDS object; the progress counters are read and written through address_space(3) volatile pointers: as generic volatile
+// pointers hipcc emits flat accesses behind an aperture test and trips over it -- "Illegal instruction detected: Operand has
+// incorrect register class", V_CMP_NE_U32_e32 0, $src_shared_base)
+__shared__ __align__(16) WSmem g_wsm;
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ int peek(const int who) { return *(const volatile lds_int *)(&g_wsm.cnt[who]); }
+// wait until role `who` has completed step t (cnt > t).  `seen` caches the last value read: while the producer is two or more steps
+// ahead no LDS read stands in front of the step
+__device__ __forceinline__ void wait_step(const int who, const int t, int &seen) {
+    if (seen <= t) {
+        while ((seen = peek(who)) <= t) { if (NSD_F48W_SLEEP) __builtin_amdgcn_s_sleep(NSD_F48W_SLEEP); }
+    }
+    asm volatile("" ::: "memory");
+}
+// a producer must not overwrite ring entries its consumer has not read: checked every eighth step for the eight steps that follow
+__device__ __forceinline__ void wait_room(const int cons, const int t) {
+    if ((t & 7) == 0) {
+        while (peek(cons) + RG - 8 <= t) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void publish(const int me, const int t, const int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's LDS writes of the step are in LDS
+    if (lane == 0) *(volatile lds_int *)(&g_wsm.cnt[me]) = t + 1;
+}
+
+// all four gates of unit u against a 48-vector in LDS (broadcast reads: every lane reads the same 16 bytes)
+__device__ __forceinline__ void gates_dot(const f32x2 (&w)[4][24], const float *v, f32x2 (&acc)[4]) {
+#pragma unroll
+    for (int qb = 0; qb < 12; qb += 4) {                              // four reads in flight at a time (16 registers, not 48)
+        f32x4 hv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const f32x4 *>(v + 4 * (qb + q));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 lo = {hv[q][0], hv[q][1]}, hi = {hv[q][2], hv[q][3]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { acc[g] = pk_fma(w[g][2 * (qb + q)], lo, acc[g]); acc[g] = pk_fma(w[g][2 * (qb + q) + 1], hi, acc[g]); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__device__ __forceinline__ void load_w(const float *w, const int u, f32x2 (&wv)[4][24]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            wv[g][q].x = gate_scale(g) * w[(size_t)(g * H + u) * H + 2 * q];
+            wv[g][q].y = gate_scale(g) * w[(size_t)(g * H + u) * H + 2 * q + 1];
+        }
+}
+struct Cell { float i, f, g, o, c, h; };
+// arg[g]: exp2 arguments of the four gates (pre-activation x -log2e, tanh row x -2 log2e); c: cell state (updated)
+__device__ __forceinline__ Cell cell(const float (&arg)[4], float &c) {
+    Cell r;
+    r.i = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg[0]));
+    r.f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg[1]));
+    r.g = fmaf(2.f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg[2])), -1.f);
+    r.o = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg[3]));
+    c = fmaf(r.f, c, r.i * r.g);
+    r.c = c;
+    r.h = r.o * fmaf(2.f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(KC * c)), -1.f);
+    return r;
+}
+
+__device__ __attribute__((noinline)) void role_x(const Lstm2FwdArgs &a_in, const int lane) {
+    // (a called function with its own register allocation: inlined into one kernel body, the four roles' 192 weight registers each pushed
+    // hipcc into 88 AGPRs and ~60 v_accvgpr copies per step; uniform_copy: nsd_common.h)
+    WSmem &sm = g_wsm;
+    const Lstm2FwdArgs a = uniform_copy(a_in);
+    const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
+    const bool live = lane < H;
+    const int T = a.T, B = a.B, C = a.C;
+    (void)C; (void)live; (void)sm;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 64) { sm.h0[RG - 1][threadIdx.x] = 0.f; sm.h1[RG - 1][threadIdx.x] = 0.f; }      // h(-1) = 0
+        __syncthreads();
+        const size_t bt = (size_t)b * T;
+        {
+            // ---- X: W_ih0 x_t + b_ih0 + b_hh0 (scaled), multipliers
+            float wx[4][8], bias[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bias[g] = gate_scale(g) * (a.b_ih0[g * H + u] + a.b_hh0[g * H + u]);
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) wx[g][ch] = ch < C ? gate_scale(g) * a.w_ih0[(size_t)(g * H + u) * C + ch] : 0.f;
+            }
+            // (x and the explicit multipliers are requested XD steps ahead: a load per step used at once put the memory latency on every step)
+            constexpr int XD = 8;
+            float xq[XD][8], mq[XD];
+#pragma unroll
+            for (int k = 0; k < XD; ++k) {
+                const int tc = k < T ? k : T - 1;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) xq[k][ch] = ch < C ? a.x[(bt + tc) * C + ch] : 0.f;
+                mq[k] = (a.mask && !a.rng.on) ? a.mask[(bt + tc) * H + u] : 1.f;
+            }
+            // (the loop runs to a multiple of XD: the surplus steps write ring entries nobody reads and count past T, which nobody waits for)
+            for (int t0 = 0; t0 < T; t0 += XD) {
+#pragma unroll
+                for (int k = 0; k < XD; ++k) {
+                    const int t = t0 + k;
+                    float mkv = mq[k];
+                    if (a.rng.on) mkv = nsd_rand_u32(a.rng.seed, a.rng.base, (bt + (t < T ? t : T - 1)) * H + u) < a.rng.thr_lstm ? 0.f : a.rng.keep_lstm;
+                    f32x4 acc = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[g] = fmaf(wx[g][ch], xq[k][ch], acc[g]);
+                    const int tn = t + XD < T ? t + XD : T - 1;
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) xq[k][ch] = ch < C ? a.x[(bt + tn) * C + ch] : 0.f;
+                    mq[k] = (a.mask && !a.rng.on) ? a.mask[(bt + tn) * H + u] : 1.f;
+                    wait_room(1, t);
+                    if (live) { *reinterpret_cast<f32x4 *>(&g_wsm.xp[t & (RG - 1)][u][0]) = acc; g_wsm.mk[t & (RG - 1)][u] = mkv; }
+                    publish(0, t, lane);
+                }
+            }
+        }
+        __syncthreads();                                             // every role has finished the trial: the rings and counters may be reset
+    }
+}
+
+__device__ __attribute__((noinline)) void role_l0(const Lstm2FwdArgs &a_in, const int lane) {
+    // (a called function with its own register allocation: inlined into one kernel body, the four roles' 192 weight registers each pushed
+    // hipcc into 88 AGPRs and ~60 v_accvgpr copies per step; uniform_copy: nsd_common.h)
+    WSmem &sm = g_wsm;
+    const Lstm2FwdArgs a = uniform_copy(a_in);
+    const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
+    const bool live = lane < H;
+    const int T = a.T, B = a.B, C = a.C;
+    (void)C; (void)live; (void)sm;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 64) { sm.h0[RG - 1][threadIdx.x] = 0.f; sm.h1[RG - 1][threadIdx.x] = 0.f; }      // h(-1) = 0
+        __syncthreads();
+        const size_t bt = (size_t)b * T;
+        {
+            // ---- L0
+            f32x2 wv[4][24];
+            load_w(a.w_hh0, u, wv);
+            float c = 0.f;
+            int seen = 0;
+            for (int t = 0; t < T; ++t) {
+                wait_step(0, t, seen);
+                const f32x4 xa = *reinterpret_cast<const f32x4 *>(&sm.xp[t & (RG - 1)][u][0]);
+                const float mkv = sm.mk[t & (RG - 1)][u];
+                f32x2 acc[4] = {{xa[0], 0.f}, {xa[1], 0.f}, {xa[2], 0.f}, {xa[3], 0.f}};
+                gates_dot(wv, &sm.h0[(t + RG - 1) & (RG - 1)][0], acc);
+                const float arg[4] = {acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y};
+                const Cell r = cell(arg, c);
+                const float hm = r.h * mkv;
+                wait_room(2, t);
+                if (live) { sm.h0[t & (RG - 1)][u] = r.h; sm.in1[t & (RG - 1)][u] = hm; }
+                publish(1, t, lane);
+                if (live && !NSD_F48W_NOSAVE) {                     // saved activations of the step (behind the hand-off)
+                    const size_t e = (bt + t) * H + u;
+                    *reinterpret_cast<f32x4 *>(a.gact0 + e * 4) = f32x4{r.i, r.f, r.g, r.o};
+                    a.hseq0[e] = r.h; a.cseq0[e] = r.c; a.inseq[e] = hm;
+                }
+            }
+        }
+        __syncthreads();                                             // every role has finished the trial: the rings and counters may be reset
+    }
+}
+
+__device__ __attribute__((noinline)) void role_p(const Lstm2FwdArgs &a_in, const int lane) {
+    // (a called function with its own register allocation: inlined into one kernel body, the four roles' 192 weight registers each pushed
+    // hipcc into 88 AGPRs and ~60 v_accvgpr copies per step; uniform_copy: nsd_common.h)
+    WSmem &sm = g_wsm;
+    const Lstm2FwdArgs a = uniform_copy(a_in);
+    const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
+    const bool live = lane < H;
+    const int T = a.T, B = a.B, C = a.C;
+    (void)C; (void)live; (void)sm;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 64) { sm.h0[RG - 1][threadIdx.x] = 0.f; sm.h1[RG - 1][threadIdx.x] = 0.f; }      // h(-1) = 0
+        __syncthreads();
+        const size_t bt = (size_t)b * T;
+        {
+            // ---- P: W_ih1 in1_t + b_ih1 + b_hh1
+            f32x2 wv[4][24];
+            load_w(a.w_ih1, u, wv);
+            float bias[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[g] = gate_scale(g) * (a.b_ih1[g * H + u] + a.b_hh1[g * H + u]);
+            int seen = 0;
+            for (int t = 0; t < T; ++t) {
+                wait_step(1, t, seen);
+                f32x2 acc[4] = {{bias[0], 0.f}, {bias[1], 0.f}, {bias[2], 0.f}, {bias[3], 0.f}};
+                gates_dot(wv, &sm.in1[t & (RG - 1)][0], acc);
+                wait_room(3, t);
+                if (live) *reinterpret_cast<f32x4 *>(&sm.pb[t & (RG - 1)][u][0]) = f32x4{acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y};
+                publish(2, t, lane);
+            }
+        }
+        __syncthreads();                                             // every role has finished the trial: the rings and counters may be reset
+    }
+}
+
+__device__ __attribute__((noinline)) void role_l1(const Lstm2FwdArgs &a_in, const int lane) {
+    // (a called function with its own register allocation: inlined into one kernel body, the four roles' 192 weight registers each pushed
+    // hipcc into 88 AGPRs and ~60 v_accvgpr copies per step; uniform_copy: nsd_common.h)
+    WSmem &sm = g_wsm;
+    const Lstm2FwdArgs a = uniform_copy(a_in);
+    const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
+    const bool live = lane < H;
+    const int T = a.T, B = a.B, C = a.C;
+    (void)C; (void)live; (void)sm;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 64) { sm.h0[RG - 1][threadIdx.x] = 0.f; sm.h1[RG - 1][threadIdx.x] = 0.f; }      // h(-1) = 0
+        __syncthreads();
+        const size_t bt = (size_t)b * T;
+        {
+            // ---- L1
+            f32x2 wv[4][24];
+            load_w(a.w_hh1, u, wv);
+            float c = 0.f;
+            int seen = 0;
+            for (int t = 0; t < T; ++t) {
+                wait_step(2, t, seen);
+                const f32x4 pa = *reinterpret_cast<const f32x4 *>(&sm.pb[t & (RG - 1)][u][0]);
+                f32x2 acc[4] = {{pa[0], 0.f}, {pa[1], 0.f}, {pa[2], 0.f}, {pa[3], 0.f}};
+                gates_dot(wv, &sm.h1[(t + RG - 1) & (RG - 1)][0], acc);
+                const float arg[4] = {acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y};
+                const Cell r = cell(arg, c);
+                if (live) sm.h1[t & (RG - 1)][u] = r.h;
+                publish(3, t, lane);
+                if (live && !NSD_F48W_NOSAVE) {
+                    const size_t e = (bt + t) * H + u;
+                    *reinterpret_cast<f32x4 *>(a.gact1 + e * 4) = f32x4{r.i, r.f, r.g, r.o};
+                    a.hseq1[e] = r.h; a.cseq1[e] = r.c;
+                    if (a.top) a.top[e] = r.h;
+                }
+            }
+        }
+        __syncthreads();                                             // every role has finished the trial: the rings and counters may be reset
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm2_fwd48w_kernel(Lstm2FwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0)      role_x(a, lane);
+    else if (wave == 1) role_l0(a, lane);
+    else if (wave == 2) role_p(a, lane);
+    else                role_l1(a, lane);
+}
+
+}  // namespace
+
+bool nsd_lstm2_fwd48w_ok(const Lstm2FwdArgs &a) {
+    return !a.residual && !a.logits_out && !a.head_train && a.C <= 8 && a.gact0 && a.hseq0 && a.cseq0 && a.inseq && a.gact1 && a.hseq1 && a.cseq1;
+}
+
+int nsd_lstm2_fwd48w_launch(const Lstm2FwdArgs &a, int grid, hipStream_t st) {
+    if (!nsd_lstm2_fwd48w_ok(a)) { nsd_set_error("lstm2_fwd48w: launch outside the kernel's domain"); return NSD_E_INVALID; }
+    hipLaunchKernelGGL(lstm2_fwd48w_kernel, dim3(grid), dim3(256), 0, st, a);
+    NSD_CHECK_LAUNCH("lstm2_fwd48w");
+    return NSD_OK;
+}

@@ -1271,3 +1271,38 @@ def test_batch_bands_of_the_dispatch_vs_oracle(nsd, dev, ref_state, B, T):
         _grad_close(out["grads"], g_ref, D, rtol=3e-4)
         res.append(out["grads"])
     assert np.abs(res[0] - res[1]).max() <= 2e-5 * np.abs(res[0]).max()
+
+
+@pytest.mark.parametrize("B,T", [(5, 33), (3, 250), (300, 7)])
+def test_experimental_one_wave_per_layer_forward_matches_the_product_kernel(nsd, dev, ref_state, B, T):
+    """csrc/nsd_lstm2_fwd48w.hip (diagnostic twin only, nsd_diag_force_fwd48(8)): the recurrence of a layer in ONE wave, the waves handing
+    off through progress counters in LDS instead of the step barrier -- an experiment kept honest: same written regions of the workspace
+    as the product's one-trial forward, every saved activation within 2e-5, logits within 1e-4 of the oracle (explicit masks and the
+    streams drawn in the kernel)."""
+    from nsd_amd import _lib, ops
+    spec = ops.ModelSpec()
+    flat_np = orc.flatten_state(ref_state, D)
+    flat = _t(flat_np, dev)
+    xn = synth_x(B, T, seed=B + T)
+    x = _t(xn, dev)
+    dln, sln, dhn = counter_masks(B, T, 48, 32, seed=3 * B + T)
+    fw = orc.forward(flat_np, xn, D, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn) if hasattr(orc, "forward") else None
+    with _lib.diagnostic_library():
+        try:
+            res = {}
+            for nb in (1, 8):
+                ops.force_fwd48(nb)
+                ws = ops.new_workspace(spec, B, T, dev)
+                ws.fill_(float("nan"))
+                logits, _ = ops.train_forward(spec, flat, x, ws, drop_lstm=_t(dln, dev), rrelu_slope=_t(sln, dev), drop_head=_t(dhn, dev))
+                torch.cuda.synchronize()
+                res[nb] = (logits.clone(), ws.clone())
+        finally:
+            ops.force_fwd48(0)
+    (l1, w1), (l8, w8) = res[1], res[8]
+    assert torch.isfinite(l8).all()
+    assert bool((torch.isnan(w1) == torch.isnan(w8)).all())
+    assert torch.where(torch.isnan(w1), torch.zeros_like(w1), (w1 - w8).abs()).max().item() < 2e-5
+    assert (l1 - l8).abs().max().item() < 2e-5
+    if fw is not None:
+        assert np.abs(l8.cpu().numpy() - fw["logits"]).max() < LOGIT_TOL
