@@ -88,6 +88,14 @@ __device__ __forceinline__ void load_w(const float *w, const int u, f32x2 (&wv)[
             wv[g][q].y = gate_scale(g) * w[(size_t)(g * H + u) * H + 2 * q + 1];
         }
 }
+// one field of the argument block as a wave-uniform value (the block arrives behind a pointer in VGPRs; a role copies the few fields it
+// uses, not all ~170 dwords)
+template <class P> __device__ __forceinline__ P *uni(P *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<P *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
 struct Cell { float i, f, g, o, c, h; };
 // arg[g]: exp2 arguments of the four gates (pre-activation x -log2e, tanh row x -2 log2e); c: cell state (updated)
 __device__ __forceinline__ Cell cell(const float (&arg)[4], float &c) {
@@ -103,13 +111,21 @@ __device__ __forceinline__ Cell cell(const float (&arg)[4], float &c) {
 }
 
 __device__ __attribute__((noinline)) void role_x(const Lstm2FwdArgs &a_in, const int lane) {
-    // (a called function with its own register allocation: inlined into one kernel body, the four roles' 192 weight registers each pushed
-    // hipcc into 88 AGPRs and ~60 v_accvgpr copies per step; uniform_copy: nsd_common.h)
+    // (a called function with its own register allocation; only the fields it uses are made wave-uniform: uni())
     WSmem &sm = g_wsm;
-    const Lstm2FwdArgs a = uniform_copy(a_in);
+    struct {
+        const float *x, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *mask;
+        float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
+        RngArgs rng;
+    } a;
+    a.x = uni(a_in.x); a.w_ih0 = uni(a_in.w_ih0); a.w_hh0 = uni(a_in.w_hh0); a.b_ih0 = uni(a_in.b_ih0); a.b_hh0 = uni(a_in.b_hh0);
+    a.w_ih1 = uni(a_in.w_ih1); a.w_hh1 = uni(a_in.w_hh1); a.b_ih1 = uni(a_in.b_ih1); a.b_hh1 = uni(a_in.b_hh1); a.mask = uni(a_in.mask);
+    a.hseq0 = uni(a_in.hseq0); a.hseq1 = uni(a_in.hseq1); a.cseq0 = uni(a_in.cseq0); a.cseq1 = uni(a_in.cseq1);
+    a.gact0 = uni(a_in.gact0); a.gact1 = uni(a_in.gact1); a.inseq = uni(a_in.inseq); a.top = uni(a_in.top);
+    a.rng = uniform_copy(a_in.rng);
     const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
     const bool live = lane < H;
-    const int T = a.T, B = a.B, C = a.C;
+    const int T = uni(a_in.T), B = uni(a_in.B), C = uni(a_in.C);
     (void)C; (void)live; (void)sm;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
@@ -162,13 +178,21 @@ __device__ __attribute__((noinline)) void role_x(const Lstm2FwdArgs &a_in, const
 }
 
 __device__ __attribute__((noinline)) void role_l0(const Lstm2FwdArgs &a_in, const int lane) {
-    // (a called function with its own register allocation: inlined into one kernel body, the four roles' 192 weight registers each pushed
-    // hipcc into 88 AGPRs and ~60 v_accvgpr copies per step; uniform_copy: nsd_common.h)
+    // (a called function with its own register allocation; only the fields it uses are made wave-uniform: uni())
     WSmem &sm = g_wsm;
-    const Lstm2FwdArgs a = uniform_copy(a_in);
+    struct {
+        const float *x, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *mask;
+        float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
+        RngArgs rng;
+    } a;
+    a.x = uni(a_in.x); a.w_ih0 = uni(a_in.w_ih0); a.w_hh0 = uni(a_in.w_hh0); a.b_ih0 = uni(a_in.b_ih0); a.b_hh0 = uni(a_in.b_hh0);
+    a.w_ih1 = uni(a_in.w_ih1); a.w_hh1 = uni(a_in.w_hh1); a.b_ih1 = uni(a_in.b_ih1); a.b_hh1 = uni(a_in.b_hh1); a.mask = uni(a_in.mask);
+    a.hseq0 = uni(a_in.hseq0); a.hseq1 = uni(a_in.hseq1); a.cseq0 = uni(a_in.cseq0); a.cseq1 = uni(a_in.cseq1);
+    a.gact0 = uni(a_in.gact0); a.gact1 = uni(a_in.gact1); a.inseq = uni(a_in.inseq); a.top = uni(a_in.top);
+    a.rng = uniform_copy(a_in.rng);
     const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
     const bool live = lane < H;
-    const int T = a.T, B = a.B, C = a.C;
+    const int T = uni(a_in.T), B = uni(a_in.B), C = uni(a_in.C);
     (void)C; (void)live; (void)sm;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
@@ -205,13 +229,21 @@ __device__ __attribute__((noinline)) void role_l0(const Lstm2FwdArgs &a_in, cons
 }
 
 __device__ __attribute__((noinline)) void role_p(const Lstm2FwdArgs &a_in, const int lane) {
-    // (a called function with its own register allocation: inlined into one kernel body, the four roles' 192 weight registers each pushed
-    // hipcc into 88 AGPRs and ~60 v_accvgpr copies per step; uniform_copy: nsd_common.h)
+    // (a called function with its own register allocation; only the fields it uses are made wave-uniform: uni())
     WSmem &sm = g_wsm;
-    const Lstm2FwdArgs a = uniform_copy(a_in);
+    struct {
+        const float *x, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *mask;
+        float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
+        RngArgs rng;
+    } a;
+    a.x = uni(a_in.x); a.w_ih0 = uni(a_in.w_ih0); a.w_hh0 = uni(a_in.w_hh0); a.b_ih0 = uni(a_in.b_ih0); a.b_hh0 = uni(a_in.b_hh0);
+    a.w_ih1 = uni(a_in.w_ih1); a.w_hh1 = uni(a_in.w_hh1); a.b_ih1 = uni(a_in.b_ih1); a.b_hh1 = uni(a_in.b_hh1); a.mask = uni(a_in.mask);
+    a.hseq0 = uni(a_in.hseq0); a.hseq1 = uni(a_in.hseq1); a.cseq0 = uni(a_in.cseq0); a.cseq1 = uni(a_in.cseq1);
+    a.gact0 = uni(a_in.gact0); a.gact1 = uni(a_in.gact1); a.inseq = uni(a_in.inseq); a.top = uni(a_in.top);
+    a.rng = uniform_copy(a_in.rng);
     const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
     const bool live = lane < H;
-    const int T = a.T, B = a.B, C = a.C;
+    const int T = uni(a_in.T), B = uni(a_in.B), C = uni(a_in.C);
     (void)C; (void)live; (void)sm;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
@@ -240,13 +272,21 @@ __device__ __attribute__((noinline)) void role_p(const Lstm2FwdArgs &a_in, const
 }
 
 __device__ __attribute__((noinline)) void role_l1(const Lstm2FwdArgs &a_in, const int lane) {
-    // (a called function with its own register allocation: inlined into one kernel body, the four roles' 192 weight registers each pushed
-    // hipcc into 88 AGPRs and ~60 v_accvgpr copies per step; uniform_copy: nsd_common.h)
+    // (a called function with its own register allocation; only the fields it uses are made wave-uniform: uni())
     WSmem &sm = g_wsm;
-    const Lstm2FwdArgs a = uniform_copy(a_in);
+    struct {
+        const float *x, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *mask;
+        float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
+        RngArgs rng;
+    } a;
+    a.x = uni(a_in.x); a.w_ih0 = uni(a_in.w_ih0); a.w_hh0 = uni(a_in.w_hh0); a.b_ih0 = uni(a_in.b_ih0); a.b_hh0 = uni(a_in.b_hh0);
+    a.w_ih1 = uni(a_in.w_ih1); a.w_hh1 = uni(a_in.w_hh1); a.b_ih1 = uni(a_in.b_ih1); a.b_hh1 = uni(a_in.b_hh1); a.mask = uni(a_in.mask);
+    a.hseq0 = uni(a_in.hseq0); a.hseq1 = uni(a_in.hseq1); a.cseq0 = uni(a_in.cseq0); a.cseq1 = uni(a_in.cseq1);
+    a.gact0 = uni(a_in.gact0); a.gact1 = uni(a_in.gact1); a.inseq = uni(a_in.inseq); a.top = uni(a_in.top);
+    a.rng = uniform_copy(a_in.rng);
     const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
     const bool live = lane < H;
-    const int T = a.T, B = a.B, C = a.C;
+    const int T = uni(a_in.T), B = uni(a_in.B), C = uni(a_in.C);
     (void)C; (void)live; (void)sm;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
