@@ -18,25 +18,24 @@ namespace {
 #ifndef NSD_F48W_SLEEP
 #define NSD_F48W_SLEEP 0            // s_sleep between two looks at a progress counter (0: spin)
 #endif
-#ifndef NSD_F48W_NOSAVE
-#define NSD_F48W_NOSAVE 0          // timing experiment: no saved activations
-#endif
 constexpr int H = 48;
-constexpr int RG = 16;               // ring depth (steps)
+constexpr int RG = 8;                // ring depth = unroll of the time loops: every ring slot is an immediate offset
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __host__ __device__ constexpr float gate_scale(const int g) { return g == 2 ? -2.f * LOG2E_F : -LOG2E_F; }
 constexpr float KC = -2.f * LOG2E_F;
 
+// (64 columns everywhere: lanes 48..63 compute a copy of unit 47 and write it to columns nobody reads -- no EXEC games in the loops)
 struct WSmem {
-    float xp[RG][H][4];              // layer-0 input projection + biases, exp2 arguments: [t % RG][unit][gate]
-    float pb[RG][H][4];              // layer-1 input projection + biases
+    float xp[RG][64][4];             // layer-0 input projection + biases, exp2 arguments: [t % RG][unit][gate]
+    float pb[RG][64][4];             // layer-1 input projection + biases
     float mk[RG][64];                // layer-0 dropout multipliers
     float h0[RG][64], in1[RG][64], h1[RG][64];
     int cnt[4];                      // steps completed: X, L0, P, L1
 };
-
 // (file-scope LDS object; the progress counters are read and written through address_space(3) volatile pointers: as generic volatile
 // pointers hipcc emits flat accesses behind an aperture test and trips over it -- "Illegal instruction detected: Operand has
 // incorrect register class", V_CMP_NE_U32_e32 0, $src_shared_base)
@@ -51,10 +50,10 @@ __device__ __forceinline__ void wait_step(const int who, const int t, int &seen)
     }
     asm volatile("" ::: "memory");
 }
-// a producer must not overwrite ring entries its consumer has not read: checked every eighth step for the eight steps that follow
+// a producer must not overwrite ring entries its consumer has not read: checked once per RG / 2 steps for the steps that follow
 __device__ __forceinline__ void wait_room(const int cons, const int t) {
-    if ((t & 7) == 0) {
-        while (peek(cons) + RG - 8 <= t) __builtin_amdgcn_s_sleep(1);
+    if ((t & (RG / 2 - 1)) == 0) {
+        while (peek(cons) + RG / 2 <= t) { if (NSD_F48W_SLEEP) __builtin_amdgcn_s_sleep(NSD_F48W_SLEEP); }
     }
     asm volatile("" ::: "memory");
 }
@@ -63,10 +62,10 @@ __device__ __forceinline__ void publish(const int me, const int t, const int lan
     if (lane == 0) *(volatile lds_int *)(&g_wsm.cnt[me]) = t + 1;
 }
 
-// all four gates of unit u against a 48-vector in LDS (broadcast reads: every lane reads the same 16 bytes)
+// all four gates of a unit against a 48-vector in LDS (broadcast reads: every lane reads the same 16 bytes), four reads in flight
 __device__ __forceinline__ void gates_dot(const f32x2 (&w)[4][24], const float *v, f32x2 (&acc)[4]) {
 #pragma unroll
-    for (int qb = 0; qb < 12; qb += 4) {                              // four reads in flight at a time (16 registers, not 48)
+    for (int qb = 0; qb < 12; qb += 4) {
         f32x4 hv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const f32x4 *>(v + 4 * (qb + q));
@@ -76,7 +75,6 @@ __device__ __forceinline__ void gates_dot(const f32x2 (&w)[4][24], const float *
 #pragma unroll
             for (int g = 0; g < 4; ++g) { acc[g] = pk_fma(w[g][2 * (qb + q)], lo, acc[g]); acc[g] = pk_fma(w[g][2 * (qb + q) + 1], hi, acc[g]); }
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 __device__ __forceinline__ void load_w(const float *w, const int u, f32x2 (&wv)[4][24]) {
@@ -96,6 +94,9 @@ template <class P> __device__ __forceinline__ P *uni(P *p) {
     return reinterpret_cast<P *>(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ int uni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ rsrc_t rsrc_of(const float *base, const long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
 struct Cell { float i, f, g, o, c, h; };
 // arg[g]: exp2 arguments of the four gates (pre-activation x -log2e, tanh row x -2 log2e); c: cell state (updated)
 __device__ __forceinline__ Cell cell(const float (&arg)[4], float &c) {
@@ -109,224 +110,148 @@ __device__ __forceinline__ Cell cell(const float (&arg)[4], float &c) {
     r.h = r.o * fmaf(2.f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(KC * c)), -1.f);
     return r;
 }
+// every role walks the trials of its workgroup with the same two barriers per trial; time loops run to a multiple of RG (surplus steps
+// compute on ring contents nobody uses and save nothing)
+#define TRIAL_LOOP_BEGIN                                                                                                    \
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {                                                                       \
+        if (threadIdx.x < 4) g_wsm.cnt[threadIdx.x] = 0;                                                                    \
+        if (threadIdx.x < 64) { g_wsm.h0[RG - 1][threadIdx.x] = 0.f; g_wsm.h1[RG - 1][threadIdx.x] = 0.f; }                \
+        __syncthreads();                                                                                                    \
+        const size_t bt = (size_t)b * T;
+#define TRIAL_LOOP_END                                                                                                      \
+        __syncthreads();                                                                                                    \
+    }
+constexpr unsigned VOFF_DROP = 0x80000000u;
 
 __device__ __attribute__((noinline)) void role_x(const Lstm2FwdArgs &a_in, const int lane) {
-    // (a called function with its own register allocation; only the fields it uses are made wave-uniform: uni())
-    WSmem &sm = g_wsm;
-    struct {
-        const float *x, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *mask;
-        float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
-        RngArgs rng;
-    } a;
-    a.x = uni(a_in.x); a.w_ih0 = uni(a_in.w_ih0); a.w_hh0 = uni(a_in.w_hh0); a.b_ih0 = uni(a_in.b_ih0); a.b_hh0 = uni(a_in.b_hh0);
-    a.w_ih1 = uni(a_in.w_ih1); a.w_hh1 = uni(a_in.w_hh1); a.b_ih1 = uni(a_in.b_ih1); a.b_hh1 = uni(a_in.b_hh1); a.mask = uni(a_in.mask);
-    a.hseq0 = uni(a_in.hseq0); a.hseq1 = uni(a_in.hseq1); a.cseq0 = uni(a_in.cseq0); a.cseq1 = uni(a_in.cseq1);
-    a.gact0 = uni(a_in.gact0); a.gact1 = uni(a_in.gact1); a.inseq = uni(a_in.inseq); a.top = uni(a_in.top);
-    a.rng = uniform_copy(a_in.rng);
-    const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
-    const bool live = lane < H;
+    const float *x = uni(a_in.x), *w_ih0 = uni(a_in.w_ih0), *b_ih0 = uni(a_in.b_ih0), *b_hh0 = uni(a_in.b_hh0), *mask = uni(a_in.mask);
+    const RngArgs rng = uniform_copy(a_in.rng);
     const int T = uni(a_in.T), B = uni(a_in.B), C = uni(a_in.C);
-    (void)C; (void)live; (void)sm;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
-        if (threadIdx.x < 64) { sm.h0[RG - 1][threadIdx.x] = 0.f; sm.h1[RG - 1][threadIdx.x] = 0.f; }      // h(-1) = 0
-        __syncthreads();
-        const size_t bt = (size_t)b * T;
-        {
-            // ---- X: W_ih0 x_t + b_ih0 + b_hh0 (scaled), multipliers
-            float wx[4][8], bias[4];
+    const int u = lane < H ? lane : H - 1;
+    float wx[4][8], bias[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bias[g] = gate_scale(g) * (a.b_ih0[g * H + u] + a.b_hh0[g * H + u]);
+    for (int g = 0; g < 4; ++g) {
+        bias[g] = gate_scale(g) * (b_ih0[g * H + u] + b_hh0[g * H + u]);
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch) wx[g][ch] = ch < C ? gate_scale(g) * a.w_ih0[(size_t)(g * H + u) * C + ch] : 0.f;
-            }
-            // (x and the explicit multipliers are requested XD steps ahead: a load per step used at once put the memory latency on every step)
-            constexpr int XD = 8;
-            float xq[XD][8], mq[XD];
+        for (int ch = 0; ch < 8; ++ch) wx[g][ch] = ch < C ? gate_scale(g) * w_ih0[(size_t)(g * H + u) * C + ch] : 0.f;
+    }
+    TRIAL_LOOP_BEGIN
+        // (x and the explicit multipliers are requested RG steps ahead: a load used in the step that issued it put the memory latency on every step)
+        float xq[RG][8], mq[RG];
 #pragma unroll
-            for (int k = 0; k < XD; ++k) {
-                const int tc = k < T ? k : T - 1;
+        for (int k = 0; k < RG; ++k) {
+            const int tc = k < T ? k : T - 1;
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch) xq[k][ch] = ch < C ? a.x[(bt + tc) * C + ch] : 0.f;
-                mq[k] = (a.mask && !a.rng.on) ? a.mask[(bt + tc) * H + u] : 1.f;
-            }
-            // (the loop runs to a multiple of XD: the surplus steps write ring entries nobody reads and count past T, which nobody waits for)
-            for (int t0 = 0; t0 < T; t0 += XD) {
+            for (int ch = 0; ch < 8; ++ch) xq[k][ch] = ch < C ? x[(bt + tc) * C + ch] : 0.f;
+            mq[k] = (mask && !rng.on) ? mask[(bt + tc) * H + u] : 1.f;
+        }
+        for (int t0 = 0; t0 < T; t0 += RG) {
 #pragma unroll
-                for (int k = 0; k < XD; ++k) {
-                    const int t = t0 + k;
-                    float mkv = mq[k];
-                    if (a.rng.on) mkv = nsd_rand_u32(a.rng.seed, a.rng.base, (bt + (t < T ? t : T - 1)) * H + u) < a.rng.thr_lstm ? 0.f : a.rng.keep_lstm;
-                    f32x4 acc = {bias[0], bias[1], bias[2], bias[3]};
+            for (int k = 0; k < RG; ++k) {
+                const int t = t0 + k;
+                float mkv = mq[k];
+                if (rng.on) mkv = nsd_rand_u32(rng.seed, rng.base, (bt + (t < T ? t : T - 1)) * H + u) < rng.thr_lstm ? 0.f : rng.keep_lstm;
+                f32x4 acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
-                    for (int ch = 0; ch < 8; ++ch)
+                for (int ch = 0; ch < 8; ++ch)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = fmaf(wx[g][ch], xq[k][ch], acc[g]);
-                    const int tn = t + XD < T ? t + XD : T - 1;
+                    for (int g = 0; g < 4; ++g) acc[g] = fmaf(wx[g][ch], xq[k][ch], acc[g]);
+                const int tn = t + RG < T ? t + RG : T - 1;
 #pragma unroll
-                    for (int ch = 0; ch < 8; ++ch) xq[k][ch] = ch < C ? a.x[(bt + tn) * C + ch] : 0.f;
-                    mq[k] = (a.mask && !a.rng.on) ? a.mask[(bt + tn) * H + u] : 1.f;
-                    wait_room(1, t);
-                    if (live) { *reinterpret_cast<f32x4 *>(&g_wsm.xp[t & (RG - 1)][u][0]) = acc; g_wsm.mk[t & (RG - 1)][u] = mkv; }
-                    publish(0, t, lane);
-                }
+                for (int ch = 0; ch < 8; ++ch) xq[k][ch] = ch < C ? x[(bt + tn) * C + ch] : 0.f;
+                mq[k] = (mask && !rng.on) ? mask[(bt + tn) * H + u] : 1.f;
+                wait_room(1, t);
+                *reinterpret_cast<f32x4 *>(&g_wsm.xp[k][lane][0]) = acc;
+                g_wsm.mk[k][lane] = mkv;
+                publish(0, t, lane);
             }
         }
-        __syncthreads();                                             // every role has finished the trial: the rings and counters may be reset
-    }
+    TRIAL_LOOP_END
 }
 
-__device__ __attribute__((noinline)) void role_l0(const Lstm2FwdArgs &a_in, const int lane) {
-    // (a called function with its own register allocation; only the fields it uses are made wave-uniform: uni())
-    WSmem &sm = g_wsm;
-    struct {
-        const float *x, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *mask;
-        float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
-        RngArgs rng;
-    } a;
-    a.x = uni(a_in.x); a.w_ih0 = uni(a_in.w_ih0); a.w_hh0 = uni(a_in.w_hh0); a.b_ih0 = uni(a_in.b_ih0); a.b_hh0 = uni(a_in.b_hh0);
-    a.w_ih1 = uni(a_in.w_ih1); a.w_hh1 = uni(a_in.w_hh1); a.b_ih1 = uni(a_in.b_ih1); a.b_hh1 = uni(a_in.b_hh1); a.mask = uni(a_in.mask);
-    a.hseq0 = uni(a_in.hseq0); a.hseq1 = uni(a_in.hseq1); a.cseq0 = uni(a_in.cseq0); a.cseq1 = uni(a_in.cseq1);
-    a.gact0 = uni(a_in.gact0); a.gact1 = uni(a_in.gact1); a.inseq = uni(a_in.inseq); a.top = uni(a_in.top);
-    a.rng = uniform_copy(a_in.rng);
-    const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
-    const bool live = lane < H;
-    const int T = uni(a_in.T), B = uni(a_in.B), C = uni(a_in.C);
-    (void)C; (void)live; (void)sm;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
-        if (threadIdx.x < 64) { sm.h0[RG - 1][threadIdx.x] = 0.f; sm.h1[RG - 1][threadIdx.x] = 0.f; }      // h(-1) = 0
-        __syncthreads();
-        const size_t bt = (size_t)b * T;
-        {
-            // ---- L0
-            f32x2 wv[4][24];
-            load_w(a.w_hh0, u, wv);
-            float c = 0.f;
-            int seen = 0;
-            for (int t = 0; t < T; ++t) {
-                wait_step(0, t, seen);
-                const f32x4 xa = *reinterpret_cast<const f32x4 *>(&sm.xp[t & (RG - 1)][u][0]);
-                const float mkv = sm.mk[t & (RG - 1)][u];
-                f32x2 acc[4] = {{xa[0], 0.f}, {xa[1], 0.f}, {xa[2], 0.f}, {xa[3], 0.f}};
-                gates_dot(wv, &sm.h0[(t + RG - 1) & (RG - 1)][0], acc);
+// LAYER 0: X ring + own h0 ring -> h0, in1 rings; LAYER 1: P ring + own h1 ring -> h1 ring.  Saves: gates (16 bytes), h, c (+ in1 / top)
+// as buffer stores with the time offset in a scalar register.
+template <int LAYER>
+__device__ __attribute__((noinline)) void role_cell(const Lstm2FwdArgs &a_in, const int lane) {
+    const float *w_hh = uni(LAYER == 0 ? a_in.w_hh0 : a_in.w_hh1);
+    float *gact = uni(LAYER == 0 ? a_in.gact0 : a_in.gact1), *hseq = uni(LAYER == 0 ? a_in.hseq0 : a_in.hseq1);
+    float *cseq = uni(LAYER == 0 ? a_in.cseq0 : a_in.cseq1), *aux = uni(LAYER == 0 ? a_in.inseq : a_in.top);
+    const int T = uni(a_in.T), B = uni(a_in.B);
+    const int u = lane < H ? lane : H - 1;
+    const unsigned vo4 = lane < H ? 4u * lane : VOFF_DROP, vo16 = lane < H ? 16u * lane : VOFF_DROP;
+    f32x2 wv[4][24];
+    load_w(w_hh, u, wv);
+    TRIAL_LOOP_BEGIN
+        const long row4 = (long)T * H * 4;
+        const rsrc_t r_g = rsrc_of(gact + bt * H * 4, row4 * 4), r_h = rsrc_of(hseq + bt * H, row4), r_c = rsrc_of(cseq + bt * H, row4);
+        const rsrc_t r_a = rsrc_of(aux ? aux + bt * H : hseq, aux ? row4 : 0);
+        float c = 0.f;
+        int seen = 0;
+        for (int t0 = 0; t0 < T; t0 += RG) {
+#pragma unroll
+            for (int k = 0; k < RG; ++k) {
+                const int t = t0 + k;
+                wait_step(LAYER == 0 ? 0 : 2, t, seen);
+                const f32x4 pa = *reinterpret_cast<const f32x4 *>(LAYER == 0 ? &g_wsm.xp[k][lane][0] : &g_wsm.pb[k][lane][0]);
+                f32x2 acc[4] = {{pa[0], 0.f}, {pa[1], 0.f}, {pa[2], 0.f}, {pa[3], 0.f}};
+                gates_dot(wv, LAYER == 0 ? &g_wsm.h0[(k + RG - 1) & (RG - 1)][0] : &g_wsm.h1[(k + RG - 1) & (RG - 1)][0], acc);
                 const float arg[4] = {acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y};
                 const Cell r = cell(arg, c);
-                const float hm = r.h * mkv;
-                wait_room(2, t);
-                if (live) { sm.h0[t & (RG - 1)][u] = r.h; sm.in1[t & (RG - 1)][u] = hm; }
-                publish(1, t, lane);
-                if (live && !NSD_F48W_NOSAVE) {                     // saved activations of the step (behind the hand-off)
-                    const size_t e = (bt + t) * H + u;
-                    *reinterpret_cast<f32x4 *>(a.gact0 + e * 4) = f32x4{r.i, r.f, r.g, r.o};
-                    a.hseq0[e] = r.h; a.cseq0[e] = r.c; a.inseq[e] = hm;
+                float hm = r.h;
+                if (LAYER == 0) {
+                    hm = r.h * g_wsm.mk[k][lane];
+                    wait_room(2, t);
+                    g_wsm.h0[k][lane] = r.h;
+                    g_wsm.in1[k][lane] = hm;
+                } else {
+                    g_wsm.h1[k][lane] = r.h;
+                }
+                publish(LAYER == 0 ? 1 : 3, t, lane);
+                if (t < T) {                                            // saved activations of the step (behind the hand-off)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{r.i, r.f, r.g, r.o}), r_g, (int)vo16, t * (H * 16), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r.h), r_h, (int)vo4, t * (H * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r.c), r_c, (int)vo4, t * (H * 4), 0);
+                    if (aux) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hm), r_a, (int)vo4, t * (H * 4), 0);
                 }
             }
         }
-        __syncthreads();                                             // every role has finished the trial: the rings and counters may be reset
-    }
+    TRIAL_LOOP_END
 }
 
 __device__ __attribute__((noinline)) void role_p(const Lstm2FwdArgs &a_in, const int lane) {
-    // (a called function with its own register allocation; only the fields it uses are made wave-uniform: uni())
-    WSmem &sm = g_wsm;
-    struct {
-        const float *x, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *mask;
-        float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
-        RngArgs rng;
-    } a;
-    a.x = uni(a_in.x); a.w_ih0 = uni(a_in.w_ih0); a.w_hh0 = uni(a_in.w_hh0); a.b_ih0 = uni(a_in.b_ih0); a.b_hh0 = uni(a_in.b_hh0);
-    a.w_ih1 = uni(a_in.w_ih1); a.w_hh1 = uni(a_in.w_hh1); a.b_ih1 = uni(a_in.b_ih1); a.b_hh1 = uni(a_in.b_hh1); a.mask = uni(a_in.mask);
-    a.hseq0 = uni(a_in.hseq0); a.hseq1 = uni(a_in.hseq1); a.cseq0 = uni(a_in.cseq0); a.cseq1 = uni(a_in.cseq1);
-    a.gact0 = uni(a_in.gact0); a.gact1 = uni(a_in.gact1); a.inseq = uni(a_in.inseq); a.top = uni(a_in.top);
-    a.rng = uniform_copy(a_in.rng);
-    const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
-    const bool live = lane < H;
-    const int T = uni(a_in.T), B = uni(a_in.B), C = uni(a_in.C);
-    (void)C; (void)live; (void)sm;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
-        if (threadIdx.x < 64) { sm.h0[RG - 1][threadIdx.x] = 0.f; sm.h1[RG - 1][threadIdx.x] = 0.f; }      // h(-1) = 0
-        __syncthreads();
-        const size_t bt = (size_t)b * T;
-        {
-            // ---- P: W_ih1 in1_t + b_ih1 + b_hh1
-            f32x2 wv[4][24];
-            load_w(a.w_ih1, u, wv);
-            float bias[4];
+    const float *w_ih1 = uni(a_in.w_ih1), *b_ih1 = uni(a_in.b_ih1), *b_hh1 = uni(a_in.b_hh1);
+    const int T = uni(a_in.T), B = uni(a_in.B);
+    const int u = lane < H ? lane : H - 1;
+    f32x2 wv[4][24];
+    load_w(w_ih1, u, wv);
+    float bias[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bias[g] = gate_scale(g) * (a.b_ih1[g * H + u] + a.b_hh1[g * H + u]);
-            int seen = 0;
-            for (int t = 0; t < T; ++t) {
+    for (int g = 0; g < 4; ++g) bias[g] = gate_scale(g) * (b_ih1[g * H + u] + b_hh1[g * H + u]);
+    TRIAL_LOOP_BEGIN
+        (void)bt;
+        int seen = 0;
+        for (int t0 = 0; t0 < T; t0 += RG) {
+#pragma unroll
+            for (int k = 0; k < RG; ++k) {
+                const int t = t0 + k;
                 wait_step(1, t, seen);
                 f32x2 acc[4] = {{bias[0], 0.f}, {bias[1], 0.f}, {bias[2], 0.f}, {bias[3], 0.f}};
-                gates_dot(wv, &sm.in1[t & (RG - 1)][0], acc);
+                gates_dot(wv, &g_wsm.in1[k][0], acc);
                 wait_room(3, t);
-                if (live) *reinterpret_cast<f32x4 *>(&sm.pb[t & (RG - 1)][u][0]) = f32x4{acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y};
+                *reinterpret_cast<f32x4 *>(&g_wsm.pb[k][lane][0]) = f32x4{acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y};
                 publish(2, t, lane);
             }
         }
-        __syncthreads();                                             // every role has finished the trial: the rings and counters may be reset
-    }
-}
-
-__device__ __attribute__((noinline)) void role_l1(const Lstm2FwdArgs &a_in, const int lane) {
-    // (a called function with its own register allocation; only the fields it uses are made wave-uniform: uni())
-    WSmem &sm = g_wsm;
-    struct {
-        const float *x, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *mask;
-        float *hseq0, *hseq1, *cseq0, *cseq1, *gact0, *gact1, *inseq, *top;
-        RngArgs rng;
-    } a;
-    a.x = uni(a_in.x); a.w_ih0 = uni(a_in.w_ih0); a.w_hh0 = uni(a_in.w_hh0); a.b_ih0 = uni(a_in.b_ih0); a.b_hh0 = uni(a_in.b_hh0);
-    a.w_ih1 = uni(a_in.w_ih1); a.w_hh1 = uni(a_in.w_hh1); a.b_ih1 = uni(a_in.b_ih1); a.b_hh1 = uni(a_in.b_hh1); a.mask = uni(a_in.mask);
-    a.hseq0 = uni(a_in.hseq0); a.hseq1 = uni(a_in.hseq1); a.cseq0 = uni(a_in.cseq0); a.cseq1 = uni(a_in.cseq1);
-    a.gact0 = uni(a_in.gact0); a.gact1 = uni(a_in.gact1); a.inseq = uni(a_in.inseq); a.top = uni(a_in.top);
-    a.rng = uniform_copy(a_in.rng);
-    const int u = lane < H ? lane : H - 1;                          // lanes 48..63 repeat unit 47 (their writes are switched off)
-    const bool live = lane < H;
-    const int T = uni(a_in.T), B = uni(a_in.B), C = uni(a_in.C);
-    (void)C; (void)live; (void)sm;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        if (threadIdx.x < 4) sm.cnt[threadIdx.x] = 0;
-        if (threadIdx.x < 64) { sm.h0[RG - 1][threadIdx.x] = 0.f; sm.h1[RG - 1][threadIdx.x] = 0.f; }      // h(-1) = 0
-        __syncthreads();
-        const size_t bt = (size_t)b * T;
-        {
-            // ---- L1
-            f32x2 wv[4][24];
-            load_w(a.w_hh1, u, wv);
-            float c = 0.f;
-            int seen = 0;
-            for (int t = 0; t < T; ++t) {
-                wait_step(2, t, seen);
-                const f32x4 pa = *reinterpret_cast<const f32x4 *>(&sm.pb[t & (RG - 1)][u][0]);
-                f32x2 acc[4] = {{pa[0], 0.f}, {pa[1], 0.f}, {pa[2], 0.f}, {pa[3], 0.f}};
-                gates_dot(wv, &sm.h1[(t + RG - 1) & (RG - 1)][0], acc);
-                const float arg[4] = {acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y};
-                const Cell r = cell(arg, c);
-                if (live) sm.h1[t & (RG - 1)][u] = r.h;
-                publish(3, t, lane);
-                if (live && !NSD_F48W_NOSAVE) {
-                    const size_t e = (bt + t) * H + u;
-                    *reinterpret_cast<f32x4 *>(a.gact1 + e * 4) = f32x4{r.i, r.f, r.g, r.o};
-                    a.hseq1[e] = r.h; a.cseq1[e] = r.c;
-                    if (a.top) a.top[e] = r.h;
-                }
-            }
-        }
-        __syncthreads();                                             // every role has finished the trial: the rings and counters may be reset
-    }
+    TRIAL_LOOP_END
 }
 
 __global__ __launch_bounds__(256) void lstm2_fwd48w_kernel(Lstm2FwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave == 0)      role_x(a, lane);
-    else if (wave == 1) role_l0(a, lane);
+    else if (wave == 1) role_cell<0>(a, lane);
     else if (wave == 2) role_p(a, lane);
-    else                role_l1(a, lane);
+    else                role_cell<1>(a, lane);
 }
 
 }  // namespace
