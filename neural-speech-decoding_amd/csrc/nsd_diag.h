@@ -26,7 +26,7 @@ int nsd_seq_profile(int32_t enable);
 int nsd_seq_profile_read(int32_t kind, float *total_ms, int32_t *count);
 // Pin the H = 48 forward instantiation of the fp32 fast path: 1 / 2 / 4 trials per workgroup (4 = nsd_lstm2_fwd48x4.hip where it
 // applies), 0 = the product's own choice.  Process-wide; tests compare the instantiations on the same inputs.
-int nsd_diag_force_fwd48(int32_t nb);
+int nsd_diag_force_fwd48(int32_t nb);       // 0 = the product's choice, 1 / 2 / 4 trials per workgroup, 8 = the experimental one-wave-per-layer kernel (nsd_lstm2_fwd48w.hip: unfused training launches)
 int nsd_diag_force_bwd48(int32_t nb);       // 0 = the product's choice, 2 = nsd_lstm2_bwd48.hip, 4 = nsd_lstm2_bwd48x4.hip where it applies
 }
 #endif

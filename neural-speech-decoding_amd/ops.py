@@ -127,7 +127,8 @@ def set_seq_diag_flags(l2_exchange: bool = True, spread_groups: bool = False, fu
 
 def force_fwd48(nb: int) -> None:
     """Diagnostic build only (inside `with _lib.diagnostic_library():`): pin the H = 48 forward instantiation of the fp32 fast path
-    to 1 / 2 / 4 trials per workgroup (4 = the matrix-pipe kernel where it applies), 0 = the product's own choice.  Process-wide
+    to 1 / 2 / 4 trials per workgroup (4 = the matrix-pipe kernel where it applies), 8 = the experimental one-wave-per-layer kernel
+    (unfused training launches only), 0 = the product's own choice.  Process-wide
     state of the DIAGNOSTIC library: reset it to 0 before leaving the block."""
     if not _lib.diag_active():
         raise NsdError("force_fwd48: the instantiation can be pinned in the diagnostic build only: use `with _lib.diagnostic_library():`")
