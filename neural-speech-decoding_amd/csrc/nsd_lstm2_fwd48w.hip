@@ -57,24 +57,35 @@ __device__ __forceinline__ void wait_room(const int cons, const int t) {
     }
     asm volatile("" ::: "memory");
 }
+// (no wait in front of the counter: the LDS takes a wave's requests in order, so whoever reads the new count reads behind the step's
+// data writes; every lane writes the same word -- no EXEC switch: 141 -> 134 us)
 __device__ __forceinline__ void publish(const int me, const int t, const int lane) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's LDS writes of the step are in LDS
-    if (lane == 0) *(volatile lds_int *)(&g_wsm.cnt[me]) = t + 1;
+    asm volatile("" ::: "memory");
+    *(volatile lds_int *)(&g_wsm.cnt[me]) = t + 1;
+    (void)lane;
 }
 
-// all four gates of a unit against a 48-vector in LDS (broadcast reads: every lane reads the same 16 bytes), four reads in flight
+// all four gates of a unit against a 48-vector in LDS (broadcast reads: every lane reads the same 16 bytes).  The reads run one batch
+// of four AHEAD of the FMAs that use them (8 in flight, 32 registers): with four in flight and the next four requested behind the
+// batch's FMAs three LDS latencies stood in every step (130 -> 124 us); all twelve at once do not fit beside 192 weight registers.
+// (Requesting a step's first batch right behind the previous step's write of h, ahead of its stores: no gain, 127 us.)
 __device__ __forceinline__ void gates_dot(const f32x2 (&w)[4][24], const float *v, f32x2 (&acc)[4]) {
+    f32x4 hv[3][4];
 #pragma unroll
-    for (int qb = 0; qb < 12; qb += 4) {
-        f32x4 hv[4];
+    for (int q = 0; q < 4; ++q) hv[0][q] = *reinterpret_cast<const f32x4 *>(v + 4 * q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const f32x4 *>(v + 4 * (qb + q));
+    for (int qb = 0; qb < 3; ++qb) {
+        if (qb < 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[qb + 1][q] = *reinterpret_cast<const f32x4 *>(v + 4 * (4 * (qb + 1) + q));
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x2 lo = {hv[q][0], hv[q][1]}, hi = {hv[q][2], hv[q][3]};
+            const f32x2 lo = {hv[qb][q][0], hv[qb][q][1]}, hi = {hv[qb][q][2], hv[qb][q][3]};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { acc[g] = pk_fma(w[g][2 * (qb + q)], lo, acc[g]); acc[g] = pk_fma(w[g][2 * (qb + q) + 1], hi, acc[g]); }
+            for (int g = 0; g < 4; ++g) { acc[g] = pk_fma(w[g][2 * (4 * qb + q)], lo, acc[g]); acc[g] = pk_fma(w[g][2 * (4 * qb + q) + 1], hi, acc[g]); }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 __device__ __forceinline__ void load_w(const float *w, const int u, f32x2 (&wv)[4][24]) {
@@ -193,9 +204,10 @@ __device__ __attribute__((noinline)) void role_cell(const Lstm2FwdArgs &a_in, co
                 const int t = t0 + k;
                 wait_step(LAYER == 0 ? 0 : 2, t, seen);
                 const f32x4 pa = *reinterpret_cast<const f32x4 *>(LAYER == 0 ? &g_wsm.xp[k][lane][0] : &g_wsm.pb[k][lane][0]);
-                f32x2 acc[4] = {{pa[0], 0.f}, {pa[1], 0.f}, {pa[2], 0.f}, {pa[3], 0.f}};
+                // (the projection is added BEHIND the products: as the accumulators' seed its LDS latency stood in front of the first FMA: 134 -> 130 us)
+                f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
                 gates_dot(wv, LAYER == 0 ? &g_wsm.h0[(k + RG - 1) & (RG - 1)][0] : &g_wsm.h1[(k + RG - 1) & (RG - 1)][0], acc);
-                const float arg[4] = {acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y};
+                const float arg[4] = {(acc[0].x + pa[0]) + acc[0].y, (acc[1].x + pa[1]) + acc[1].y, (acc[2].x + pa[2]) + acc[2].y, (acc[3].x + pa[3]) + acc[3].y};
                 const Cell r = cell(arg, c);
                 float hm = r.h;
                 if (LAYER == 0) {
