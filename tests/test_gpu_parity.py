@@ -1306,3 +1306,30 @@ def test_experimental_one_wave_per_layer_forward_matches_the_product_kernel(nsd,
     assert (l1 - l8).abs().max().item() < 2e-5
     if fw is not None:
         assert np.abs(l8.cpu().numpy() - fw["logits"]).max() < LOGIT_TOL
+
+
+@pytest.mark.parametrize("nb", [1, 4])
+def test_every_sequence_length_up_to_40(nsd, dev, ref_state, nb):
+    """Every T from 1 to 40 (window, chunk, lag and padding boundaries of the backward kernels: 16-step weight-gradient windows, 8-step
+    stage chunks, the four-step hand-off with its five-step lag in the one-trial kernel; 4-step windows and 16-step padding in the
+    four-trial kernel) against the oracle: logits 1e-4, gradients 3e-4 of each tensor's largest element."""
+    from nsd_amd import _lib, ops
+    flat_np = orc.flatten_state(ref_state, D)
+    B = 3 if nb == 1 else 6
+    with _lib.diagnostic_library():
+        try:
+            ops.force_fwd48(nb)
+            ops.force_bwd48(2 if nb == 1 else 4)
+            for T in range(1, 41):
+                xn, yn = synth_x(B, T, seed=50 + T), synth_labels(B, seed=50 + T)
+                dln, sln, dhn = counter_masks(B, T, 48, 32, seed=9 * T + nb)
+                loss_ref, g_ref, fw = orc.loss_and_grads(flat_np, xn, yn, D, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn)
+                loss, grads, logits = _hip_loss_grads(nsd, dev, flat_np, xn, yn, drop_lstm=dln, rrelu_slope=sln, drop_head=dhn)
+                assert np.abs(logits - fw["logits"]).max() < LOGIT_TOL, T
+                try:
+                    _grad_close(grads, g_ref, D, rtol=3e-4)
+                except AssertionError as e:
+                    raise AssertionError(f"T={T}: {e}")
+        finally:
+            ops.force_fwd48(0)
+            ops.force_bwd48(0)
